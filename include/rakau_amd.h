@@ -1,0 +1,154 @@
+/*
+ * rakau_amd C ABI -- the drop-in boundary of the MI355X-native Barnes-Hut traversal engine.
+ *
+ * Every entry point replaces one symbol of the accelerator seam of bluescarni/rakau
+ * (paths relative to the reference repository):
+ *
+ *   rk_min_size()            <- rocm_min_size()             include/rakau/detail/rocm_fwd.hpp:22
+ *                               cuda_min_size()             include/rakau/detail/cuda_fwd.hpp:23
+ *   rk_has_accelerator()     <- rocm_has_accelerator()      include/rakau/detail/rocm_fwd.hpp:24
+ *   rk_device_count()        <- cuda_device_count()         include/rakau/detail/cuda_fwd.hpp:29
+ *   rk_state_create()        <- rocm_state<..>::rocm_state  include/rakau/detail/rocm_fwd.hpp:29-30
+ *                               (called from tree::rocm_init_state(), include/rakau/tree.hpp:1495-1508)
+ *   rk_state_destroy()       <- rocm_state<..>::~rocm_state include/rakau/detail/rocm_fwd.hpp:38
+ *                               (tree::rocm_reset_state(), include/rakau/tree.hpp:1511-1519)
+ *   rk_acc_pot()             <- rocm_state<..>::acc_pot<Q>  include/rakau/detail/rocm_fwd.hpp:41-42
+ *                               (called from tree::acc_pot_impl(), include/rakau/tree.hpp:3078-3094)
+ *                               cuda_acc_pot_impl<Q,..>     include/rakau/detail/cuda_fwd.hpp:25-27
+ *
+ * The remaining entry points (rk_acc_pot_device, rk_state_export/rk_state_import, rk_state_info)
+ * have no counterpart in the reference: they keep inputs/outputs resident in HBM and let a tree that
+ * was uploaded on one GPU be replicated to the other GPUs of a node (RCCL broadcast of the exported
+ * buffers) -- the replacement of the reference's multi-GPU split (src/rakau_cuda.cu:410-527).
+ *
+ * Plain C: pointers and sizes only. All functions are blocking and may be called from any thread;
+ * at most one call may be in flight per state (same contract as the reference, tree.hpp:3071-3113).
+ * Functions returning int return RK_OK or an error code; rk_last_error() then holds the message
+ * (thread-local). The C++17 header include/rakau_amd/tree.hpp maps the codes back onto the
+ * exception types the reference throws.
+ */
+#ifndef RAKAU_AMD_H
+#define RAKAU_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RK_EXPORT __attribute__((visibility("default")))
+
+/* Floating-point type of the tree (template parameter F of rakau::tree). */
+enum { RK_F32 = 0, RK_F64 = 1 };
+/* Multipole acceptance criterion (rakau::mac, include/rakau/detail/tree_fwd.hpp:46). */
+enum { RK_MAC_BH = 0, RK_MAC_BH_GEOM = 1 };
+/* Status codes; the C++ header rethrows them as the exception types listed. */
+enum {
+    RK_OK = 0,
+    RK_EINVAL = 1,    /* std::invalid_argument */
+    RK_EDOMAIN = 2,   /* std::domain_error     */
+    RK_EOVERFLOW = 3, /* std::overflow_error   */
+    RK_ERUNTIME = 4,  /* std::runtime_error (HIP failure, missing device) */
+    RK_ENOMEM = 5     /* std::bad_alloc        */
+};
+
+typedef struct rk_state rk_state;
+
+/* Message of the last failing call on this thread ("" if none). */
+RK_EXPORT const char *rk_last_error(void);
+
+/* Smallest particle range worth offloading (rocm_min_size() == 64 in the reference). */
+RK_EXPORT unsigned rk_min_size(void);
+/* 1 if at least one gfx950 device is visible. Never throws. */
+RK_EXPORT int rk_has_accelerator(void);
+/* Number of visible HIP devices (0 on failure). */
+RK_EXPORT int rk_device_count(void);
+
+/*
+ * Build the device-resident state for a constructed tree (3-D, 64-bit codes).
+ *
+ *  fp, mac     RK_F32|RK_F64, RK_MAC_BH|RK_MAC_BH_GEOM: the F and MAC template parameters.
+ *  device      HIP device ordinal.
+ *  parts       {x, y, z, m}: host arrays of nparts values of type F in Morton order
+ *              (tree::p_its_u(), tree.hpp:3638-3641).
+ *  codes       sorted Morton codes (tree::m_codes). Not needed by this engine; may be NULL.
+ *  nparts      number of particles.
+ *  tree        host array of tree_size records laid out as rakau::tree_node_t<3, F, uint64_t, MAC>
+ *              (include/rakau/detail/tree_fwd.hpp:77-116): uint64 begin, end, n_children, code, level;
+ *              F props[4] (COM x,y,z, mass); then F dim2 (bh) or F dim, delta (bh_geom).
+ *  node_stride sizeof of one record in bytes (64/80 for bh fp32/fp64, 64/88 for bh_geom).
+ *  ncrit       tree::m_ncrit. Critical nodes (the target groups, tree.hpp:794-807) are re-derived
+ *              from the node array: first node on each root->leaf path with
+ *              (end - begin <= ncrit || n_children == 0).
+ *
+ * The state owns device copies; host arrays may be released after the call returns.
+ */
+RK_EXPORT int rk_state_create(rk_state **out, int fp, int mac, int device, const void *const parts[4],
+                              const uint64_t *codes, int64_t nparts, const void *tree, int64_t tree_size,
+                              int64_t node_stride, uint64_t ncrit);
+
+RK_EXPORT void rk_state_destroy(rk_state *s);
+
+/* info[0..7] = nparts, tree_size, n_crit, max group size, fp, mac, device, ncrit. */
+RK_EXPORT int rk_state_info(const rk_state *s, int64_t info[8]);
+
+/*
+ * Copy the particle ranges of the critical nodes (the target groups): begin_end[2*i], begin_end[2*i+1].
+ * Used to snap a split to a group boundary (tree.hpp:3053-3063). n_crit entries (see rk_state_info).
+ */
+RK_EXPORT int rk_state_crit_ranges(const rk_state *s, int64_t *begin_end);
+
+/*
+ * Accelerations and/or potentials for the particles [p_begin, p_end) (Morton order).
+ *
+ *  q              0: accelerations (3 outputs), 1: potentials (1), 2: both (4: ax, ay, az, pot).
+ *  p_begin,p_end  must coincide with critical-node boundaries (p_end == nparts qualifies).
+ *  out            q-dependent number of host arrays of type F.
+ *  mac_value      theta^-2 (bh) or theta^-1 (bh_geom), as computed at tree.hpp:3303-3312.
+ *  G              gravitational constant, applied as the final multiply (tree.hpp:2986-3002).
+ *  eps2           square of the softening length (tree.hpp:3268-3281).
+ *  offset_output  nonzero: out[j] addresses element 0 of a full-size array and results are written
+ *                 at out[j] + p_begin; zero: out[j] is a compact array of p_end - p_begin values
+ *                 (same meaning as in src/rakau_rocm.cpp:114-116).
+ */
+RK_EXPORT int rk_acc_pot(rk_state *s, int q, int64_t p_begin, int64_t p_end, void *const *out, double mac_value,
+                         double G, double eps2, int offset_output);
+
+/*
+ * Same, but out[j] are DEVICE pointers (on the state's device) and the kernels are enqueued on
+ * `hip_stream` (a hipStream_t; NULL = default stream) without synchronising: results are ready
+ * when the stream reaches this point. No host transfer takes place.
+ */
+RK_EXPORT int rk_acc_pot_device(rk_state *s, int q, int64_t p_begin, int64_t p_end, void *const *d_out,
+                                double mac_value, double G, double eps2, int offset_output, void *hip_stream);
+
+/*
+ * Timing of the kernels enqueued by the last rk_acc_pot/rk_acc_pot_device call on this state,
+ * measured with HIP events on the stream the kernels ran on. Blocks until they have finished.
+ * ms[0] = elapsed milliseconds, first launch start -> last launch end.
+ */
+RK_EXPORT int rk_last_kernel_ms(rk_state *s, float *ms);
+
+/*
+ * Replication across GPUs. rk_state_export() lists the device buffers that make up a state
+ * (count <= RK_MAX_BUFFERS; ptrs/bytes are filled). A peer process allocates buffers of the same sizes
+ * on its own GPU, receives the contents (e.g. torch.distributed.broadcast over RCCL/xGMI) and calls
+ * rk_state_import() with the same meta block to obtain an equivalent state. Buffers passed to import are
+ * copied device-to-device; the caller keeps ownership of them.
+ */
+#define RK_MAX_BUFFERS 16
+#define RK_META_WORDS 32
+RK_EXPORT int rk_state_export(const rk_state *s, int *count, void **ptrs, int64_t *bytes, int64_t meta[RK_META_WORDS]);
+RK_EXPORT int rk_state_import(rk_state **out, int device, int count, void *const *ptrs, const int64_t *bytes,
+                              const int64_t meta[RK_META_WORDS]);
+
+/* Select the traversal kernel: 0 = automatic (default), 1 = wave-per-group scalar DFS,
+ * 2 = LDS interaction-list kernel. For tests and benchmarks only. */
+RK_EXPORT int rk_set_kernel_variant(rk_state *s, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

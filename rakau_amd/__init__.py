@@ -1,0 +1,9 @@
+"""rakau_amd: MI355X-native Barnes-Hut tree-traversal engine behind rakau's accs/pots API.
+
+The package holds only what the hot path needs: ``csrc/`` (hand-written HIP kernels for gfx950 and the
+C ABI of ``include/rakau_amd.h``), ``lib/`` (the built ``librakau_amd.so``) and thin ctypes plumbing.
+"""
+from . import _capi
+from .state import State, node_dtype, mac_value_of, NRES
+
+__all__ = ["State", "node_dtype", "mac_value_of", "NRES"]

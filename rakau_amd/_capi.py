@@ -1,0 +1,74 @@
+"""ctypes binding of librakau_amd.so (the C ABI declared in include/rakau_amd.h).
+
+Plumbing only: loads the in-tree shared library and declares the prototypes. The product path fails
+loudly if the HIP library is missing -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librakau_amd.so")
+
+RK_F32, RK_F64 = 0, 1
+RK_MAC_BH, RK_MAC_BH_GEOM = 0, 1
+RK_MAX_BUFFERS, RK_META_WORDS = 16, 32
+
+# Status code -> Python exception mirroring the C++ exception types of the reference
+# (std::invalid_argument, std::domain_error, std::overflow_error, std::runtime_error, std::bad_alloc).
+_EXC = {1: ValueError, 2: ArithmeticError, 3: OverflowError, 4: RuntimeError, 5: MemoryError}
+
+# Every symbol include/rakau_amd.h declares (checked by tests/test_capi_symbols.py).
+SYMBOLS = [
+    "rk_last_error", "rk_min_size", "rk_has_accelerator", "rk_device_count", "rk_state_create", "rk_state_destroy",
+    "rk_state_info", "rk_state_crit_ranges", "rk_acc_pot", "rk_acc_pot_device", "rk_last_kernel_ms", "rk_state_export",
+    "rk_state_import", "rk_set_kernel_variant",
+    # host-side tree builder (include/rakau_amd_tree.h)
+    "rk_tree_create", "rk_tree_destroy", "rk_tree_info", "rk_tree_get", "rk_tree_nodes", "rk_tree_state",
+    "rk_tree_acc_pot", "rk_tree_exact", "rk_tree_update_particles", "rk_plummer",
+]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "rakau_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C rakau_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i64, u64, dbl, ci = C.c_void_p, C.c_int64, C.c_uint64, C.c_double, C.c_int
+    L.rk_last_error.restype = C.c_char_p
+    L.rk_min_size.restype = C.c_uint
+    L.rk_state_create.argtypes = [C.POINTER(vp), ci, ci, ci, C.POINTER(vp), vp, i64, vp, i64, i64, u64]
+    L.rk_state_destroy.argtypes = [vp]
+    L.rk_state_destroy.restype = None
+    L.rk_state_info.argtypes = [vp, C.POINTER(i64)]
+    L.rk_state_crit_ranges.argtypes = [vp, vp]
+    L.rk_acc_pot.argtypes = [vp, ci, i64, i64, C.POINTER(vp), dbl, dbl, dbl, ci]
+    L.rk_acc_pot_device.argtypes = [vp, ci, i64, i64, C.POINTER(vp), dbl, dbl, dbl, ci, vp]
+    L.rk_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.rk_state_export.argtypes = [vp, C.POINTER(ci), C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)]
+    L.rk_state_import.argtypes = [C.POINTER(vp), ci, ci, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)]
+    L.rk_set_kernel_variant.argtypes = [vp, ci]
+    if hasattr(L, "rk_tree_create"):
+        L.rk_tree_create.argtypes = [C.POINTER(vp), ci, ci, vp, vp, vp, vp, i64, dbl, u64, u64, ci]
+        L.rk_tree_destroy.argtypes = [vp]
+        L.rk_tree_destroy.restype = None
+        L.rk_tree_info.argtypes = [vp, C.POINTER(i64), C.POINTER(dbl)]
+        L.rk_tree_get.argtypes = [vp, ci, vp]
+        L.rk_tree_nodes.argtypes = [vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)]
+        L.rk_tree_state.argtypes = [vp, C.POINTER(vp)]
+        L.rk_tree_acc_pot.argtypes = [vp, ci, ci, C.POINTER(vp), dbl, dbl, dbl, C.POINTER(dbl), ci]
+        L.rk_tree_exact.argtypes = [vp, ci, ci, i64, dbl, dbl, vp]
+        L.rk_tree_update_particles.argtypes = [vp, vp, vp, vp, vp]
+        L.rk_plummer.argtypes = [ci, vp, i64, dbl, dbl, u64, ci]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc:
+        raise _EXC.get(rc, RuntimeError)(lib().rk_last_error().decode())

@@ -1,0 +1,113 @@
+// Shared declarations of the rakau_amd engine (host + device).
+#ifndef RK_COMMON_HPP
+#define RK_COMMON_HPP
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/rakau_amd.h"
+
+namespace rk
+{
+
+// Vector types per floating-point type.
+template <typename F>
+struct vt;
+template <>
+struct vt<float> {
+    using v4 = float4;
+    using v2 = float2;
+};
+template <>
+struct vt<double> {
+    using v4 = double4;
+    using v2 = double2;
+};
+
+// Number of result vectors for Q (tree_fwd.hpp:129-137 of the reference).
+__host__ __device__ constexpr int nres_of(int q)
+{
+    return q == 0 ? 3 : (q == 1 ? 1 : 4);
+}
+
+// Target groups (critical nodes) are binned by the number of targets each lane of a wave holds:
+// class c holds groups with size <= 64 * R(c); the last class is served by the block-per-group kernel.
+constexpr int n_classes = 5;
+__host__ __device__ constexpr int class_R(int c)
+{
+    return c == 0 ? 1 : (c == 1 ? 2 : (c == 2 ? 4 : 8));
+}
+inline int class_of(int64_t size)
+{
+    if (size <= 64) return 0;
+    if (size <= 128) return 1;
+    if (size <= 256) return 2;
+    if (size <= 512) return 3;
+    return 4;
+}
+
+// Kernel parameter block (passed by value).
+template <typename F>
+struct kparams {
+    const typename vt<F>::v4 *part4;    // particles, Morton order: x, y, z, m
+    const typename vt<F>::v4 *node_com; // nodes, depth-first order: COM x, y, z, mass
+    const typename vt<F>::v2 *node_mac; // {dim2, 0} (bh) or {dim, delta} (bh_geom)
+    const uint4 *node_topo;             // {n_children, begin, end, child-table slot}
+    const uint4 *crit;                  // target groups: {begin, end, node index, size}
+    const uint32_t *child_tab;          // 8 child node indices per internal node (0 = none)
+    uint32_t n_nodes;
+    F mac_value, eps2, G;
+    F *out[4];
+    uint32_t out_sub; // value subtracted from the particle index when writing (compact output)
+};
+
+struct error : std::runtime_error {
+    int code;
+    error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+#define RK_HIP(expr)                                                                                                   \
+    do {                                                                                                               \
+        hipError_t e_ = (expr);                                                                                        \
+        if (e_ != hipSuccess) {                                                                                        \
+            throw ::rk::error(e_ == hipErrorOutOfMemory ? RK_ENOMEM : RK_ERUNTIME,                                     \
+                              std::string("HIP call failed: " #expr ": ") + hipGetErrorString(e_));                    \
+        }                                                                                                              \
+    } while (0)
+
+} // namespace rk
+
+// Device buffer indices in rk_state::buf (also the export order).
+enum { RK_BUF_PART4 = 0, RK_BUF_NODE_COM, RK_BUF_NODE_MAC, RK_BUF_NODE_TOPO, RK_BUF_CRIT, RK_BUF_CHILD, RK_BUF_CLASS, RK_NBUF };
+
+struct rk_state {
+    int fp = 0, mac = 0, device = 0;
+    int64_t nparts = 0, tree_size = 0, n_crit = 0, max_group = 0, n_internal = 0;
+    uint64_t ncrit = 0;
+    void *buf[RK_NBUF] = {};
+    int64_t buf_bytes[RK_NBUF] = {};
+    // Host mirrors used to map a particle range onto groups.
+    std::vector<int64_t> crit_begin, crit_end;
+    std::vector<uint32_t> class_list[rk::n_classes]; // ascending group ids per class
+    int64_t class_off[rk::n_classes + 1] = {};       // offsets into the concatenated device list
+    // Output scratch for rk_acc_pot (host outputs).
+    void *d_out = nullptr;
+    size_t d_out_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    int variant = 0;
+};
+
+namespace rk
+{
+// Implemented in rk_kernels.hip.
+template <typename F>
+void launch_traversal(const rk_state &s, int q, const kparams<F> &p, const int64_t cls_begin[n_classes],
+                      const int64_t cls_end[n_classes], hipStream_t stream);
+} // namespace rk
+
+#endif

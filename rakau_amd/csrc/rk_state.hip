@@ -1,0 +1,622 @@
+// Host side of the rakau_amd C ABI: state creation / replication and the acc_pot entry points.
+#include "rk_common.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <memory>
+
+namespace
+{
+
+thread_local std::string g_err;
+
+template <typename Fn>
+int guard(Fn &&f) noexcept
+{
+    try {
+        f();
+        g_err.clear();
+        return RK_OK;
+    } catch (const rk::error &e) {
+        g_err = e.what();
+        return e.code;
+    } catch (const std::bad_alloc &) {
+        g_err = "out of host memory";
+        return RK_ENOMEM;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return RK_ERUNTIME;
+    }
+}
+
+struct device_guard {
+    int prev = 0;
+    explicit device_guard(int dev)
+    {
+        RK_HIP(hipGetDevice(&prev));
+        if (prev != dev) {
+            RK_HIP(hipSetDevice(dev));
+        }
+        cur = dev;
+    }
+    ~device_guard()
+    {
+        if (prev != cur) {
+            (void)hipSetDevice(prev);
+        }
+    }
+    int cur = 0;
+};
+
+void free_state(rk_state *s)
+{
+    if (!s) {
+        return;
+    }
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(s->device);
+    for (auto &b : s->buf) {
+        if (b) {
+            (void)hipFree(b);
+        }
+    }
+    if (s->d_out) {
+        (void)hipFree(s->d_out);
+    }
+    if (s->ev0) {
+        (void)hipEventDestroy(s->ev0);
+    }
+    if (s->ev1) {
+        (void)hipEventDestroy(s->ev1);
+    }
+    (void)hipSetDevice(prev);
+    delete s;
+}
+
+struct state_deleter {
+    void operator()(rk_state *s) const
+    {
+        free_state(s);
+    }
+};
+using state_ptr = std::unique_ptr<rk_state, state_deleter>;
+
+void alloc_upload(rk_state &s, int which, const void *host, size_t bytes)
+{
+    s.buf_bytes[which] = static_cast<int64_t>(bytes);
+    if (!bytes) {
+        return;
+    }
+    RK_HIP(hipMalloc(&s.buf[which], bytes));
+    if (host) {
+        RK_HIP(hipMemcpy(s.buf[which], host, bytes, hipMemcpyHostToDevice));
+    }
+}
+
+// Build the host mirrors (group ranges, class lists) from the crit array.
+void build_host_mirrors(rk_state &s, const std::vector<uint4> &crit)
+{
+    s.n_crit = static_cast<int64_t>(crit.size());
+    s.crit_begin.resize(crit.size());
+    s.crit_end.resize(crit.size());
+    s.max_group = 0;
+    for (auto &l : s.class_list) {
+        l.clear();
+    }
+    for (size_t i = 0; i < crit.size(); ++i) {
+        s.crit_begin[i] = crit[i].x;
+        s.crit_end[i] = crit[i].y;
+        const int64_t size = static_cast<int64_t>(crit[i].y) - crit[i].x;
+        s.max_group = std::max(s.max_group, size);
+        s.class_list[rk::class_of(size)].push_back(static_cast<uint32_t>(i));
+    }
+    s.class_off[0] = 0;
+    for (int c = 0; c < rk::n_classes; ++c) {
+        s.class_off[c + 1] = s.class_off[c] + static_cast<int64_t>(s.class_list[c].size());
+    }
+}
+
+template <typename F>
+void create_impl(rk_state &s, const void *const parts[4], int64_t nparts, const void *tree, int64_t tree_size,
+                 int64_t node_stride)
+{
+    using v4 = typename rk::vt<F>::v4;
+    using v2 = typename rk::vt<F>::v2;
+    // Offsets inside rakau::tree_node_t<3, F, uint64_t, MAC> (tree_fwd.hpp:77-116 of the reference).
+    constexpr size_t off_props = 5 * sizeof(uint64_t);
+    constexpr size_t off_dim = off_props + 4 * sizeof(F);
+    const size_t min_stride = off_dim + (s.mac == RK_MAC_BH ? 1 : 2) * sizeof(F);
+    if (node_stride < static_cast<int64_t>(min_stride)) {
+        throw rk::error(RK_EINVAL, "node_stride (" + std::to_string(node_stride)
+                                       + ") is smaller than the node record of the selected F/MAC ("
+                                       + std::to_string(min_stride) + ")");
+    }
+    const auto *x = static_cast<const F *>(parts[0]), *y = static_cast<const F *>(parts[1]),
+               *z = static_cast<const F *>(parts[2]), *m = static_cast<const F *>(parts[3]);
+    const auto n = static_cast<size_t>(nparts), nn = static_cast<size_t>(tree_size);
+
+    std::vector<v4> part4(n);
+    for (size_t i = 0; i < n; ++i) {
+        part4[i].x = x[i];
+        part4[i].y = y[i];
+        part4[i].z = z[i];
+        part4[i].w = m[i];
+    }
+
+    std::vector<v4> com(nn);
+    std::vector<v2> macp(nn);
+    std::vector<uint4> topo(nn);
+    const auto *base = static_cast<const unsigned char *>(tree);
+    size_t n_internal = 0;
+    for (size_t i = 0; i < nn; ++i) {
+        const unsigned char *rec = base + i * static_cast<size_t>(node_stride);
+        uint64_t hdr[5];
+        std::memcpy(hdr, rec, sizeof(hdr));
+        F props[4], dim[2] = {F(0), F(0)};
+        std::memcpy(props, rec + off_props, sizeof(props));
+        std::memcpy(dim, rec + off_dim, (s.mac == RK_MAC_BH ? 1 : 2) * sizeof(F));
+        const uint64_t begin = hdr[0], end = hdr[1], nch = hdr[2];
+        if (begin >= end || end > static_cast<uint64_t>(nparts) || nch > nn - 1 - i) {
+            throw rk::error(RK_EINVAL, "inconsistent tree node at index " + std::to_string(i));
+        }
+        com[i].x = props[0];
+        com[i].y = props[1];
+        com[i].z = props[2];
+        com[i].w = props[3];
+        macp[i].x = dim[0];
+        macp[i].y = dim[1];
+        topo[i].x = static_cast<uint32_t>(nch);
+        topo[i].y = static_cast<uint32_t>(begin);
+        topo[i].z = static_cast<uint32_t>(end);
+        topo[i].w = nch ? static_cast<uint32_t>(n_internal++) : 0xffffffffu;
+    }
+
+    // Child table: the indices of the (up to 8) children of every internal node. In the depth-first
+    // layout the first child of node i is i + 1 and the next sibling of c is c + n_children(c) + 1
+    // (tree.hpp:2783 of the reference).
+    std::vector<uint32_t> child(n_internal * 8, 0u);
+    for (size_t i = 0; i < nn; ++i) {
+        if (!topo[i].x) {
+            continue;
+        }
+        const size_t slot = topo[i].w, last = i + topo[i].x;
+        size_t c = i + 1, k = 0;
+        while (c <= last) {
+            if (k >= 8) {
+                throw rk::error(RK_EINVAL, "tree node " + std::to_string(i) + " has more than 8 children");
+            }
+            child[slot * 8 + k++] = static_cast<uint32_t>(c);
+            c += static_cast<size_t>(topo[c].x) + 1;
+        }
+        if (c != last + 1) {
+            throw rk::error(RK_EINVAL, "inconsistent children counts below tree node " + std::to_string(i));
+        }
+    }
+
+    // Critical nodes: the first node on each root->leaf path with at most ncrit particles or without
+    // children (equivalent to the rule at tree.hpp:801-803 of the reference: a node has no children
+    // iff it holds at most max_leaf_n particles or sits at the deepest level).
+    std::vector<uint4> crit;
+    for (size_t i = 0; i < nn;) {
+        const uint64_t np = static_cast<uint64_t>(topo[i].z) - topo[i].y;
+        if (np <= s.ncrit || topo[i].x == 0) {
+            uint4 c;
+            c.x = topo[i].y;
+            c.y = topo[i].z;
+            c.z = static_cast<uint32_t>(i);
+            c.w = static_cast<uint32_t>(np);
+            crit.push_back(c);
+            i += static_cast<size_t>(topo[i].x) + 1;
+        } else {
+            ++i;
+        }
+    }
+    // The groups must tile [0, nparts).
+    uint64_t expect = 0;
+    for (const auto &c : crit) {
+        if (c.x != expect) {
+            throw rk::error(RK_EINVAL, "the critical nodes derived from the tree do not tile the particle range");
+        }
+        expect = c.y;
+    }
+    if (expect != static_cast<uint64_t>(nparts)) {
+        throw rk::error(RK_EINVAL, "the critical nodes derived from the tree do not cover all particles");
+    }
+
+    build_host_mirrors(s, crit);
+    s.n_internal = static_cast<int64_t>(n_internal);
+    std::vector<uint32_t> lists;
+    for (const auto &l : s.class_list) {
+        lists.insert(lists.end(), l.begin(), l.end());
+    }
+
+    alloc_upload(s, RK_BUF_PART4, part4.data(), part4.size() * sizeof(v4));
+    alloc_upload(s, RK_BUF_NODE_COM, com.data(), com.size() * sizeof(v4));
+    alloc_upload(s, RK_BUF_NODE_MAC, macp.data(), macp.size() * sizeof(v2));
+    alloc_upload(s, RK_BUF_NODE_TOPO, topo.data(), topo.size() * sizeof(uint4));
+    alloc_upload(s, RK_BUF_CRIT, crit.data(), crit.size() * sizeof(uint4));
+    alloc_upload(s, RK_BUF_CHILD, child.data(), child.size() * sizeof(uint32_t));
+    alloc_upload(s, RK_BUF_CLASS, lists.data(), lists.size() * sizeof(uint32_t));
+}
+
+void check_common(int fp, int mac)
+{
+    if (fp != RK_F32 && fp != RK_F64) {
+        throw rk::error(RK_EINVAL, "fp must be RK_F32 or RK_F64");
+    }
+    if (mac != RK_MAC_BH && mac != RK_MAC_BH_GEOM) {
+        throw rk::error(RK_EINVAL, "mac must be RK_MAC_BH or RK_MAC_BH_GEOM");
+    }
+}
+
+void check_device(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        throw rk::error(RK_ERUNTIME, "no HIP device is available: the rakau_amd engine needs a gfx950 GPU");
+    }
+    if (device < 0 || device >= n) {
+        throw rk::error(RK_EINVAL, "invalid device ordinal " + std::to_string(device) + " (" + std::to_string(n)
+                                       + " devices visible)");
+    }
+}
+
+// Map [p_begin, p_end) onto per-class slices of the group lists.
+void range_to_classes(const rk_state &s, int64_t p_begin, int64_t p_end, int64_t cb[rk::n_classes],
+                      int64_t ce[rk::n_classes])
+{
+    if (p_begin < 0 || p_end < p_begin || p_end > s.nparts) {
+        throw rk::error(RK_EINVAL, "invalid particle range [" + std::to_string(p_begin) + ", " + std::to_string(p_end)
+                                       + ") for a tree with " + std::to_string(s.nparts) + " particles");
+    }
+    // First group starting at or after p_begin / p_end.
+    const auto g0 = std::lower_bound(s.crit_begin.begin(), s.crit_begin.end(), p_begin) - s.crit_begin.begin();
+    const auto g1 = std::lower_bound(s.crit_begin.begin(), s.crit_begin.end(), p_end) - s.crit_begin.begin();
+    const bool b_ok = p_begin == s.nparts || (g0 < s.n_crit && s.crit_begin[g0] == p_begin);
+    const bool e_ok = p_end == s.nparts || (g1 < s.n_crit && s.crit_begin[g1] == p_end);
+    if (!b_ok || !e_ok) {
+        throw rk::error(RK_EINVAL, "the particle range [" + std::to_string(p_begin) + ", " + std::to_string(p_end)
+                                       + ") does not start and end at critical node boundaries");
+    }
+    for (int c = 0; c < rk::n_classes; ++c) {
+        const auto &l = s.class_list[c];
+        cb[c] = std::lower_bound(l.begin(), l.end(), static_cast<uint32_t>(g0)) - l.begin();
+        ce[c] = std::lower_bound(l.begin(), l.end(), static_cast<uint32_t>(g1)) - l.begin();
+    }
+}
+
+template <typename F>
+void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d_out, double mac_value, double G,
+              double eps2, int offset_output, hipStream_t stream)
+{
+    int64_t cb[rk::n_classes], ce[rk::n_classes];
+    range_to_classes(s, p_begin, p_end, cb, ce);
+    rk::kparams<F> p{};
+    p.part4 = static_cast<const typename rk::vt<F>::v4 *>(s.buf[RK_BUF_PART4]);
+    p.node_com = static_cast<const typename rk::vt<F>::v4 *>(s.buf[RK_BUF_NODE_COM]);
+    p.node_mac = static_cast<const typename rk::vt<F>::v2 *>(s.buf[RK_BUF_NODE_MAC]);
+    p.node_topo = static_cast<const uint4 *>(s.buf[RK_BUF_NODE_TOPO]);
+    p.crit = static_cast<const uint4 *>(s.buf[RK_BUF_CRIT]);
+    p.child_tab = static_cast<const uint32_t *>(s.buf[RK_BUF_CHILD]);
+    p.n_nodes = static_cast<uint32_t>(s.tree_size);
+    p.mac_value = static_cast<F>(mac_value);
+    p.eps2 = static_cast<F>(eps2);
+    p.G = static_cast<F>(G);
+    for (int k = 0; k < rk::nres_of(q); ++k) {
+        p.out[k] = static_cast<F *>(d_out[k]);
+    }
+    p.out_sub = offset_output ? 0u : static_cast<uint32_t>(p_begin);
+    if (!s.ev0) {
+        RK_HIP(hipEventCreate(&s.ev0));
+        RK_HIP(hipEventCreate(&s.ev1));
+    }
+    RK_HIP(hipEventRecord(s.ev0, stream));
+    rk::launch_traversal<F>(s, q, p, cb, ce, stream);
+    RK_HIP(hipEventRecord(s.ev1, stream));
+    s.timed = true;
+}
+
+void check_call(const rk_state *s, int q, void *const *out, double mac_value, double G, double eps2)
+{
+    if (!s) {
+        throw rk::error(RK_EINVAL, "null state");
+    }
+    if (q < 0 || q > 2) {
+        throw rk::error(RK_EINVAL, "q must be 0 (accelerations), 1 (potentials) or 2 (both)");
+    }
+    if (!out) {
+        throw rk::error(RK_EINVAL, "null output array");
+    }
+    for (int k = 0; k < rk::nres_of(q); ++k) {
+        if (!out[k]) {
+            throw rk::error(RK_EINVAL, "null output pointer");
+        }
+    }
+    // Same domain checks as tree.hpp:3299-3319 of the reference, on the transformed values.
+    if (!std::isfinite(mac_value) || mac_value <= 0.) {
+        throw rk::error(RK_EDOMAIN, "The transformed MAC value must be finite and positive, but it is "
+                                        + std::to_string(mac_value) + " instead");
+    }
+    if (!std::isfinite(eps2) || eps2 < 0.) {
+        throw rk::error(RK_EDOMAIN, "The square of the softening length must be finite and non-negative, but it is "
+                                        + std::to_string(eps2) + " instead");
+    }
+    if (!std::isfinite(G)) {
+        throw rk::error(RK_EDOMAIN, "The value of the gravitational constant G must be finite, but it is "
+                                        + std::to_string(G) + " instead");
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+const char *rk_last_error(void)
+{
+    return g_err.c_str();
+}
+
+unsigned rk_min_size(void)
+{
+    // One wavefront of targets, like rocm_min_size() (src/rakau_rocm.cpp of the reference).
+    return 64u;
+}
+
+int rk_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        return 0;
+    }
+    return n;
+}
+
+int rk_has_accelerator(void)
+{
+    const int n = rk_device_count();
+    for (int i = 0; i < n; ++i) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, i) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) {
+            return 1;
+        }
+    }
+    return 0;
+}
+
+int rk_state_create(rk_state **out, int fp, int mac, int device, const void *const parts[4], const uint64_t *codes,
+                    int64_t nparts, const void *tree, int64_t tree_size, int64_t node_stride, uint64_t ncrit)
+{
+    (void)codes;
+    return guard([&] {
+        if (!out) {
+            throw rk::error(RK_EINVAL, "null output pointer");
+        }
+        *out = nullptr;
+        check_common(fp, mac);
+        if (nparts < 0 || tree_size < 0) {
+            throw rk::error(RK_EINVAL, "negative size");
+        }
+        if (nparts > 0 && (!parts || !parts[0] || !parts[1] || !parts[2] || !parts[3] || !tree || tree_size == 0)) {
+            throw rk::error(RK_EINVAL, "null particle or tree array");
+        }
+        if (static_cast<uint64_t>(nparts) >= 0xffffffffull || static_cast<uint64_t>(tree_size) >= 0xffffffffull) {
+            throw rk::error(RK_EOVERFLOW, "The number of particles or tree nodes (" + std::to_string(nparts) + ", "
+                                              + std::to_string(tree_size)
+                                              + ") is too large for the 32-bit device indices");
+        }
+        if (!ncrit) {
+            throw rk::error(RK_EINVAL, "ncrit must be nonzero");
+        }
+        check_device(device);
+        device_guard dg(device);
+        state_ptr s(new rk_state);
+        s->fp = fp;
+        s->mac = mac;
+        s->device = device;
+        s->nparts = nparts;
+        s->tree_size = tree_size;
+        s->ncrit = ncrit;
+        if (nparts > 0) {
+            if (fp == RK_F32) {
+                create_impl<float>(*s, parts, nparts, tree, tree_size, node_stride);
+            } else {
+                create_impl<double>(*s, parts, nparts, tree, tree_size, node_stride);
+            }
+        }
+        *out = s.release();
+    });
+}
+
+void rk_state_destroy(rk_state *s)
+{
+    free_state(s);
+}
+
+int rk_state_info(const rk_state *s, int64_t info[8])
+{
+    return guard([&] {
+        if (!s || !info) {
+            throw rk::error(RK_EINVAL, "null argument");
+        }
+        info[0] = s->nparts;
+        info[1] = s->tree_size;
+        info[2] = s->n_crit;
+        info[3] = s->max_group;
+        info[4] = s->fp;
+        info[5] = s->mac;
+        info[6] = s->device;
+        info[7] = static_cast<int64_t>(s->ncrit);
+    });
+}
+
+int rk_state_crit_ranges(const rk_state *s, int64_t *begin_end)
+{
+    return guard([&] {
+        if (!s || !begin_end) {
+            throw rk::error(RK_EINVAL, "null argument");
+        }
+        for (int64_t i = 0; i < s->n_crit; ++i) {
+            begin_end[2 * i] = s->crit_begin[static_cast<size_t>(i)];
+            begin_end[2 * i + 1] = s->crit_end[static_cast<size_t>(i)];
+        }
+    });
+}
+
+int rk_acc_pot_device(rk_state *s, int q, int64_t p_begin, int64_t p_end, void *const *d_out, double mac_value,
+                      double G, double eps2, int offset_output, void *hip_stream)
+{
+    return guard([&] {
+        check_call(s, q, d_out, mac_value, G, eps2);
+        device_guard dg(s->device);
+        auto stream = static_cast<hipStream_t>(hip_stream);
+        if (s->fp == RK_F32) {
+            run_impl<float>(*s, q, p_begin, p_end, d_out, mac_value, G, eps2, offset_output, stream);
+        } else {
+            run_impl<double>(*s, q, p_begin, p_end, d_out, mac_value, G, eps2, offset_output, stream);
+        }
+    });
+}
+
+int rk_acc_pot(rk_state *s, int q, int64_t p_begin, int64_t p_end, void *const *out, double mac_value, double G,
+               double eps2, int offset_output)
+{
+    return guard([&] {
+        check_call(s, q, out, mac_value, G, eps2);
+        if (p_begin < 0 || p_end < p_begin || p_end > s->nparts) {
+            throw rk::error(RK_EINVAL, "invalid particle range");
+        }
+        const size_t fsz = s->fp == RK_F32 ? sizeof(float) : sizeof(double);
+        const auto count = static_cast<size_t>(p_end - p_begin);
+        const int nres = rk::nres_of(q);
+        if (!count) {
+            return;
+        }
+        device_guard dg(s->device);
+        const size_t need = count * fsz * static_cast<size_t>(nres);
+        if (s->d_out_bytes < need) {
+            if (s->d_out) {
+                RK_HIP(hipFree(s->d_out));
+                s->d_out = nullptr;
+                s->d_out_bytes = 0;
+            }
+            RK_HIP(hipMalloc(&s->d_out, need));
+            s->d_out_bytes = need;
+        }
+        void *d_ptrs[4] = {};
+        for (int k = 0; k < nres; ++k) {
+            d_ptrs[k] = static_cast<unsigned char *>(s->d_out) + static_cast<size_t>(k) * count * fsz;
+        }
+        if (s->fp == RK_F32) {
+            run_impl<float>(*s, q, p_begin, p_end, d_ptrs, mac_value, G, eps2, 0, nullptr);
+        } else {
+            run_impl<double>(*s, q, p_begin, p_end, d_ptrs, mac_value, G, eps2, 0, nullptr);
+        }
+        for (int k = 0; k < nres; ++k) {
+            auto *dst = static_cast<unsigned char *>(out[k]) + (offset_output ? static_cast<size_t>(p_begin) * fsz : 0);
+            RK_HIP(hipMemcpy(dst, d_ptrs[k], count * fsz, hipMemcpyDeviceToHost));
+        }
+    });
+}
+
+int rk_last_kernel_ms(rk_state *s, float *ms)
+{
+    return guard([&] {
+        if (!s || !ms) {
+            throw rk::error(RK_EINVAL, "null argument");
+        }
+        if (!s->timed) {
+            throw rk::error(RK_EINVAL, "no traversal has been run on this state");
+        }
+        device_guard dg(s->device);
+        RK_HIP(hipEventSynchronize(s->ev1));
+        RK_HIP(hipEventElapsedTime(ms, s->ev0, s->ev1));
+    });
+}
+
+int rk_state_export(const rk_state *s, int *count, void **ptrs, int64_t *bytes, int64_t meta[RK_META_WORDS])
+{
+    return guard([&] {
+        if (!s || !count || !ptrs || !bytes || !meta) {
+            throw rk::error(RK_EINVAL, "null argument");
+        }
+        *count = RK_NBUF;
+        for (int i = 0; i < RK_NBUF; ++i) {
+            ptrs[i] = s->buf[i];
+            bytes[i] = s->buf_bytes[i];
+        }
+        std::fill(meta, meta + RK_META_WORDS, int64_t(0));
+        meta[0] = 0x726b3031; // layout tag "rk01"
+        meta[1] = s->fp;
+        meta[2] = s->mac;
+        meta[3] = s->nparts;
+        meta[4] = s->tree_size;
+        meta[5] = s->n_crit;
+        meta[6] = static_cast<int64_t>(s->ncrit);
+        meta[7] = s->n_internal;
+        for (int i = 0; i < RK_NBUF; ++i) {
+            meta[8 + i] = s->buf_bytes[i];
+        }
+    });
+}
+
+int rk_state_import(rk_state **out, int device, int count, void *const *ptrs, const int64_t *bytes,
+                    const int64_t meta[RK_META_WORDS])
+{
+    return guard([&] {
+        if (!out || !ptrs || !bytes || !meta) {
+            throw rk::error(RK_EINVAL, "null argument");
+        }
+        *out = nullptr;
+        if (meta[0] != 0x726b3031 || count != RK_NBUF) {
+            throw rk::error(RK_EINVAL, "unrecognised state layout");
+        }
+        check_common(static_cast<int>(meta[1]), static_cast<int>(meta[2]));
+        check_device(device);
+        device_guard dg(device);
+        state_ptr s(new rk_state);
+        s->fp = static_cast<int>(meta[1]);
+        s->mac = static_cast<int>(meta[2]);
+        s->device = device;
+        s->nparts = meta[3];
+        s->tree_size = meta[4];
+        s->ncrit = static_cast<uint64_t>(meta[6]);
+        s->n_internal = meta[7];
+        for (int i = 0; i < RK_NBUF; ++i) {
+            if (bytes[i] != meta[8 + i]) {
+                throw rk::error(RK_EINVAL, "buffer size mismatch in rk_state_import");
+            }
+            s->buf_bytes[i] = bytes[i];
+            if (bytes[i]) {
+                if (!ptrs[i]) {
+                    throw rk::error(RK_EINVAL, "null buffer in rk_state_import");
+                }
+                RK_HIP(hipMalloc(&s->buf[i], static_cast<size_t>(bytes[i])));
+                RK_HIP(hipMemcpy(s->buf[i], ptrs[i], static_cast<size_t>(bytes[i]), hipMemcpyDeviceToDevice));
+            }
+        }
+        std::vector<uint4> crit(static_cast<size_t>(meta[5]));
+        if (!crit.empty()) {
+            if (static_cast<size_t>(bytes[RK_BUF_CRIT]) != crit.size() * sizeof(uint4)) {
+                throw rk::error(RK_EINVAL, "critical node buffer size mismatch in rk_state_import");
+            }
+            RK_HIP(hipMemcpy(crit.data(), s->buf[RK_BUF_CRIT], crit.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+        }
+        build_host_mirrors(*s, crit);
+        *out = s.release();
+    });
+}
+
+int rk_set_kernel_variant(rk_state *s, int variant)
+{
+    return guard([&] {
+        if (!s || variant < 0 || variant > 2) {
+            throw rk::error(RK_EINVAL, "invalid kernel variant");
+        }
+        s->variant = variant;
+    });
+}
+
+} // extern "C"

@@ -1,0 +1,132 @@
+"""Device-resident traversal state: the Python face of rk_state_* / rk_acc_pot (include/rakau_amd.h).
+
+Mirrors ``rakau::rocm_state<3, F, uint64_t, MAC>`` (include/rakau/detail/rocm_fwd.hpp:26-46 of the
+reference): constructed from the Morton-ordered particle arrays and the node array of a built tree,
+``acc_pot(q, p_begin, p_end, ...)`` fills caller-owned outputs.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+NRES = {0: 3, 1: 1, 2: 4}
+_FP = {np.dtype(np.float32): _capi.RK_F32, np.dtype(np.float64): _capi.RK_F64}
+_MAC = {"bh": _capi.RK_MAC_BH, "bh_geom": _capi.RK_MAC_BH_GEOM}
+
+
+def node_dtype(fp_dtype, mac="bh"):
+    """numpy structured dtype laid out as rakau::tree_node_t<3, F, uint64_t, MAC>
+    (include/rakau/detail/tree_fwd.hpp:77-116 of the reference): 64/80 bytes (bh), 64/88 (bh_geom)."""
+    f = np.dtype(fp_dtype)
+    fields = [("begin", "<u8"), ("end", "<u8"), ("n_children", "<u8"), ("code", "<u8"), ("level", "<u8"),
+              ("props", f, (4,))]
+    fields += [("dim2", f)] if mac == "bh" else [("dim", f), ("delta", f)]
+    return np.dtype(fields, align=True)
+
+
+def mac_value_of(theta, mac, dtype):
+    """theta -> theta**-2 (bh) or theta**-1 (bh_geom) in the tree's precision (tree.hpp:3303-3312)."""
+    t = np.dtype(dtype).type(theta)
+    one = np.dtype(dtype).type(1)
+    return float(one / (t * t)) if mac == "bh" else float(one / t)
+
+
+class State:
+    def __init__(self, x, y, z, m, nodes, ncrit=128, mac="bh", device=0, codes=None):
+        lib = _capi.lib()
+        x, y, z, m = (np.ascontiguousarray(v) for v in (x, y, z, m))
+        self.dtype = x.dtype
+        if self.dtype not in _FP or any(v.dtype != self.dtype for v in (y, z, m)):
+            raise TypeError("x, y, z, m must share a float32 or float64 dtype")
+        nodes = np.ascontiguousarray(nodes)
+        if nodes.dtype != node_dtype(self.dtype, mac):
+            raise TypeError("nodes must have dtype node_dtype(%s, %r)" % (self.dtype, mac))
+        self.mac = mac
+        self._h = C.c_void_p()
+        parts = (C.c_void_p * 4)(x.ctypes.data, y.ctypes.data, z.ctypes.data, m.ctypes.data)
+        _capi.check(lib.rk_state_create(C.byref(self._h), _FP[self.dtype], _MAC[mac], device, parts,
+                                        codes.ctypes.data if codes is not None else None, x.size,
+                                        nodes.ctypes.data, nodes.size, nodes.dtype.itemsize, ncrit))
+        self._read_info()
+
+    @classmethod
+    def _from_handle(cls, handle, dtype, mac):
+        self = cls.__new__(cls)
+        self._h = handle
+        self.dtype = np.dtype(dtype)
+        self.mac = mac
+        self._owned = True
+        self._read_info()
+        return self
+
+    def _read_info(self):
+        info = (C.c_int64 * 8)()
+        _capi.check(_capi.lib().rk_state_info(self._h, info))
+        self.nparts, self.tree_size, self.n_crit, self.max_group = (int(v) for v in info[:4])
+        self.device = int(info[6])
+        self.ncrit = int(info[7])
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self, "_owned", True):
+            _capi.lib().rk_state_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def crit_ranges(self):
+        out = np.empty((self.n_crit, 2), dtype=np.int64)
+        _capi.check(_capi.lib().rk_state_crit_ranges(self._h, out.ctypes.data))
+        return out
+
+    def set_variant(self, v):
+        _capi.check(_capi.lib().rk_set_kernel_variant(self._h, v))
+
+    def acc_pot(self, q, mac_value, G=1.0, eps2=0.0, p_begin=0, p_end=None, out=None, offset_output=True):
+        """rocm_state::acc_pot<Q>: host outputs (numpy). Returns the list of output arrays."""
+        p_end = self.nparts if p_end is None else p_end
+        if out is None:
+            n = self.nparts if offset_output else p_end - p_begin
+            out = [np.zeros(n, dtype=self.dtype) for _ in range(NRES[q])]
+        ptrs = (C.c_void_p * 4)(*[o.ctypes.data for o in out], *([None] * (4 - len(out))))
+        _capi.check(_capi.lib().rk_acc_pot(self._h, q, p_begin, p_end, ptrs, mac_value, G, eps2, int(offset_output)))
+        return out
+
+    def acc_pot_device(self, q, mac_value, d_ptrs, G=1.0, eps2=0.0, p_begin=0, p_end=None, offset_output=True,
+                       stream=None):
+        """Outputs stay in HBM: d_ptrs are device addresses (e.g. torch.Tensor.data_ptr())."""
+        p_end = self.nparts if p_end is None else p_end
+        ptrs = (C.c_void_p * 4)(*d_ptrs, *([None] * (4 - len(d_ptrs))))
+        _capi.check(_capi.lib().rk_acc_pot_device(self._h, q, p_begin, p_end, ptrs, mac_value, G, eps2,
+                                                  int(offset_output), stream))
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        _capi.check(_capi.lib().rk_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def export(self):
+        """(ptrs, bytes, meta) of the device buffers that make up the state (for replication)."""
+        cnt = C.c_int()
+        ptrs = (C.c_void_p * _capi.RK_MAX_BUFFERS)()
+        nbytes = (C.c_int64 * _capi.RK_MAX_BUFFERS)()
+        meta = (C.c_int64 * _capi.RK_META_WORDS)()
+        _capi.check(_capi.lib().rk_state_export(self._h, C.byref(cnt), ptrs, nbytes, meta))
+        n = cnt.value
+        return [ptrs[i] or 0 for i in range(n)], [int(nbytes[i]) for i in range(n)], [int(v) for v in meta]
+
+    @classmethod
+    def from_buffers(cls, device, ptrs, nbytes, meta):
+        h = C.c_void_p()
+        n = len(ptrs)
+        cp = (C.c_void_p * n)(*ptrs)
+        cb = (C.c_int64 * n)(*nbytes)
+        cm = (C.c_int64 * _capi.RK_META_WORDS)(*meta)
+        _capi.check(_capi.lib().rk_state_import(C.byref(h), device, n, cp, cb, cm))
+        dtype = np.float32 if meta[1] == _capi.RK_F32 else np.float64
+        mac = "bh" if meta[2] == _capi.RK_MAC_BH else "bh_geom"
+        return cls._from_handle(h, dtype, mac)
