@@ -1,0 +1,313 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: accs_u() on a Plummer sphere (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one accs_u() call (one traversal of the resident tree for all target particles) with the
+tree and the particles already in HBM and the accelerations left in HBM. For N > 1 (launched through
+torch.distributed.run, one rank per GPU) rank 0 builds the tree and uploads it, the device buffers are
+replicated with RCCL broadcasts, and every rank traverses its contiguous Morton shard of the targets
+(cut at critical-node boundaries): no data-path collective. The total number of particles is fixed as N
+grows ("scaling": "strong").
+
+Rank 0 prints ONE JSON line. Besides the contract's fields it carries `roofline` (FP32/FP64 vector-ALU
+bound: the path is rsqrt/FMA bound; the compulsory-HBM figures ride along) and, at
+N = 1, `cpu_baseline` (the CPU oracle -- a restatement of the reference's scalar CPU path -- timed on
+the host cores of the same box on the same tree).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# Workloads: BASELINE.json configs. "workload" strings name them in the JSON line.
+WORKLOADS = {
+    "plummer4m_f32": dict(n=4_000_000, dtype="float32", theta=0.75, q=0, eps=0.0,
+                          desc="3D fp32, 4M-particle Plummer, theta=0.75, accs_u() (README headline config)"),
+    "plummer100k_f32": dict(n=100_000, dtype="float32", theta=0.75, q=0, eps=0.0,
+                            desc="3D fp32, 100k-particle Plummer, theta=0.75, accs_u()"),
+    "plummer4m_f32_accpot": dict(n=4_000_000, dtype="float32", theta=0.75, q=2, eps=None,
+                                 desc="3D fp32, 4M-particle Plummer, theta=0.75, accs_pots_u() with softening"),
+    "plummer16m_f64": dict(n=16_000_000, dtype="float64", theta=0.5, q=0, eps=0.0,
+                           desc="3D fp64, 16M-particle Plummer, theta=0.5, accs_u()"),
+    "plummer64m_f32": dict(n=64_000_000, dtype="float32", theta=0.75, q=0, eps=0.0,
+                           desc="3D fp32, 64M-particle Plummer, theta=0.75, accs_u()"),
+}
+
+PEAK_TFLOPS = {"float32": 157.3, "float64": 78.6}  # vector ALU peaks, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM_GBS = 8000.0
+
+
+def plummer_numpy(n, dtype, seed=20261002, a=1.0):
+    """Plummer sphere with the transform of benchmark/common.hpp:95-124 of the reference (masses U[0.1,1.9),
+    r = a / sqrt(u^(-2/3) - 1), uniform direction), drawn from numpy's PCG64 with a recorded seed."""
+    rng = np.random.default_rng(seed)
+    f = np.dtype(dtype).type
+    m = rng.uniform(0.1, 1.9, n).astype(dtype)
+    u = rng.random(n)
+    u = np.clip(u, 1e-12, 1.0 - 1e-12)
+    r = a / np.sqrt(u ** (-2.0 / 3.0) - 1.0)
+    lon = 2.0 * np.pi * rng.random(n)
+    colat = np.arccos(np.clip(2.0 * rng.random(n) - 1.0, -1.0, 1.0))
+    x = (r * np.cos(lon) * np.sin(colat)).astype(dtype)
+    y = (r * np.sin(lon) * np.sin(colat)).astype(dtype)
+    z = (r * np.cos(colat)).astype(dtype)
+    del f
+    return m, x, y, z
+
+
+def shard_cuts(crit_ranges, nparts, world):
+    """Contiguous Morton shards with (nearly) equal particle counts, cut at critical-node boundaries."""
+    begins = crit_ranges[:, 0]
+    cuts = [0]
+    for r in range(1, world):
+        target = nparts * r // world
+        i = int(np.searchsorted(begins, target, side="left"))
+        cuts.append(int(begins[i]) if i < len(begins) else nparts)
+    cuts.append(nparts)
+    return [max(c, cuts[i - 1]) if i else c for i, c in enumerate(cuts)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="plummer4m_f32", choices=sorted(WORKLOADS))
+    ap.add_argument("--nparts", type=int, default=None, help="override the particle count of the workload")
+    ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 = default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all host cores)")
+    args = ap.parse_args()
+
+    import torch
+    import rakau_amd
+    from rakau_amd import _capi
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.nparts:
+        wl["n"] = args.nparts
+    n, dtype, theta, q = wl["n"], wl["dtype"], wl["theta"], wl["q"]
+    # Softening of the reference's leapfrog benchmark, eps = 0.45 * N^-0.73 (benchmark_leapfrog.cpp:218-223).
+    eps = wl["eps"] if wl["eps"] is not None else 0.45 * n ** -0.73
+    nres = rakau_amd.NRES[q]
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                             % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    dev = local_rank if world > 1 else 0
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+
+    lib = _capi.lib()
+    mac = "bh"
+    mac_value = rakau_amd.mac_value_of(theta, mac, dtype)
+    eps2 = float(np.dtype(dtype).type(eps) ** 2)
+
+    # ---- build (rank 0) and replicate -------------------------------------------------------------------
+    t_build = t_upload = 0.0
+    tree = None
+    if rank == 0:
+        m, x, y, z = plummer_numpy(n, dtype)
+        t0 = time.perf_counter()
+        tree = rakau_amd.Octree(x, y, z, m, mac=mac)
+        t_build = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        state = tree.state()
+        torch.cuda.synchronize()
+        t_upload = time.perf_counter() - t0
+    if world > 1:
+        payload = [None]
+        if rank == 0:
+            ptrs, nbytes, meta = state.export()
+            payload = [(nbytes, meta)]
+        dist.broadcast_object_list(payload, src=0)
+        nbytes, meta = payload[0]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        bufs = [torch.empty(max(b, 1), dtype=torch.uint8, device="cuda") for b in nbytes]
+        if rank == 0:
+            for t, p, b in zip(bufs, ptrs, nbytes):
+                _capi.check(lib.rk_device_memcpy(t.data_ptr(), p, b, dev))
+        for t in bufs:
+            dist.broadcast(t, src=0)  # RCCL over xGMI
+        torch.cuda.synchronize()
+        t_replicate = time.perf_counter() - t0
+        if rank != 0:
+            state = rakau_amd.State.from_buffers(dev, [t.data_ptr() for t in bufs], nbytes, meta)
+        del bufs
+    else:
+        t_replicate = 0.0
+    if args.variant:
+        state.set_variant(args.variant)
+
+    crit = state.crit_ranges()
+    cuts = shard_cuts(crit, state.nparts, world)
+    p_begin, p_end = cuts[rank], cuts[rank + 1]
+    n_local = p_end - p_begin
+
+    tdt = torch.float32 if dtype == "float32" else torch.float64
+    outs = [torch.zeros(max(n_local, 1), dtype=tdt, device="cuda") for _ in range(nres)]
+    d_ptrs = [o.data_ptr() for o in outs]
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        state.acc_pot_device(q, mac_value, d_ptrs, G=1.0, eps2=eps2, p_begin=p_begin, p_end=p_end,
+                             offset_output=False, stream=stream)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    # Kernel-only time of one step, HIP events recorded by the library on the launch stream.
+    kms = []
+    for _ in range(min(args.steps, 10)):
+        step()
+        kms.append(state.last_kernel_ms())
+    kernel_ms = float(np.median(kms))
+
+    census = state.count_interactions(mac_value, p_begin, p_end)
+    inter_local = census["com"] + census["pp"] + census["self"]
+
+    if dist is not None:
+        red = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(red, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms_max = float(red[0]), float(red[1])
+        tot = torch.tensor([float(inter_local), float(census["mac"])], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        inter_total, mac_total = float(tot[0]), float(tot[1])
+    else:
+        kernel_ms_max, inter_total, mac_total = kernel_ms, float(inter_local), float(census["mac"])
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = n / (elapsed / args.steps) / 1e6
+    fsz = np.dtype(dtype).itemsize
+    flop_per_inter = 19 if q == 0 else (21 if q == 2 else 12)
+    # Roofline of the dominant (traversal) launch on this rank: algorithmic flops / measured kernel time.
+    flops_launch = inter_local * flop_per_inter
+    achieved_tflops = flops_launch / (kernel_ms * 1e-3) / 1e12
+    n_nodes = state.tree_size
+    bytes_launch = n_local * (4 * fsz + nres * fsz) + n_nodes * (5 * fsz + 12)
+    hbm_gbs = bytes_launch / (kernel_ms * 1e-3) / 1e9
+    line = {
+        "metric": "Mparticles/s, accs_u() 4M Plummer fp32 theta=0.75" if args.workload == "plummer4m_f32"
+        else "Mparticles/s, %s" % wl["desc"],
+        "value": round(value, 2),
+        "unit": "Mparticles/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32" if dtype == "float32" else "f64",
+        "data": "synthetic Plummer sphere (numpy PCG64 seed 20261002), tree built on host, resident in HBM",
+        "config": {"workload": wl["desc"], "nparts": n, "theta": theta, "q": q, "eps": eps, "max_leaf_n": 16,
+                   "ncrit": 128, "mac": mac, "nodes": n_nodes, "critical_nodes": int(state.n_crit),
+                   "sharding": "contiguous Morton range per GPU, tree replicated by RCCL broadcast" if world > 1
+                   else "single GPU", "kernel_variant": args.variant},
+        "kernel_ms": round(kernel_ms_max, 4),
+        "interactions_per_particle": round(inter_total / n, 2),
+        "mac_evals_per_particle": round(mac_total / n, 2),
+        "roofline": {
+            "bound": "valu", "achieved": round(achieved_tflops, 3), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
+            "frac": round(achieved_tflops / PEAK_TFLOPS[dtype], 4), "traffic": None,
+            "flop_per_interaction": flop_per_inter, "interactions_per_launch": int(inter_local),
+            "kernel_ms": round(kernel_ms, 4),
+            "hbm": {"achieved": round(hbm_gbs, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(hbm_gbs / PEAK_HBM_GBS, 5), "algorithmic_bytes_per_launch": int(bytes_launch)},
+        },
+        "host": {"tree_build_s": round(t_build, 3), "upload_s": round(t_upload, 3),
+                 "replicate_s": round(t_replicate, 4)},
+        "reference_published": {"best_cpu_2xXeon6148_Mps": 48.8, "V100_Mps": 42.1, "RX570_rocm_path_Mps": 15.6,
+                                "note": "README.md:42-49 of the reference, single cold calls on other hardware"},
+    }
+
+    # PCIe-inclusive rate (never `value`): the C ABI call with host output buffers.
+    try:
+        t0 = time.perf_counter()
+        host_out = tree.accs_u(theta) if q == 0 else None
+        if host_out is not None:
+            line["host"]["accs_u_host_outputs_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+    except Exception as e:  # pragma: no cover
+        line["host"]["accs_u_host_outputs_error"] = str(e)
+
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(m, x, y, z, mac, theta, eps, q, n, args.cpu_threads, outs, p_begin)
+
+    print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(m, x, y, z, mac, theta, eps, q, n, threads, gpu_outs, p_begin):
+    """The CPU oracle (restatement of the reference's scalar CPU engine, oracle/rakau_oracle.cpp) on the same
+    inputs and tree parameters, all host cores. Bounded: critical nodes are processed until ~20 s of wall
+    time have been spent (whole workload if it fits). Also cross-checks the GPU result on the sample."""
+    import oracle
+    threads = threads or min(os.cpu_count() or 1, 256)
+    ot = oracle.Tree(x, y, z, m, mac=mac)
+    crit = ot.crit_nodes()
+    ncrit = len(crit)
+    # Probe speed on 1/64 of the groups, then size the sample for ~20 s.
+    probe = max(threads * 16, ncrit // 64)
+    t0 = time.perf_counter()
+    ot.acc_pot(q, theta, eps=eps, nthreads=threads, c_begin=0, c_end=probe)
+    dt = time.perf_counter() - t0
+    rate = probe / max(dt, 1e-6)
+    sample = int(min(ncrit, max(probe, rate * 20.0)))
+    t0 = time.perf_counter()
+    ref = ot.acc_pot(q, theta, eps=eps, nthreads=threads, c_begin=0, c_end=sample)
+    dt = time.perf_counter() - t0
+    parts = int(crit[sample - 1, 2])
+    out = {"value": round(parts / dt / 1e6, 3), "unit": "Mparticles/s", "cores": threads, "kind": "port",
+           "sample": "critical nodes [0, %d) of %d = particles [0, %d) of %d, %.2f s" % (sample, ncrit, parts, n, dt),
+           "note": "scalar restatement of rakau's CPU engine (no TBB/xsimd available); not the reference's performance"}
+    # Parity of the timed GPU result against the oracle on the sample (vector norm, as SURVEY 8(d) Gate A).
+    try:
+        if q in (0, 2) and p_begin == 0:
+            g = np.stack([o[:parts].cpu().numpy().astype(np.float64) for o in gpu_outs[:3]], axis=1)
+            r = np.stack([np.asarray(v[:parts], dtype=np.float64) for v in ref[:3]], axis=1)
+            den = np.linalg.norm(r, axis=1)
+            den[den == 0] = 1.0
+            err = np.linalg.norm(g - r, axis=1) / den
+            out["parity_max_rel_err"] = float(err.max())
+            out["parity_median_rel_err"] = float(np.median(err))
+    except Exception as e:  # pragma: no cover
+        out["parity_error"] = str(e)
+    return out
+
+
+if __name__ == "__main__":
+    main()

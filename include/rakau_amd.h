@@ -143,6 +143,20 @@ RK_EXPORT int rk_state_export(const rk_state *s, int *count, void **ptrs, int64_
 RK_EXPORT int rk_state_import(rk_state **out, int device, int count, void *const *ptrs, const int64_t *bytes,
                               const int64_t meta[RK_META_WORDS]);
 
+/* Device-to-device copy on `device` (plumbing for rk_state_export/import users that stage through their
+ * own device buffers). */
+RK_EXPORT int rk_device_memcpy(void *dst, const void *src, int64_t bytes, int device);
+
+/*
+ * Census of the traversal for the particles [p_begin, p_end): counts[0] = target x node MAC evaluations,
+ * counts[1] = target x accepted-node (monopole) interactions, counts[2] = target x particle interactions
+ * with opened leaves, counts[3] = ordered particle pairs inside the critical nodes. The sum of the last
+ * three is the number of particle-level interactions an acc/pot call evaluates (the reference's CPU engine
+ * evaluates exactly the same set); bench.py derives the algorithmic flop count from it.
+ */
+RK_EXPORT int rk_count_interactions(rk_state *s, int64_t p_begin, int64_t p_end, double mac_value,
+                                    uint64_t counts[4]);
+
 /* Select the traversal kernel: 0 = automatic (default), 1 = wave-per-group scalar DFS,
  * 2 = LDS interaction-list kernel. For tests and benchmarks only. */
 RK_EXPORT int rk_set_kernel_variant(rk_state *s, int variant);

@@ -150,11 +150,12 @@ class Tree:
         n = self.nparts
         outs = [np.zeros(n, dtype=self.dtype) for _ in range(NRES[q])]
         ptrs = (C.c_void_p * 4)(*[o.ctypes.data for o in outs], *([None] * (4 - len(outs))))
-        stats = np.zeros(5, dtype=np.uint64)
+        stats = np.zeros(9, dtype=np.uint64)
         _check(lib().orc_acc_pot(self._h, q, ptrs, int(ordered), theta, G, eps, nthreads, c_begin, c_end,
                                  stats.ctypes.data if want_stats else None))
         if want_stats:
-            return outs, dict(zip(("visits", "com", "leaves", "pp", "self_pairs"), (int(s) for s in stats)))
+            return outs, dict(zip(("visits", "com", "leaves", "pp", "self_pairs", "w_visits", "w_com", "w_pp", "w_self"),
+                                   (int(s) for s in stats)))
         return outs
 
     def accs_u(self, theta, **kw):

@@ -401,7 +401,10 @@ struct tree_t {
 
     // Per-group statistics used for the roofline's algorithmic work count.
     struct stats_t {
-        u64 visits = 0, com = 0, leaves = 0, pp = 0, self_pairs = 0;
+        // Per-group counts: MAC evaluations, accepted nodes, opened leaves, source particles of opened
+        // leaves, unordered pairs inside the group. w_*: the same weighted by the group size, i.e.
+        // particle-level interaction counts (targets x sources); w_self counts ordered pairs.
+        u64 visits = 0, com = 0, leaves = 0, pp = 0, self_pairs = 0, w_visits = 0, w_com = 0, w_pp = 0, w_self = 0;
     };
 
     // Reference: tree.hpp:2073-2321 (tree_self_interactions), scalar branch 2258-2320.
@@ -530,6 +533,7 @@ struct tree_t {
         }
         if (st) {
             ++st->visits;
+            st->w_visits += tgt_size;
         }
         if (mac_flag) {
             // tree.hpp:2564-2589.
@@ -547,6 +551,7 @@ struct tree_t {
             }
             if (st) {
                 ++st->com;
+                st->w_com += tgt_size;
             }
             return src_idx + n_children_src + 1u;
         }
@@ -555,6 +560,7 @@ struct tree_t {
             if (st) {
                 ++st->leaves;
                 st->pp += src.end - src.begin;
+                st->w_pp += tgt_size * (src.end - src.begin);
             }
         }
         return src_idx + 1u;
@@ -584,6 +590,7 @@ struct tree_t {
         self_interactions<Q>(eps2, tgt_size, p, res);
         if (st) {
             st->self_pairs += tgt_size * (tgt_size - 1u) / 2u;
+            st->w_self += tgt_size * (tgt_size - 1u);
         }
     }
 
@@ -664,6 +671,10 @@ struct tree_t {
                 stats_out->leaves += t.leaves;
                 stats_out->pp += t.pp;
                 stats_out->self_pairs += t.self_pairs;
+                stats_out->w_visits += t.w_visits;
+                stats_out->w_com += t.w_com;
+                stats_out->w_pp += t.w_pp;
+                stats_out->w_self += t.w_self;
             }
         }
     }
@@ -850,6 +861,10 @@ void acc_pot_q(const T &t, int q, void *const *out, int ordered, double theta, d
         stats[2] = st.leaves;
         stats[3] = st.pp;
         stats[4] = st.self_pairs;
+        stats[5] = st.w_visits;
+        stats[6] = st.w_com;
+        stats[7] = st.w_pp;
+        stats[8] = st.w_self;
     }
 }
 
@@ -1029,7 +1044,8 @@ void orc_tree_get_crit(void *hp, u64 *crit)
 
 // q: 0 accs (3 outputs), 1 pots (1), 2 accs+pots (4). ordered: 0 -> *_u, 1 -> *_o.
 // Only critical nodes [c_begin, c_end) are processed (c_end is clamped); outputs of the other
-// particles are left untouched. stats (may be null): visits, com, leaves, pp, self_pairs.
+// particles are left untouched. stats (may be null, else 9 entries): visits, com, leaves, pp, self_pairs,
+// w_visits, w_com, w_pp, w_self (see stats_t).
 int orc_acc_pot(void *hp, int q, void *const *out, int ordered, double theta, double G, double eps,
                 unsigned nthreads, u64 c_begin, u64 c_end, u64 *stats)
 {

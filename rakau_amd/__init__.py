@@ -5,5 +5,6 @@ C ABI of ``include/rakau_amd.h``), ``lib/`` (the built ``librakau_amd.so``) and 
 """
 from . import _capi
 from .state import State, node_dtype, mac_value_of, NRES
+from .tree import Octree
 
-__all__ = ["State", "node_dtype", "mac_value_of", "NRES"]
+__all__ = ["State", "Octree", "node_dtype", "mac_value_of", "NRES"]

@@ -21,10 +21,10 @@ _EXC = {1: ValueError, 2: ArithmeticError, 3: OverflowError, 4: RuntimeError, 5:
 SYMBOLS = [
     "rk_last_error", "rk_min_size", "rk_has_accelerator", "rk_device_count", "rk_state_create", "rk_state_destroy",
     "rk_state_info", "rk_state_crit_ranges", "rk_acc_pot", "rk_acc_pot_device", "rk_last_kernel_ms", "rk_state_export",
-    "rk_state_import", "rk_set_kernel_variant",
+    "rk_state_import", "rk_set_kernel_variant", "rk_device_memcpy", "rk_count_interactions",
     # host-side tree builder (include/rakau_amd_tree.h)
     "rk_tree_create", "rk_tree_destroy", "rk_tree_info", "rk_tree_get", "rk_tree_nodes", "rk_tree_state",
-    "rk_tree_acc_pot", "rk_tree_exact", "rk_tree_update_particles", "rk_plummer",
+    "rk_tree_acc_pot", "rk_tree_exact", "rk_tree_update_particles",
 ]
 
 _lib = None
@@ -53,6 +53,8 @@ def lib():
     L.rk_state_export.argtypes = [vp, C.POINTER(ci), C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)]
     L.rk_state_import.argtypes = [C.POINTER(vp), ci, ci, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)]
     L.rk_set_kernel_variant.argtypes = [vp, ci]
+    L.rk_device_memcpy.argtypes = [vp, vp, i64, ci]
+    L.rk_count_interactions.argtypes = [vp, i64, i64, dbl, C.POINTER(u64)]
     if hasattr(L, "rk_tree_create"):
         L.rk_tree_create.argtypes = [C.POINTER(vp), ci, ci, vp, vp, vp, vp, i64, dbl, u64, u64, ci]
         L.rk_tree_destroy.argtypes = [vp]
@@ -64,7 +66,6 @@ def lib():
         L.rk_tree_acc_pot.argtypes = [vp, ci, ci, C.POINTER(vp), dbl, dbl, dbl, C.POINTER(dbl), ci]
         L.rk_tree_exact.argtypes = [vp, ci, ci, i64, dbl, dbl, vp]
         L.rk_tree_update_particles.argtypes = [vp, vp, vp, vp, vp]
-        L.rk_plummer.argtypes = [ci, vp, i64, dbl, dbl, u64, ci]
     _lib = L
     return L
 

@@ -108,6 +108,9 @@ namespace rk
 template <typename F>
 void launch_traversal(const rk_state &s, int q, const kparams<F> &p, const int64_t cls_begin[n_classes],
                       const int64_t cls_end[n_classes], hipStream_t stream);
+template <typename F>
+void launch_census(const rk_state &s, const kparams<F> &p, int64_t g_begin, int64_t g_end,
+                   unsigned long long *d_counts, hipStream_t stream);
 } // namespace rk
 
 #endif

@@ -17,7 +17,6 @@ int guard(Fn &&f) noexcept
 {
     try {
         f();
-        g_err.clear();
         return RK_OK;
     } catch (const rk::error &e) {
         g_err = e.what();
@@ -289,6 +288,44 @@ void range_to_classes(const rk_state &s, int64_t p_begin, int64_t p_end, int64_t
 }
 
 template <typename F>
+rk::kparams<F> base_params(const rk_state &s, double mac_value, double G, double eps2)
+{
+    rk::kparams<F> p{};
+    p.part4 = static_cast<const typename rk::vt<F>::v4 *>(s.buf[RK_BUF_PART4]);
+    p.node_com = static_cast<const typename rk::vt<F>::v4 *>(s.buf[RK_BUF_NODE_COM]);
+    p.node_mac = static_cast<const typename rk::vt<F>::v2 *>(s.buf[RK_BUF_NODE_MAC]);
+    p.node_topo = static_cast<const uint4 *>(s.buf[RK_BUF_NODE_TOPO]);
+    p.crit = static_cast<const uint4 *>(s.buf[RK_BUF_CRIT]);
+    p.child_tab = static_cast<const uint32_t *>(s.buf[RK_BUF_CHILD]);
+    p.n_nodes = static_cast<uint32_t>(s.tree_size);
+    p.mac_value = static_cast<F>(mac_value);
+    p.eps2 = static_cast<F>(eps2);
+    p.G = static_cast<F>(G);
+    return p;
+}
+
+template <typename F>
+void census_impl(rk_state &s, int64_t p_begin, int64_t p_end, double mac_value, uint64_t counts[4])
+{
+    int64_t cb[rk::n_classes], ce[rk::n_classes];
+    range_to_classes(s, p_begin, p_end, cb, ce); // validates the range
+    const auto g0 = std::lower_bound(s.crit_begin.begin(), s.crit_begin.end(), p_begin) - s.crit_begin.begin();
+    const auto g1 = std::lower_bound(s.crit_begin.begin(), s.crit_begin.end(), p_end) - s.crit_begin.begin();
+    auto p = base_params<F>(s, mac_value, 1., 0.);
+    unsigned long long *d_counts = nullptr;
+    RK_HIP(hipMalloc(&d_counts, 4 * sizeof(unsigned long long)));
+    try {
+        RK_HIP(hipMemset(d_counts, 0, 4 * sizeof(unsigned long long)));
+        rk::launch_census<F>(s, p, g0, g1, d_counts, nullptr);
+        RK_HIP(hipMemcpy(counts, d_counts, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    } catch (...) {
+        (void)hipFree(d_counts);
+        throw;
+    }
+    RK_HIP(hipFree(d_counts));
+}
+
+template <typename F>
 void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d_out, double mac_value, double G,
               double eps2, int offset_output, hipStream_t stream)
 {
@@ -357,6 +394,12 @@ extern "C" {
 const char *rk_last_error(void)
 {
     return g_err.c_str();
+}
+
+// Internal (not declared in the public header): lets rk_tree_capi.cpp report through rk_last_error().
+RK_EXPORT void rk_set_last_error_(const char *msg)
+{
+    g_err = msg ? msg : "";
 }
 
 unsigned rk_min_size(void)
@@ -606,6 +649,43 @@ int rk_state_import(rk_state **out, int device, int count, void *const *ptrs, co
         }
         build_host_mirrors(*s, crit);
         *out = s.release();
+    });
+}
+
+int rk_count_interactions(rk_state *s, int64_t p_begin, int64_t p_end, double mac_value, uint64_t counts[4])
+{
+    return guard([&] {
+        if (!s || !counts) {
+            throw rk::error(RK_EINVAL, "null argument");
+        }
+        if (!std::isfinite(mac_value) || mac_value <= 0.) {
+            throw rk::error(RK_EDOMAIN, "The transformed MAC value must be finite and positive, but it is "
+                                            + std::to_string(mac_value) + " instead");
+        }
+        std::fill(counts, counts + 4, uint64_t(0));
+        if (!s->nparts) {
+            return;
+        }
+        device_guard dg(s->device);
+        if (s->fp == RK_F32) {
+            census_impl<float>(*s, p_begin, p_end, mac_value, counts);
+        } else {
+            census_impl<double>(*s, p_begin, p_end, mac_value, counts);
+        }
+    });
+}
+
+int rk_device_memcpy(void *dst, const void *src, int64_t bytes, int device)
+{
+    return guard([&] {
+        if (bytes < 0 || (bytes > 0 && (!dst || !src))) {
+            throw rk::error(RK_EINVAL, "invalid arguments to rk_device_memcpy");
+        }
+        check_device(device);
+        device_guard dg(device);
+        if (bytes) {
+            RK_HIP(hipMemcpy(dst, src, static_cast<size_t>(bytes), hipMemcpyDeviceToDevice));
+        }
     });
 }
 

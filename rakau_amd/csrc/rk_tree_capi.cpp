@@ -1,0 +1,303 @@
+// C ABI over rakau_amd::octree<F, MAC> (declared in include/rakau_amd_tree.h).
+#include "../../include/rakau_amd/tree.hpp"
+#include "../../include/rakau_amd_tree.h"
+
+#include <variant>
+
+namespace
+{
+
+using namespace rakau_amd;
+
+using any_tree = std::variant<octree<float, mac::bh>, octree<float, mac::bh_geom>, octree<double, mac::bh>,
+                              octree<double, mac::bh_geom>>;
+
+thread_local std::string g_tree_err;
+
+} // namespace
+
+struct rk_tree {
+    any_tree t;
+};
+
+// Defined in rk_state.hip: lets this translation unit report through rk_last_error().
+extern "C" void rk_set_last_error_(const char *msg);
+
+namespace
+{
+
+template <typename Fn>
+int guard(Fn &&f) noexcept
+{
+    try {
+        f();
+        return RK_OK;
+    } catch (const std::domain_error &e) {
+        rk_set_last_error_(e.what());
+        return RK_EDOMAIN;
+    } catch (const std::invalid_argument &e) {
+        rk_set_last_error_(e.what());
+        return RK_EINVAL;
+    } catch (const std::overflow_error &e) {
+        rk_set_last_error_(e.what());
+        return RK_EOVERFLOW;
+    } catch (const std::bad_alloc &) {
+        rk_set_last_error_("out of memory");
+        return RK_ENOMEM;
+    } catch (const std::exception &e) {
+        rk_set_last_error_(e.what());
+        return RK_ERUNTIME;
+    }
+}
+
+template <typename Tree>
+struct fp_of;
+template <typename F, mac M>
+struct fp_of<tree<3, F, std::size_t, M>> {
+    using type = F;
+};
+
+template <typename F, mac M>
+octree<F, M> make_tree(const void *x, const void *y, const void *z, const void *m, std::int64_t n, double box,
+                       std::uint64_t max_leaf_n, std::uint64_t ncrit)
+{
+    const auto *xs = static_cast<const F *>(x), *ys = static_cast<const F *>(y), *zs = static_cast<const F *>(z),
+               *ms = static_cast<const F *>(m);
+    if (box == 0.) {
+        return octree<F, M>{kwargs::x_coords = xs,         kwargs::y_coords = ys,
+                            kwargs::z_coords = zs,         kwargs::masses = ms,
+                            kwargs::nparts = n,            kwargs::max_leaf_n = max_leaf_n,
+                            kwargs::ncrit = ncrit};
+    }
+    return octree<F, M>{kwargs::x_coords = xs,         kwargs::y_coords = ys, kwargs::z_coords = zs,
+                        kwargs::masses = ms,           kwargs::nparts = n,    kwargs::box_size = box,
+                        kwargs::max_leaf_n = max_leaf_n, kwargs::ncrit = ncrit};
+}
+
+} // namespace
+
+extern "C" {
+
+int rk_tree_create(rk_tree **out, int fp, int mac_kind, const void *x, const void *y, const void *z, const void *m,
+                   int64_t nparts, double box_size, uint64_t max_leaf_n, uint64_t ncrit, int)
+{
+    return guard([&] {
+        if (!out) {
+            throw std::invalid_argument("null output pointer");
+        }
+        *out = nullptr;
+        if (nparts < 0 || (nparts > 0 && (!x || !y || !z || !m))) {
+            throw std::invalid_argument("invalid particle arrays");
+        }
+        const int key = fp * 2 + mac_kind;
+        std::unique_ptr<rk_tree> t;
+        switch (key) {
+            case 0:
+                t.reset(new rk_tree{make_tree<float, mac::bh>(x, y, z, m, nparts, box_size, max_leaf_n, ncrit)});
+                break;
+            case 1:
+                t.reset(new rk_tree{make_tree<float, mac::bh_geom>(x, y, z, m, nparts, box_size, max_leaf_n, ncrit)});
+                break;
+            case 2:
+                t.reset(new rk_tree{make_tree<double, mac::bh>(x, y, z, m, nparts, box_size, max_leaf_n, ncrit)});
+                break;
+            case 3:
+                t.reset(
+                    new rk_tree{make_tree<double, mac::bh_geom>(x, y, z, m, nparts, box_size, max_leaf_n, ncrit)});
+                break;
+            default:
+                throw std::invalid_argument("invalid fp / mac selector");
+        }
+        *out = t.release();
+    });
+}
+
+void rk_tree_destroy(rk_tree *t)
+{
+    delete t;
+}
+
+int rk_tree_info(const rk_tree *t, int64_t info[8], double *box_size)
+{
+    return guard([&] {
+        if (!t || !info || !box_size) {
+            throw std::invalid_argument("null argument");
+        }
+        std::visit(
+            [&](const auto &tr) {
+                info[0] = static_cast<int64_t>(tr.nparts());
+                info[1] = static_cast<int64_t>(tr.nodes().size());
+                info[2] = static_cast<int64_t>(tr.crit_nodes().size());
+                info[3] = static_cast<int64_t>(tr.max_leaf_n());
+                info[4] = static_cast<int64_t>(tr.ncrit());
+                info[5] = tr.box_size_deduced();
+                info[6] = static_cast<int64_t>(sizeof(tr.nodes()[0]));
+                info[7] = 0;
+                *box_size = static_cast<double>(tr.box_size());
+            },
+            t->t);
+    });
+}
+
+int rk_tree_get(const rk_tree *t, int what, void *dst)
+{
+    return guard([&] {
+        if (!t || !dst) {
+            throw std::invalid_argument("null argument");
+        }
+        std::visit(
+            [&](const auto &tr) {
+                using F = typename fp_of<std::decay_t<decltype(tr)>>::type;
+                const auto n = tr.nparts();
+                if (what >= 0 && what <= 3) {
+                    std::memcpy(dst, tr.p_its_u()[static_cast<std::size_t>(what)], n * sizeof(F));
+                } else if (what == 4) {
+                    std::memcpy(dst, tr.c_it_u(), n * sizeof(std::uint64_t));
+                } else if (what == 5) {
+                    std::memcpy(dst, tr.perm().data(), n * sizeof(std::uint64_t));
+                } else if (what == 6) {
+                    std::memcpy(dst, tr.last_perm().data(), n * sizeof(std::uint64_t));
+                } else if (what == 7) {
+                    std::memcpy(dst, tr.inv_perm().data(), n * sizeof(std::uint64_t));
+                } else if (what == 8) {
+                    auto *o = static_cast<std::uint64_t *>(dst);
+                    for (const auto &c : tr.crit_nodes()) {
+                        *o++ = c.code;
+                        *o++ = c.begin;
+                        *o++ = c.end;
+                    }
+                } else {
+                    throw std::invalid_argument("invalid array selector");
+                }
+            },
+            t->t);
+    });
+}
+
+int rk_tree_nodes(const rk_tree *t, const void **ptr, int64_t *count, int64_t *stride)
+{
+    return guard([&] {
+        if (!t || !ptr || !count || !stride) {
+            throw std::invalid_argument("null argument");
+        }
+        std::visit(
+            [&](const auto &tr) {
+                *ptr = tr.nodes().data();
+                *count = static_cast<int64_t>(tr.nodes().size());
+                *stride = static_cast<int64_t>(sizeof(tr.nodes()[0]));
+            },
+            t->t);
+    });
+}
+
+int rk_tree_state(const rk_tree *t, rk_state **state)
+{
+    return guard([&] {
+        if (!t || !state) {
+            throw std::invalid_argument("null argument");
+        }
+        std::visit([&](const auto &tr) { *state = tr.device_state(0); }, t->t);
+    });
+}
+
+int rk_tree_acc_pot(const rk_tree *t, int q, int ordered, void *const *out, double theta, double G, double eps,
+                    const double *split, int n_split)
+{
+    return guard([&] {
+        if (!t || !out) {
+            throw std::invalid_argument("null argument");
+        }
+        const std::vector<double> sp(split, split + (split ? n_split : 0));
+        std::visit(
+            [&](const auto &tr) {
+                using F = typename fp_of<std::decay_t<decltype(tr)>>::type;
+                auto o = [&](int k) { return static_cast<F *>(out[k]); };
+                const F th = static_cast<F>(theta);
+                switch (q * 2 + (ordered ? 1 : 0)) {
+                    case 0:
+                        tr.accs_u(std::array<F *, 3>{o(0), o(1), o(2)}, th, kwargs::G = G, kwargs::eps = eps,
+                                  kwargs::split = sp);
+                        break;
+                    case 1:
+                        tr.accs_o(std::array<F *, 3>{o(0), o(1), o(2)}, th, kwargs::G = G, kwargs::eps = eps,
+                                  kwargs::split = sp);
+                        break;
+                    case 2:
+                        tr.pots_u(o(0), th, kwargs::G = G, kwargs::eps = eps, kwargs::split = sp);
+                        break;
+                    case 3:
+                        tr.pots_o(o(0), th, kwargs::G = G, kwargs::eps = eps, kwargs::split = sp);
+                        break;
+                    case 4:
+                        tr.accs_pots_u(std::array<F *, 4>{o(0), o(1), o(2), o(3)}, th, kwargs::G = G,
+                                       kwargs::eps = eps, kwargs::split = sp);
+                        break;
+                    case 5:
+                        tr.accs_pots_o(std::array<F *, 4>{o(0), o(1), o(2), o(3)}, th, kwargs::G = G,
+                                       kwargs::eps = eps, kwargs::split = sp);
+                        break;
+                    default:
+                        throw std::invalid_argument("q must be 0, 1 or 2");
+                }
+            },
+            t->t);
+    });
+}
+
+int rk_tree_exact(const rk_tree *t, int q, int ordered, int64_t idx, double G, double eps, void *out)
+{
+    return guard([&] {
+        if (!t || !out) {
+            throw std::invalid_argument("null argument");
+        }
+        std::visit(
+            [&](const auto &tr) {
+                using F = typename fp_of<std::decay_t<decltype(tr)>>::type;
+                auto *o = static_cast<F *>(out);
+                if (idx < 0 || static_cast<std::size_t>(idx) >= tr.nparts()) {
+                    throw std::invalid_argument("particle index out of range");
+                }
+                const auto i = static_cast<std::size_t>(idx);
+                if (q == 0) {
+                    const auto r = ordered ? tr.exact_acc_o(i, kwargs::G = G, kwargs::eps = eps)
+                                           : tr.exact_acc_u(i, kwargs::G = G, kwargs::eps = eps);
+                    std::copy(r.begin(), r.end(), o);
+                } else if (q == 1) {
+                    o[0] = ordered ? tr.exact_pot_o(i, kwargs::G = G, kwargs::eps = eps)
+                                   : tr.exact_pot_u(i, kwargs::G = G, kwargs::eps = eps);
+                } else if (q == 2) {
+                    const auto r = ordered ? tr.exact_acc_pot_o(i, kwargs::G = G, kwargs::eps = eps)
+                                           : tr.exact_acc_pot_u(i, kwargs::G = G, kwargs::eps = eps);
+                    std::copy(r.begin(), r.end(), o);
+                } else {
+                    throw std::invalid_argument("q must be 0, 1 or 2");
+                }
+            },
+            t->t);
+    });
+}
+
+int rk_tree_update_particles(rk_tree *t, const void *x, const void *y, const void *z, const void *m)
+{
+    return guard([&] {
+        if (!t) {
+            throw std::invalid_argument("null argument");
+        }
+        std::visit(
+            [&](auto &tr) {
+                using F = typename fp_of<std::decay_t<decltype(tr)>>::type;
+                const auto n = tr.nparts();
+                const void *src[4] = {x, y, z, m};
+                tr.update_particles_u([&](const auto &its) {
+                    for (std::size_t j = 0; j < 4; ++j) {
+                        if (src[j]) {
+                            std::copy(static_cast<const F *>(src[j]), static_cast<const F *>(src[j]) + n, its[j]);
+                        }
+                    }
+                });
+            },
+            t->t);
+    });
+}
+
+} // extern "C"

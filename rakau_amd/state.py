@@ -104,6 +104,13 @@ class State:
         _capi.check(_capi.lib().rk_acc_pot_device(self._h, q, p_begin, p_end, ptrs, mac_value, G, eps2,
                                                   int(offset_output), stream))
 
+    def count_interactions(self, mac_value, p_begin=0, p_end=None):
+        """Census of the traversal: dict(mac=..., com=..., pp=..., self=...) particle-level counts."""
+        p_end = self.nparts if p_end is None else p_end
+        c = (C.c_uint64 * 4)()
+        _capi.check(_capi.lib().rk_count_interactions(self._h, p_begin, p_end, mac_value, c))
+        return dict(mac=int(c[0]), com=int(c[1]), pp=int(c[2]), self=int(c[3]))
+
     def last_kernel_ms(self):
         ms = C.c_float()
         _capi.check(_capi.lib().rk_last_kernel_ms(self._h, C.byref(ms)))
