@@ -49,6 +49,39 @@ inline int class_of(int64_t size)
     if (size <= 512) return 3;
     return 4;
 }
+// Variant 2 (LDS interaction lists): each lane holds R targets, TP = ceil(T / R) target slots and
+// NS = floor(64 / TP) source splits share the wave. The dense phase costs R / NS lane-iterations per
+// source; pick the R that minimises it (ties: fewer registers).
+inline int class2_of(int64_t size)
+{
+    if (size > 512) return 4;
+    int best = -1;
+    double best_cost = 0.;
+    for (int c = 0; c < 4; ++c) {
+        const int64_t R = class_R(c), TP = (size + R - 1) / R;
+        if (TP > 64) continue;
+        const double cost = static_cast<double>(R) / static_cast<double>(64 / TP);
+        if (best < 0 || cost < best_cost - 1e-12) {
+            best = c;
+            best_cost = cost;
+        }
+    }
+    return best;
+}
+
+// All-in-one node record of the list kernel: one aligned record per node so that a lane fetches
+// everything it may need about its candidate node (including the indices of its children) with
+// independent 16-byte loads issued together. Leaves store their particle range where internal nodes
+// store their children.
+template <typename F>
+struct node_rec {
+    typename vt<F>::v4 com; // COM x, y, z, mass
+    typename vt<F>::v2 mac; // {dim2, 0} (bh) or {dim, delta} (bh_geom)
+    uint32_t nch;           // number of descendants (0 for a leaf)
+    uint32_t pad;
+    uint32_t link[8];       // internal node: child node indices (0 = none); leaf: {begin, end, 0...}
+};
+static_assert(sizeof(node_rec<float>) == 64 && sizeof(node_rec<double>) == 96, "unexpected node record size");
 
 // Kernel parameter block (passed by value).
 template <typename F>
@@ -59,6 +92,7 @@ struct kparams {
     const uint4 *node_topo;             // {n_children, begin, end, child-table slot}
     const uint4 *crit;                  // target groups: {begin, end, node index, size}
     const uint32_t *child_tab;          // 8 child node indices per internal node (0 = none)
+    const node_rec<F> *node_rec;        // all-in-one records (list kernel)
     uint32_t n_nodes;
     F mac_value, eps2, G;
     F *out[4];
@@ -82,7 +116,7 @@ struct error : std::runtime_error {
 } // namespace rk
 
 // Device buffer indices in rk_state::buf (also the export order).
-enum { RK_BUF_PART4 = 0, RK_BUF_NODE_COM, RK_BUF_NODE_MAC, RK_BUF_NODE_TOPO, RK_BUF_CRIT, RK_BUF_CHILD, RK_BUF_CLASS, RK_NBUF };
+enum { RK_BUF_PART4 = 0, RK_BUF_NODE_COM, RK_BUF_NODE_MAC, RK_BUF_NODE_TOPO, RK_BUF_CRIT, RK_BUF_CHILD, RK_BUF_CLASS, RK_BUF_NODE_REC, RK_NBUF };
 
 struct rk_state {
     int fp = 0, mac = 0, device = 0;
@@ -92,8 +126,10 @@ struct rk_state {
     int64_t buf_bytes[RK_NBUF] = {};
     // Host mirrors used to map a particle range onto groups.
     std::vector<int64_t> crit_begin, crit_end;
-    std::vector<uint32_t> class_list[rk::n_classes]; // ascending group ids per class
+    std::vector<uint32_t> class_list[rk::n_classes]; // ascending group ids per class (variant 1 binning)
     int64_t class_off[rk::n_classes + 1] = {};       // offsets into the concatenated device list
+    std::vector<uint32_t> class2_list[rk::n_classes]; // variant 2 binning (best targets-per-lane R)
+    int64_t class2_off[rk::n_classes + 1] = {};
     // Output scratch for rk_acc_pot (host outputs).
     void *d_out = nullptr;
     size_t d_out_bytes = 0;
@@ -108,6 +144,11 @@ namespace rk
 template <typename F>
 void launch_traversal(const rk_state &s, int q, const kparams<F> &p, const int64_t cls_begin[n_classes],
                       const int64_t cls_end[n_classes], hipStream_t stream);
+template <typename F>
+void launch_list(const rk_state &s, int q, const kparams<F> &p, const int64_t cls_begin[n_classes],
+                 const int64_t cls_end[n_classes], hipStream_t stream);
+template <typename F>
+void launch_block(const rk_state &s, int q, const kparams<F> &p, const uint32_t *list, int64_t n, hipStream_t stream);
 template <typename F>
 void launch_census(const rk_state &s, const kparams<F> &p, int64_t g_begin, int64_t g_end,
                    unsigned long long *d_counts, hipStream_t stream);

@@ -1,0 +1,113 @@
+// Device-side helpers shared by the traversal kernels.
+#ifndef RK_DEVICE_HPP
+#define RK_DEVICE_HPP
+
+#include "rk_common.hpp"
+
+namespace rk
+{
+
+// ------------------------------------------------------------------------------------------------
+// Arithmetic helpers.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float rk_fma(float a, float b, float c)
+{
+    return __builtin_fmaf(a, b, c);
+}
+__device__ __forceinline__ double rk_fma(double a, double b, double c)
+{
+    return __builtin_fma(a, b, c);
+}
+// 1/sqrt(x): v_rsq_f32 (1 ulp) for fp32; for fp64 v_rsq_f64 refined by two Newton steps.
+__device__ __forceinline__ float rk_rsqrt(float x)
+{
+    return __builtin_amdgcn_rsqf(x);
+}
+__device__ __forceinline__ double rk_rsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    // y <- y + y * (0.5 * (1 - x*y*y)), twice: v_rsq_f64 delivers ~2^-26 relative accuracy.
+    double e = rk_fma(-x * y, y, 1.0);
+    y = rk_fma(y * 0.5, e, y);
+    e = rk_fma(-x * y, y, 1.0);
+    y = rk_fma(y * 0.5, e, y);
+    return y;
+}
+
+__device__ __forceinline__ float rk_min(float a, float b)
+{
+    return __builtin_fminf(a, b);
+}
+__device__ __forceinline__ double rk_min(double a, double b)
+{
+    return __builtin_fmin(a, b);
+}
+
+template <typename F>
+__device__ __forceinline__ F mac_lhs(int mac, typename vt<F>::v2 mp, F mac_value)
+{
+    // tree.hpp:2632-2642 of the reference.
+    if (mac == RK_MAC_BH) {
+        return mp.x * mac_value;
+    }
+    const F t = rk_fma(mp.x, mac_value, mp.y);
+    return t * t;
+}
+
+// One monopole interaction on a target: d = source - target, d2 = softened squared distance.
+// Q == 0: acc[0..2] += d * m / r^3.  Q == 1: acc[0] -= m_tgt * m / r.  Q == 2: both (pot in acc[3]).
+// Arithmetic of tree.hpp:2008-2068 / 2564-2589 of the reference with 1/sqrt in place of sqrt + divide.
+template <typename F, int Q>
+__device__ __forceinline__ void interact(F (&acc)[nres_of(Q)], F dx, F dy, F dz, F d2, F m_src, F m_tgt)
+{
+    const F rinv = rk_rsqrt(d2);
+    const F mr = m_src * rinv;
+    if constexpr (Q == 0 || Q == 2) {
+        const F mr3 = mr * (rinv * rinv);
+        acc[0] = rk_fma(dx, mr3, acc[0]);
+        acc[1] = rk_fma(dy, mr3, acc[1]);
+        acc[2] = rk_fma(dz, mr3, acc[2]);
+    }
+    if constexpr (Q == 1) {
+        acc[0] = rk_fma(-m_tgt, mr, acc[0]);
+    }
+    if constexpr (Q == 2) {
+        acc[3] = rk_fma(-m_tgt, mr, acc[3]);
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Wave-level primitives (wave64).
+// ------------------------------------------------------------------------------------------------
+// Number of set bits of `mask` below the calling lane.
+__device__ __forceinline__ unsigned wave_prefix_count(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mask >> 32),
+                                     __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mask), 0u));
+}
+// Orders LDS traffic between the lanes of one wavefront (no instruction besides the waits the compiler
+// needs; DS operations of a wave execute in order).
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// Inclusive prefix sum over the 64 lanes.
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned v)
+{
+    const int lane = static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned o = static_cast<unsigned>(__shfl_up(static_cast<int>(v), d, 64));
+        if (lane >= d) {
+            v += o;
+        }
+    }
+    return v;
+}
+
+} // namespace rk
+
+#endif

@@ -6,69 +6,10 @@
 // (tree.hpp:2662-2672), so a group shares one interaction list, and that list is identical to the
 // CPU engine's.
 #include "rk_common.hpp"
+#include "rk_device.hpp"
 
 namespace rk
 {
-
-// ------------------------------------------------------------------------------------------------
-// Arithmetic helpers.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float rk_fma(float a, float b, float c)
-{
-    return __builtin_fmaf(a, b, c);
-}
-__device__ __forceinline__ double rk_fma(double a, double b, double c)
-{
-    return __builtin_fma(a, b, c);
-}
-// 1/sqrt(x): v_rsq_f32 (1 ulp) for fp32; for fp64 v_rsq_f64 refined by two Newton steps.
-__device__ __forceinline__ float rk_rsqrt(float x)
-{
-    return __builtin_amdgcn_rsqf(x);
-}
-__device__ __forceinline__ double rk_rsqrt(double x)
-{
-    double y = __builtin_amdgcn_rsq(x);
-    // y <- y + y * (0.5 * (1 - x*y*y)), twice: v_rsq_f64 delivers ~2^-26 relative accuracy.
-    double e = rk_fma(-x * y, y, 1.0);
-    y = rk_fma(y * 0.5, e, y);
-    e = rk_fma(-x * y, y, 1.0);
-    y = rk_fma(y * 0.5, e, y);
-    return y;
-}
-
-template <typename F>
-__device__ __forceinline__ F mac_lhs(int mac, typename vt<F>::v2 mp, F mac_value)
-{
-    // tree.hpp:2632-2642 of the reference.
-    if (mac == RK_MAC_BH) {
-        return mp.x * mac_value;
-    }
-    const F t = rk_fma(mp.x, mac_value, mp.y);
-    return t * t;
-}
-
-// One monopole interaction on a target: d = source - target, d2 = softened squared distance.
-// Q == 0: acc[0..2] += d * m / r^3.  Q == 1: acc[0] -= m_tgt * m / r.  Q == 2: both (pot in acc[3]).
-// Arithmetic of tree.hpp:2008-2068 / 2564-2589 of the reference with 1/sqrt in place of sqrt + divide.
-template <typename F, int Q>
-__device__ __forceinline__ void interact(F (&acc)[nres_of(Q)], F dx, F dy, F dz, F d2, F m_src, F m_tgt)
-{
-    const F rinv = rk_rsqrt(d2);
-    const F mr = m_src * rinv;
-    if constexpr (Q == 0 || Q == 2) {
-        const F mr3 = mr * (rinv * rinv);
-        acc[0] = rk_fma(dx, mr3, acc[0]);
-        acc[1] = rk_fma(dy, mr3, acc[1]);
-        acc[2] = rk_fma(dz, mr3, acc[2]);
-    }
-    if constexpr (Q == 1) {
-        acc[0] = rk_fma(-m_tgt, mr, acc[0]);
-    }
-    if constexpr (Q == 2) {
-        acc[3] = rk_fma(-m_tgt, mr, acc[3]);
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // Variant 1: one wavefront per target group, scalar depth-first traversal.
@@ -410,6 +351,28 @@ void launch_traversal(const rk_state &s, int q, const kparams<F> &p, const int64
     }
     RK_HIP(hipGetLastError());
 }
+
+template <typename F>
+void launch_block(const rk_state &s, int q, const kparams<F> &p, const uint32_t *list, int64_t n, hipStream_t stream)
+{
+    if (n <= 0) {
+        return;
+    }
+    const dim3 grid(static_cast<unsigned>(n)), block(256);
+    const int cnt = static_cast<int>(n);
+    switch (q * 2 + s.mac) {
+        case 0: hipLaunchKernelGGL((k_dfs_block<F, 0, 0>), grid, block, 0, stream, p, list, cnt); break;
+        case 1: hipLaunchKernelGGL((k_dfs_block<F, 0, 1>), grid, block, 0, stream, p, list, cnt); break;
+        case 2: hipLaunchKernelGGL((k_dfs_block<F, 1, 0>), grid, block, 0, stream, p, list, cnt); break;
+        case 3: hipLaunchKernelGGL((k_dfs_block<F, 1, 1>), grid, block, 0, stream, p, list, cnt); break;
+        case 4: hipLaunchKernelGGL((k_dfs_block<F, 2, 0>), grid, block, 0, stream, p, list, cnt); break;
+        case 5: hipLaunchKernelGGL((k_dfs_block<F, 2, 1>), grid, block, 0, stream, p, list, cnt); break;
+        default: throw error(RK_EINVAL, "invalid q / mac combination");
+    }
+    RK_HIP(hipGetLastError());
+}
+template void launch_block<float>(const rk_state &, int, const kparams<float> &, const uint32_t *, int64_t, hipStream_t);
+template void launch_block<double>(const rk_state &, int, const kparams<double> &, const uint32_t *, int64_t, hipStream_t);
 
 template void launch_traversal<float>(const rk_state &, int, const kparams<float> &, const int64_t[n_classes],
                                       const int64_t[n_classes], hipStream_t);

@@ -1,0 +1,441 @@
+// Variant 2 of the traversal: per-wavefront interaction lists in LDS.
+//
+// One wavefront serves one target group (critical node). It alternates between two lane mappings:
+//
+//  (1) list building, lane = candidate node. Up to 64 candidate nodes are popped from a per-wave LDS
+//      stack, their records are fetched with 64 independent loads (memory-level parallelism instead of
+//      the dependent scalar chain of variant 1), and every lane tests ITS node against ALL targets of
+//      the group (target coordinates arrive through scalar loads, i.e. as SGPR operands). Accepted nodes
+//      are compacted (ballot + prefix popcount) into an LDS tile of sources {x, y, z, m}; rejected
+//      internal nodes push their children; rejected leaves queue their particle range, which is then
+//      gathered into the same tile.
+//  (2) dense evaluation, lane = (target slot, source split). When the tile is full it is consumed by a
+//      dense targets x sources loop: each lane keeps R targets in registers and walks the tile with
+//      stride NS (the number of source splits that fit in 64 lanes next to the target slots), reading
+//      sources with broadcast ds_read_b128. Accumulators live in registers across tiles; the splits are
+//      summed in a fixed order at the end (deterministic).
+//
+// The MAC decisions are those of the reference's CPU engine (all particles of the critical node must
+// pass, include/rakau/tree.hpp:2662-2672 of the reference), hence the interaction set is identical;
+// only the summation order differs.
+#include "rk_common.hpp"
+#include "rk_device.hpp"
+
+namespace rk
+{
+
+constexpr int LK_STACK_CAP = 768;
+// Worst-case growth of the stack while descending depth-first from one node: 7 pending siblings per level.
+constexpr int LK_DFS_RESERVE = 7 * 21;
+constexpr int LK_LQ_CAP = 128;
+// Groups up to this size keep a copy of their targets in LDS for the MAC test (larger groups read them
+// through the scalar cache instead).
+constexpr int LK_TGT_CAP = 128;
+
+template <typename F>
+struct lk_cfg {
+    static constexpr int src_cap = sizeof(F) == 4 ? 256 : 128; // 4 KiB of sources per wave
+};
+
+// Per-wave LDS: 3 + 4 + 1 + 2 KiB = 10 KiB (fp32), i.e. 40 KiB per 4-wave block, 4 blocks per CU.
+template <typename F>
+struct lk_wave_lds {
+    uint32_t stack[LK_STACK_CAP];
+    typename vt<F>::v4 src[lk_cfg<F>::src_cap];
+    uint2 lq[LK_LQ_CAP];
+    typename vt<F>::v4 tgt[LK_TGT_CAP];
+};
+
+// Blocks are dealt round-robin to the 8 XCDs; give each XCD a contiguous slice of the (Morton-ordered)
+// group list so that the groups resident on one XCD share most of their nodes in that XCD's L2.
+// Bijective for any grid size. Placement only affects speed.
+__device__ __forceinline__ unsigned xcd_chunked_block(unsigned b, unsigned nb)
+{
+    const unsigned q = nb >> 3, r = nb & 7u, xcd = b & 7u, pos = b >> 3;
+    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + pos;
+}
+
+template <typename F, int Q, int R, bool SELF>
+__device__ __forceinline__ void lk_interact_src(const typename vt<F>::v4 &s, int j, const typename vt<F>::v4 (&tp)[R],
+                                                F (&acc)[R][nres_of(Q)], F eps2, const int (&tidx)[R])
+{
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const F ex = s.x - tp[r].x, ey = s.y - tp[r].y, ez = s.z - tp[r].z;
+        F e2 = rk_fma(ez, ez, rk_fma(ey, ey, rk_fma(ex, ex, eps2)));
+        F ms = s.w;
+        if constexpr (SELF) {
+            const bool self = (j == tidx[r]);
+            e2 = self ? F(1) : e2;
+            ms = self ? F(0) : ms;
+        }
+        interact<F, Q>(acc[r], ex, ey, ez, e2, ms, tp[r].w);
+    }
+}
+
+// Dense targets x sources evaluation of one LDS tile. Lane (ts, sp) walks sources sp, sp + ns, ...;
+// the trip count of the main loop is uniform (n_src / ns), the remainder is one masked step.
+template <typename F, int Q, int R, bool SELF>
+__device__ __forceinline__ void lk_eval_tile(const typename vt<F>::v4 *__restrict__ src, int n_src, int sp, int ns,
+                                             bool lane_on, const typename vt<F>::v4 (&tp)[R],
+                                             F (&acc)[R][nres_of(Q)], F eps2, const int (&tidx)[R])
+{
+    using v4 = typename vt<F>::v4;
+    // Keep about four interactions in flight per lane whatever R is.
+    constexpr int UNR = R >= 4 ? 1 : (R == 2 ? 2 : 4);
+    const int full = n_src / ns, rem = n_src - full * ns;
+    const v4 *p = src + sp;
+    int j = sp;
+#pragma unroll UNR
+    for (int it = 0; it < full; ++it) {
+        const v4 s = *p;
+        lk_interact_src<F, Q, R, SELF>(s, j, tp, acc, eps2, tidx);
+        p += ns;
+        j += ns;
+    }
+    if (lane_on && sp < rem) {
+        const v4 s = *p;
+        lk_interact_src<F, Q, R, SELF>(s, j, tp, acc, eps2, tidx);
+    }
+}
+
+template <typename F, int Q, int MAC, int R>
+__global__ void __launch_bounds__(256) k_list(const kparams<F> P, const uint32_t *__restrict__ list, int n_list)
+{
+    using v4 = typename vt<F>::v4;
+    using v2 = typename vt<F>::v2;
+    constexpr int NR = nres_of(Q);
+    constexpr int SRC_CAP = lk_cfg<F>::src_cap;
+    static_assert(sizeof(lk_wave_lds<F>) >= 64 * 4 * sizeof(F), "reduction scratch does not fit");
+    __shared__ lk_wave_lds<F> s_lds[4];
+
+    const int wib = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const unsigned blk = xcd_chunked_block(blockIdx.x, gridDim.x);
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(blk * 4u) + wib);
+    if (wave >= n_list) {
+        return;
+    }
+    lk_wave_lds<F> &L = s_lds[wib];
+
+    const uint32_t g = __builtin_amdgcn_readfirstlane(list[wave]);
+    const uint4 c = P.crit[g];
+    const uint32_t tb = c.x, te = c.y, cnode = c.z;
+    const int T = static_cast<int>(te - tb);
+
+    // Lane mapping of the dense phase: TP target slots, NS source splits.
+    const int TP = (T + R - 1) / R;
+    const int NS = 64 / TP;
+    const int ts = lane % TP, sp_raw = lane / TP;
+    const bool lane_on = sp_raw < NS;
+    const int sp = lane_on ? sp_raw : 0; // idle lanes shadow split 0; their results are never stored
+
+    v4 tp[R];
+    int tidx[R];
+    F acc[R][NR];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        tidx[r] = ts + r * TP;
+        const bool valid = tidx[r] < T;
+        tp[r] = P.part4[tb + (valid ? tidx[r] : 0)];
+        if (!valid) {
+            tidx[r] = -1;
+        }
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            acc[r][k] = F(0);
+        }
+    }
+
+    // Targets for the MAC test, padded to a multiple of 4 with copies of the last one.
+    const bool tgt_in_lds = T <= LK_TGT_CAP;
+    const int T4 = (T + 3) & ~3;
+    if (tgt_in_lds) {
+        for (int t = lane; t < T4; t += 64) {
+            L.tgt[t] = P.part4[tb + static_cast<uint32_t>(t < T ? t : T - 1)];
+        }
+    }
+
+    const F mac_value = P.mac_value, eps2 = P.eps2;
+    int size = 1, n_src = 0, n_lq = 0;
+    if (lane == 0) {
+        L.stack[0] = 0u; // root
+    }
+    wave_sync();
+
+    auto flush = [&]() {
+        if (n_src > 0) {
+            lk_eval_tile<F, Q, R, false>(L.src, n_src, sp, NS, lane_on, tp, acc, eps2, tidx);
+            n_src = 0;
+            wave_sync();
+        }
+    };
+
+    for (;;) {
+        // ---- (1) list building: pop candidates while there is room for their worst-case output ----
+        while (size > 0 && n_src + 64 <= SRC_CAP && n_lq + 64 <= LK_LQ_CAP) {
+            // Batch size: as many as keep the stack within bounds even if every popped node pushes
+            // 8 children; otherwise one node at a time (depth-first), which is bounded by LK_DFS_RESERVE.
+            int k = size < 64 ? size : 64;
+            const int room = (LK_STACK_CAP - LK_DFS_RESERVE - size) / 7;
+            if (room < k) {
+                k = room > 1 ? room : 1;
+            }
+            const bool active = lane < k;
+            const uint32_t node = active ? L.stack[size - 1 - lane] : 0u;
+            size -= k;
+            // Everything about the candidate in four independent 16-byte loads (node 0 for idle lanes).
+            const node_rec<F> *rec = P.node_rec + node;
+            const v4 com = rec->com;
+            const v2 mp = rec->mac;
+            const uint32_t nch = rec->nch;
+            const uint4 lk0 = *reinterpret_cast<const uint4 *>(&rec->link[0]);
+            const uint4 lk1 = *reinterpret_cast<const uint4 *>(&rec->link[4]);
+            // Ancestor-or-self of the target group (tree.hpp:2828-2838 of the reference) on the depth-first
+            // index interval of the subtree.
+            const bool anc = active && node <= cnode && cnode <= node + nch;
+            const bool self = anc && node == cnode;
+            const bool test = active && !anc;
+            const F mac_lh = mac_lhs<F>(MAC, mp, mac_value);
+            // min over the targets of the unsoftened squared distance to the node's centre of mass.
+            F mind2 = std::numeric_limits<F>::infinity();
+            if (tgt_in_lds) {
+#pragma unroll 2
+                for (int t = 0; t < T4; t += 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const v4 tg = L.tgt[t + u];
+                        const F dx = com.x - tg.x, dy = com.y - tg.y, dz = com.z - tg.z;
+                        const F d2 = rk_fma(dz, dz, rk_fma(dy, dy, dx * dx));
+                        mind2 = rk_min(mind2, d2);
+                    }
+                }
+            } else {
+                for (int t = 0; t < T; t += 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int ti = (t + u < T) ? t + u : T - 1;
+                        const v4 tg = P.part4[tb + static_cast<uint32_t>(ti)];
+                        const F dx = com.x - tg.x, dy = com.y - tg.y, dz = com.z - tg.z;
+                        const F d2 = rk_fma(dz, dz, rk_fma(dy, dy, dx * dx));
+                        mind2 = rk_min(mind2, d2);
+                    }
+                }
+            }
+            const bool fail = mac_lh >= mind2;
+            const bool accept = test && !fail;
+            const bool open = (test && fail) || (anc && !self);
+            const bool leaf = open && nch == 0u;
+            const bool expand = open && nch != 0u;
+
+            // Accepted nodes -> source tile.
+            const unsigned long long m_acc = __builtin_amdgcn_ballot_w64(accept);
+            if (accept) {
+                L.src[n_src + static_cast<int>(wave_prefix_count(m_acc))] = com;
+            }
+            n_src += __builtin_popcountll(m_acc);
+            // Opened leaves -> leaf queue.
+            const unsigned long long m_leaf = __builtin_amdgcn_ballot_w64(leaf);
+            if (leaf) {
+                L.lq[n_lq + static_cast<int>(wave_prefix_count(m_leaf))] = make_uint2(lk0.x, lk0.y);
+            }
+            n_lq += __builtin_popcountll(m_leaf);
+            // Opened internal nodes -> children onto the stack.
+            const unsigned long long m_exp = __builtin_amdgcn_ballot_w64(expand);
+            if (m_exp != 0ull) {
+                const uint32_t ch[8] = {lk0.x, lk0.y, lk0.z, lk0.w, lk1.x, lk1.y, lk1.z, lk1.w};
+                unsigned nc = 0;
+                if (expand) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        nc += ch[i] != 0u;
+                    }
+                }
+                const unsigned incl = wave_incl_scan(nc);
+                const int total = __builtin_amdgcn_readlane(static_cast<int>(incl), 63);
+                if (expand) {
+                    // Children are stored so that the first child of the first expanding lane ends on top.
+                    const int base = size + total - static_cast<int>(incl);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        if (static_cast<unsigned>(i) < nc) {
+                            L.stack[base + static_cast<int>(nc) - 1 - i] = ch[i];
+                        }
+                    }
+                }
+                size += total;
+            }
+            wave_sync();
+        }
+
+        // ---- gather the particles of the opened leaves into the tile, evaluating when it fills ----
+        while (n_lq > 0) {
+            const int free_slots = SRC_CAP - n_src;
+            uint2 lf = make_uint2(0u, 0u);
+            if (lane < n_lq) {
+                lf = L.lq[lane];
+            }
+            const unsigned cnt = lane < n_lq ? lf.y - lf.x : 0u;
+            const unsigned incl = wave_incl_scan(cnt);
+            const bool fits = lane < n_lq && incl <= static_cast<unsigned>(free_slots);
+            const unsigned long long m_fit = __builtin_amdgcn_ballot_w64(fits);
+            const int m = __builtin_popcountll(m_fit); // leaves [0, m) fit (prefix property)
+            if (m == 0) {
+                if (n_src > 0) {
+                    flush();
+                    continue;
+                }
+                // A single leaf larger than the whole tile: take SRC_CAP of its particles.
+                const uint32_t b0 = __builtin_amdgcn_readfirstlane(lf.x);
+                for (int j = lane; j < SRC_CAP; j += 64) {
+                    L.src[j] = P.part4[b0 + static_cast<uint32_t>(j)];
+                }
+                if (lane == 0) {
+                    L.lq[0] = make_uint2(b0 + static_cast<uint32_t>(SRC_CAP), lf.y);
+                }
+                n_src = SRC_CAP;
+                wave_sync();
+                flush();
+                continue;
+            }
+            if (fits) {
+                const int dst = n_src + static_cast<int>(incl - cnt);
+                for (unsigned j = 0; j < cnt; ++j) {
+                    L.src[dst + static_cast<int>(j)] = P.part4[lf.x + j];
+                }
+            }
+            n_src += __builtin_amdgcn_readlane(static_cast<int>(incl), m - 1);
+            // Drop the consumed leaves from the queue (move the rest down, 64 entries at a time).
+            const int tail = n_lq - m;
+            wave_sync();
+            for (int j0 = 0; j0 < tail; j0 += 64) {
+                const int j = j0 + lane;
+                uint2 mv = make_uint2(0u, 0u);
+                if (j < tail) {
+                    mv = L.lq[j + m];
+                }
+                wave_sync();
+                if (j < tail) {
+                    L.lq[j] = mv;
+                }
+                wave_sync();
+            }
+            n_lq = tail;
+            if (n_src + 64 > SRC_CAP) {
+                flush();
+            }
+        }
+
+        if (size == 0) {
+            flush();
+            break;
+        }
+        if (n_src + 64 > SRC_CAP) {
+            flush();
+        }
+    }
+
+    // ---- interactions inside the group: its own particles as sources, self-pair masked ----
+    for (int b0 = 0; b0 < T; b0 += SRC_CAP) {
+        const int n = (T - b0) < SRC_CAP ? (T - b0) : SRC_CAP;
+        for (int j = lane; j < n; j += 64) {
+            L.src[j] = P.part4[tb + static_cast<uint32_t>(b0 + j)];
+        }
+        wave_sync();
+        int tloc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            tloc[r] = tidx[r] < 0 ? -1 : tidx[r] - b0;
+        }
+        lk_eval_tile<F, Q, R, true>(L.src, n, sp, NS, lane_on, tp, acc, eps2, tloc);
+        wave_sync();
+    }
+
+    // ---- sum the source splits in a fixed order, scale by G, write out ----
+    const F G = P.G;
+    if (NS > 1) {
+        // One target slot r at a time: the scratch then needs 64 * NR values (<= 2 KiB), well inside
+        // this wave's LDS region for every F, Q and R.
+        F *red = reinterpret_cast<F *>(&L);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (lane_on) {
+#pragma unroll
+                for (int k = 0; k < NR; ++k) {
+                    red[(sp_raw * TP + ts) * NR + k] = acc[r][k];
+                }
+            }
+            wave_sync();
+            if (lane_on && sp_raw == 0) {
+#pragma unroll
+                for (int k = 0; k < NR; ++k) {
+                    F sum = F(0);
+                    for (int s = 0; s < NS; ++s) {
+                        sum += red[(s * TP + ts) * NR + k];
+                    }
+                    acc[r][k] = sum;
+                }
+            }
+            wave_sync();
+        }
+    }
+    if (lane_on && sp_raw == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (tidx[r] >= 0) {
+                const uint32_t o = tb + static_cast<uint32_t>(tidx[r]) - P.out_sub;
+#pragma unroll
+                for (int k = 0; k < NR; ++k) {
+                    P.out[k][o] = acc[r][k] * G;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Launch.
+// ------------------------------------------------------------------------------------------------
+template <typename F, int Q, int MAC>
+static void launch_list_qm(const rk_state &s, const kparams<F> &p, const int64_t cb[n_classes],
+                           const int64_t ce[n_classes], hipStream_t stream)
+{
+    const auto *lists = static_cast<const uint32_t *>(s.buf[RK_BUF_CLASS]);
+    auto go = [&](auto Rtag, int c) {
+        constexpr int R = decltype(Rtag)::value;
+        const int64_t n = ce[c] - cb[c];
+        if (n <= 0) {
+            return;
+        }
+        const auto grid = static_cast<unsigned>((n + 3) / 4);
+        hipLaunchKernelGGL((k_list<F, Q, MAC, R>), dim3(grid), dim3(256), 0, stream, p,
+                           lists + s.class2_off[c] + cb[c], static_cast<int>(n));
+    };
+    go(std::integral_constant<int, 1>{}, 0);
+    go(std::integral_constant<int, 2>{}, 1);
+    go(std::integral_constant<int, 4>{}, 2);
+    go(std::integral_constant<int, 8>{}, 3);
+}
+
+template <typename F>
+void launch_list(const rk_state &s, int q, const kparams<F> &p, const int64_t cb[n_classes],
+                 const int64_t ce[n_classes], hipStream_t stream)
+{
+    switch (q * 2 + s.mac) {
+        case 0: launch_list_qm<F, 0, 0>(s, p, cb, ce, stream); break;
+        case 1: launch_list_qm<F, 0, 1>(s, p, cb, ce, stream); break;
+        case 2: launch_list_qm<F, 1, 0>(s, p, cb, ce, stream); break;
+        case 3: launch_list_qm<F, 1, 1>(s, p, cb, ce, stream); break;
+        case 4: launch_list_qm<F, 2, 0>(s, p, cb, ce, stream); break;
+        case 5: launch_list_qm<F, 2, 1>(s, p, cb, ce, stream); break;
+        default: throw error(RK_EINVAL, "invalid q / mac combination");
+    }
+    RK_HIP(hipGetLastError());
+}
+
+template void launch_list<float>(const rk_state &, int, const kparams<float> &, const int64_t[n_classes],
+                                 const int64_t[n_classes], hipStream_t);
+template void launch_list<double>(const rk_state &, int, const kparams<double> &, const int64_t[n_classes],
+                                  const int64_t[n_classes], hipStream_t);
+
+} // namespace rk

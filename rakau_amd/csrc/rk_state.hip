@@ -102,8 +102,9 @@ void build_host_mirrors(rk_state &s, const std::vector<uint4> &crit)
     s.crit_begin.resize(crit.size());
     s.crit_end.resize(crit.size());
     s.max_group = 0;
-    for (auto &l : s.class_list) {
-        l.clear();
+    for (int c = 0; c < rk::n_classes; ++c) {
+        s.class_list[c].clear();
+        s.class2_list[c].clear();
     }
     for (size_t i = 0; i < crit.size(); ++i) {
         s.crit_begin[i] = crit[i].x;
@@ -111,11 +112,29 @@ void build_host_mirrors(rk_state &s, const std::vector<uint4> &crit)
         const int64_t size = static_cast<int64_t>(crit[i].y) - crit[i].x;
         s.max_group = std::max(s.max_group, size);
         s.class_list[rk::class_of(size)].push_back(static_cast<uint32_t>(i));
+        s.class2_list[rk::class2_of(size)].push_back(static_cast<uint32_t>(i));
     }
+    // Device layout of RK_BUF_CLASS: the variant 1 lists, then the variant 2 lists.
     s.class_off[0] = 0;
     for (int c = 0; c < rk::n_classes; ++c) {
         s.class_off[c + 1] = s.class_off[c] + static_cast<int64_t>(s.class_list[c].size());
     }
+    s.class2_off[0] = s.class_off[rk::n_classes];
+    for (int c = 0; c < rk::n_classes; ++c) {
+        s.class2_off[c + 1] = s.class2_off[c] + static_cast<int64_t>(s.class2_list[c].size());
+    }
+}
+
+std::vector<uint32_t> concat_class_lists(const rk_state &s)
+{
+    std::vector<uint32_t> lists;
+    for (const auto &l : s.class_list) {
+        lists.insert(lists.end(), l.begin(), l.end());
+    }
+    for (const auto &l : s.class2_list) {
+        lists.insert(lists.end(), l.begin(), l.end());
+    }
+    return lists;
 }
 
 template <typename F>
@@ -195,6 +214,27 @@ void create_impl(rk_state &s, const void *const parts[4], int64_t nparts, const 
         }
     }
 
+    // All-in-one records for the list kernel.
+    std::vector<rk::node_rec<F>> recs(nn);
+    for (size_t i = 0; i < nn; ++i) {
+        auto &r = recs[i];
+        r.com = com[i];
+        r.mac = macp[i];
+        r.nch = topo[i].x;
+        r.pad = 0;
+        for (auto &l : r.link) {
+            l = 0;
+        }
+        if (topo[i].x) {
+            for (int k = 0; k < 8; ++k) {
+                r.link[k] = child[static_cast<size_t>(topo[i].w) * 8 + k];
+            }
+        } else {
+            r.link[0] = topo[i].y;
+            r.link[1] = topo[i].z;
+        }
+    }
+
     // Critical nodes: the first node on each root->leaf path with at most ncrit particles or without
     // children (equivalent to the rule at tree.hpp:801-803 of the reference: a node has no children
     // iff it holds at most max_leaf_n particles or sits at the deepest level).
@@ -227,10 +267,7 @@ void create_impl(rk_state &s, const void *const parts[4], int64_t nparts, const 
 
     build_host_mirrors(s, crit);
     s.n_internal = static_cast<int64_t>(n_internal);
-    std::vector<uint32_t> lists;
-    for (const auto &l : s.class_list) {
-        lists.insert(lists.end(), l.begin(), l.end());
-    }
+    const std::vector<uint32_t> lists = concat_class_lists(s);
 
     alloc_upload(s, RK_BUF_PART4, part4.data(), part4.size() * sizeof(v4));
     alloc_upload(s, RK_BUF_NODE_COM, com.data(), com.size() * sizeof(v4));
@@ -239,6 +276,7 @@ void create_impl(rk_state &s, const void *const parts[4], int64_t nparts, const 
     alloc_upload(s, RK_BUF_CRIT, crit.data(), crit.size() * sizeof(uint4));
     alloc_upload(s, RK_BUF_CHILD, child.data(), child.size() * sizeof(uint32_t));
     alloc_upload(s, RK_BUF_CLASS, lists.data(), lists.size() * sizeof(uint32_t));
+    alloc_upload(s, RK_BUF_NODE_REC, recs.data(), recs.size() * sizeof(rk::node_rec<F>));
 }
 
 void check_common(int fp, int mac)
@@ -265,7 +303,7 @@ void check_device(int device)
 
 // Map [p_begin, p_end) onto per-class slices of the group lists.
 void range_to_classes(const rk_state &s, int64_t p_begin, int64_t p_end, int64_t cb[rk::n_classes],
-                      int64_t ce[rk::n_classes])
+                      int64_t ce[rk::n_classes], bool variant2 = false)
 {
     if (p_begin < 0 || p_end < p_begin || p_end > s.nparts) {
         throw rk::error(RK_EINVAL, "invalid particle range [" + std::to_string(p_begin) + ", " + std::to_string(p_end)
@@ -281,7 +319,7 @@ void range_to_classes(const rk_state &s, int64_t p_begin, int64_t p_end, int64_t
                                        + ") does not start and end at critical node boundaries");
     }
     for (int c = 0; c < rk::n_classes; ++c) {
-        const auto &l = s.class_list[c];
+        const auto &l = variant2 ? s.class2_list[c] : s.class_list[c];
         cb[c] = std::lower_bound(l.begin(), l.end(), static_cast<uint32_t>(g0)) - l.begin();
         ce[c] = std::lower_bound(l.begin(), l.end(), static_cast<uint32_t>(g1)) - l.begin();
     }
@@ -297,6 +335,7 @@ rk::kparams<F> base_params(const rk_state &s, double mac_value, double G, double
     p.node_topo = static_cast<const uint4 *>(s.buf[RK_BUF_NODE_TOPO]);
     p.crit = static_cast<const uint4 *>(s.buf[RK_BUF_CRIT]);
     p.child_tab = static_cast<const uint32_t *>(s.buf[RK_BUF_CHILD]);
+    p.node_rec = static_cast<const rk::node_rec<F> *>(s.buf[RK_BUF_NODE_REC]);
     p.n_nodes = static_cast<uint32_t>(s.tree_size);
     p.mac_value = static_cast<F>(mac_value);
     p.eps2 = static_cast<F>(eps2);
@@ -329,19 +368,11 @@ template <typename F>
 void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d_out, double mac_value, double G,
               double eps2, int offset_output, hipStream_t stream)
 {
+    // Variant 2 (LDS interaction lists) is the default; variant 1 is kept for cross-checks.
+    const bool v2 = s.variant != 1;
     int64_t cb[rk::n_classes], ce[rk::n_classes];
-    range_to_classes(s, p_begin, p_end, cb, ce);
-    rk::kparams<F> p{};
-    p.part4 = static_cast<const typename rk::vt<F>::v4 *>(s.buf[RK_BUF_PART4]);
-    p.node_com = static_cast<const typename rk::vt<F>::v4 *>(s.buf[RK_BUF_NODE_COM]);
-    p.node_mac = static_cast<const typename rk::vt<F>::v2 *>(s.buf[RK_BUF_NODE_MAC]);
-    p.node_topo = static_cast<const uint4 *>(s.buf[RK_BUF_NODE_TOPO]);
-    p.crit = static_cast<const uint4 *>(s.buf[RK_BUF_CRIT]);
-    p.child_tab = static_cast<const uint32_t *>(s.buf[RK_BUF_CHILD]);
-    p.n_nodes = static_cast<uint32_t>(s.tree_size);
-    p.mac_value = static_cast<F>(mac_value);
-    p.eps2 = static_cast<F>(eps2);
-    p.G = static_cast<F>(G);
+    range_to_classes(s, p_begin, p_end, cb, ce, v2);
+    auto p = base_params<F>(s, mac_value, G, eps2);
     for (int k = 0; k < rk::nres_of(q); ++k) {
         p.out[k] = static_cast<F *>(d_out[k]);
     }
@@ -351,7 +382,14 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
         RK_HIP(hipEventCreate(&s.ev1));
     }
     RK_HIP(hipEventRecord(s.ev0, stream));
-    rk::launch_traversal<F>(s, q, p, cb, ce, stream);
+    if (v2) {
+        rk::launch_list<F>(s, q, p, cb, ce, stream);
+        // Groups beyond 512 particles are served by the block-per-group kernel in both variants.
+        rk::launch_block<F>(s, q, p, static_cast<const uint32_t *>(s.buf[RK_BUF_CLASS]) + s.class2_off[4] + cb[4],
+                            ce[4] - cb[4], stream);
+    } else {
+        rk::launch_traversal<F>(s, q, p, cb, ce, stream);
+    }
     RK_HIP(hipEventRecord(s.ev1, stream));
     s.timed = true;
 }
@@ -591,7 +629,7 @@ int rk_state_export(const rk_state *s, int *count, void **ptrs, int64_t *bytes, 
             bytes[i] = s->buf_bytes[i];
         }
         std::fill(meta, meta + RK_META_WORDS, int64_t(0));
-        meta[0] = 0x726b3031; // layout tag "rk01"
+        meta[0] = 0x726b3032; // layout tag "rk02"
         meta[1] = s->fp;
         meta[2] = s->mac;
         meta[3] = s->nparts;
@@ -613,7 +651,7 @@ int rk_state_import(rk_state **out, int device, int count, void *const *ptrs, co
             throw rk::error(RK_EINVAL, "null argument");
         }
         *out = nullptr;
-        if (meta[0] != 0x726b3031 || count != RK_NBUF) {
+        if (meta[0] != 0x726b3032 || count != RK_NBUF) {
             throw rk::error(RK_EINVAL, "unrecognised state layout");
         }
         check_common(static_cast<int>(meta[1]), static_cast<int>(meta[2]));

@@ -1,0 +1,46 @@
+"""The C-ABI library loads on a machine without a GPU and exports every symbol include/*.h declares."""
+import ctypes
+import os
+import re
+
+from rakau_amd import _capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    names = []
+    for hdr in ("rakau_amd.h", "rakau_amd_tree.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names += re.findall(r"RK_EXPORT\s+[\w\s\*]+?\b(rk_\w+)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_capi.LIB_PATH)
+    decl = declared_symbols()
+    assert len(decl) >= 20
+    missing = [n for n in decl if not hasattr(lib, n)]
+    assert not missing, missing
+    # The Python binding lists exactly the declared symbols.
+    assert sorted(_capi.SYMBOLS) == decl
+
+
+def test_no_gpu_queries_do_not_crash():
+    lib = _capi.lib()
+    assert lib.rk_min_size() == 64
+    assert lib.rk_device_count() >= 0
+    assert lib.rk_has_accelerator() in (0, 1)
+
+
+def test_product_never_touches_the_oracle():
+    """The product path must not import, link or call anything under oracle/."""
+    for base, _, files in os.walk(os.path.join(ROOT, "rakau_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")) or f == "Makefile":
+                text = open(os.path.join(base, f), errors="ignore").read()
+                assert "oracle" not in text.lower(), os.path.join(base, f)
+    for f in ("rakau_amd.h", "rakau_amd_tree.h", os.path.join("rakau_amd", "tree.hpp"),
+              os.path.join("rakau_amd", "kwargs.hpp")):
+        assert "oracle" not in open(os.path.join(ROOT, "include", f)).read().lower()

@@ -1,0 +1,135 @@
+"""Host side of the product (include/rakau_amd/tree.hpp through its C wrappers) against the CPU oracle:
+tree construction node for node, permutation bookkeeping, exact sums, updates, error behaviour.
+No GPU needed."""
+import numpy as np
+import pytest
+
+import oracle
+import rakau_amd
+
+
+def assert_same_tree(pt, ot):
+    assert (pt.nparts, pt.n_nodes, pt.n_crit) == (ot.nparts, ot.n_nodes, ot.n_crit)
+    assert pt.box_size == ot.box_size
+    on, pn = ot.nodes(), pt.nodes()
+    for k in ("begin", "end", "n_children", "code", "level"):
+        assert np.array_equal(on[k], pn[k]), k
+    assert np.array_equal(on["props"], pn["props"])
+    if ot.mac == "bh":
+        assert np.array_equal(on["dims"][:, 0], pn["dim2"])
+    else:
+        assert np.array_equal(on["dims"][:, 0], pn["dim"])
+        assert np.array_equal(on["dims"][:, 1], pn["delta"])
+    cp = ot.codes_perms()
+    assert np.array_equal(cp["codes"], pt.c_it_u())
+    assert np.array_equal(cp["perm"], pt.perm())
+    assert np.array_equal(cp["last_perm"], pt.last_perm())
+    assert np.array_equal(cp["inv_perm"], pt.inv_perm())
+    assert np.array_equal(ot.crit_nodes(), pt.crit_nodes())
+    for a, b in zip(ot.parts_u(), pt.p_its_u()):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("mac", ["bh", "bh_geom"])
+def test_plummer_tree_matches_oracle(dtype, mac):
+    m, x, y, z = oracle.plummer(150000, dtype)  # large enough to take the task-parallel build path
+    assert_same_tree(rakau_amd.Octree(x, y, z, m, mac=mac), oracle.Tree(x, y, z, m, mac=mac))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_parameter_matrix_matches_oracle(dtype):
+    rng = oracle.Rng(3)
+    for s in (0, 1, 2, 17, 300, 4000):
+        m, x, y, z = rng.uniform_particles(s, 1.0, dtype)
+        for max_leaf_n in (1, 2, 8, 16):
+            for ncrit in (1, 16, 128, 256):
+                for box in (1.0, None):
+                    pt = rakau_amd.Octree(x, y, z, m, box_size=box, max_leaf_n=max_leaf_n, ncrit=ncrit)
+                    ot = oracle.Tree(x, y, z, m, box_size=box or 0.0, max_leaf_n=max_leaf_n, ncrit=ncrit)
+                    if s == 0:
+                        assert pt.n_nodes == 0 and pt.n_crit == 0
+                        continue
+                    assert_same_tree(pt, ot)
+
+
+def test_coincident_particles_and_zero_masses():
+    rng = oracle.Rng(5)
+    m, x, y, z = rng.uniform_particles(3000, 1.0, np.float64)
+    x[:600], y[:600], z[:600] = 0.25, 0.25, -0.125  # deepest-level leaf with 600 particles
+    m[100:200] = 0.0
+    assert_same_tree(rakau_amd.Octree(x, y, z, m, box_size=1.0), oracle.Tree(x, y, z, m, box_size=1.0))
+    mz = np.zeros_like(m)  # massless nodes fall back to the geometric centre (tree.hpp:1176-1185)
+    for mac in ("bh", "bh_geom"):
+        assert_same_tree(rakau_amd.Octree(x, y, z, mz, box_size=1.0, mac=mac),
+                         oracle.Tree(x, y, z, mz, box_size=1.0, mac=mac))
+
+
+def test_auto_box_size():
+    """test/auto_box_size.cpp:38-56: box = 2 * max|coord| * 1.05 (fma form)."""
+    x = np.array([-3.0, 1.0, 2.0])
+    y = np.array([0.5, -1.0, 2.5])
+    z = np.array([0.0, 0.0, 0.0])
+    t = rakau_amd.Octree(x, y, z, np.ones(3))
+    assert t.box_size_deduced
+    assert t.box_size == 6.0 + 6.0 * (1.0 / 20.0)
+
+
+def test_exact_sums_match_oracle():
+    rng = oracle.Rng(9)
+    m, x, y, z = rng.uniform_particles(500, 1.0, np.float64)
+    pt, ot = rakau_amd.Octree(x, y, z, m, box_size=1.0), oracle.Tree(x, y, z, m, box_size=1.0)
+    for i in (0, 7, 499):
+        for ordered in (False, True):
+            for q, fn in ((0, "exact_acc"), (2, "exact_acc_pot")):
+                got = getattr(pt, fn + ("_o" if ordered else "_u"))(i, G=1.5, eps=0.01)
+                assert np.array_equal(got, ot.exact(q, i, G=1.5, eps=0.01, ordered=ordered))
+            assert pt.exact_pot_o(i) == ot.exact(1, i, ordered=True)[0]
+
+
+def test_update_particles_bookkeeping():
+    """test/update.cpp: after update_particles_u the tree equals a fresh tree on the moved particles and
+    perm/last_perm/inv_perm stay consistent."""
+    rng = oracle.Rng(11)
+    m, x, y, z = rng.uniform_particles(5000, 1.0, np.float32)
+    t = rakau_amd.Octree(x, y, z, m, box_size=4.0)
+    old = t.p_its_u()
+    old_perm = t.perm()
+
+    def rotate(arrs):
+        c, s = np.float32(np.cos(0.3)), np.float32(np.sin(0.3))
+        ax, ay = arrs[0].copy(), arrs[1].copy()
+        arrs[0][:] = c * ax - s * ay
+        arrs[1][:] = s * ax + c * ay
+
+    t.update_particles_u(rotate)
+    moved = [v.copy() for v in old]
+    rotate(moved)
+    lp = t.last_perm()
+    for a, b in zip(t.p_its_u(), moved):
+        assert np.array_equal(a, b[lp])
+    assert np.array_equal(t.perm(), old_perm[lp])
+    assert np.array_equal(t.inv_perm()[t.perm()], np.arange(5000, dtype=np.uint64))
+    fresh = oracle.Tree(moved[0], moved[1], moved[2], moved[3], box_size=4.0)
+    pn, on = t.nodes(), fresh.nodes()
+    assert np.array_equal(pn["code"], on["code"]) and np.array_equal(pn["props"], on["props"])
+
+
+def test_constructor_errors():
+    """Messages of tree.hpp:1350-1362, 399-413, 1644-1658."""
+    x = np.array([0.1, 0.2]), np.array([0.1, 0.2]), np.array([0.1, 0.2])
+    m = np.ones(2)
+    with pytest.raises(ValueError, match="maximum number of particles per leaf must be nonzero"):
+        rakau_amd.Octree(*x, m, max_leaf_n=0)
+    with pytest.raises(ValueError, match="critical number of particles"):
+        rakau_amd.Octree(*x, m, ncrit=0)
+    with pytest.raises(ValueError, match="box size must be a finite non-negative value"):
+        rakau_amd.Octree(*x, m, box_size=-1.0)
+    with pytest.raises(ValueError, match="outside the allowed bounds"):
+        rakau_amd.Octree(*x, m, box_size=0.1)
+    with pytest.raises(ValueError, match="non-finite"):
+        rakau_amd.Octree(np.array([0.1, np.inf]), x[1], x[2], m)
+    with pytest.raises(ValueError, match="inconsistent sizes"):
+        rakau_amd.Octree(np.ones(3), x[1], x[2], m)
+    with pytest.raises(ValueError, match="particle masses"):
+        rakau_amd.Octree(*x, np.ones(3))
