@@ -69,19 +69,24 @@ inline int class2_of(int64_t size)
     return best;
 }
 
-// All-in-one node record of the list kernel: one aligned record per node so that a lane fetches
-// everything it may need about its candidate node (including the indices of its children) with
-// independent 16-byte loads issued together. Leaves store their particle range where internal nodes
-// store their children.
+// Node records of the list kernel, stored in SIBLING order: the children of a node occupy consecutive
+// records, so that one stack entry (first child, number of children) names up to 8 candidate nodes and a
+// wave fetches them with coalesced loads. `dfs` / `nch` keep the depth-first index and descendant count of
+// the reference's layout (needed for the ancestor test and nothing else). Leaves store their particle
+// range where internal nodes store the location of their children.
 template <typename F>
 struct node_rec {
     typename vt<F>::v4 com; // COM x, y, z, mass
     typename vt<F>::v2 mac; // {dim2, 0} (bh) or {dim, delta} (bh_geom)
+    uint32_t dfs;           // index of the node in the depth-first array
     uint32_t nch;           // number of descendants (0 for a leaf)
-    uint32_t pad;
-    uint32_t link[8];       // internal node: child node indices (0 = none); leaf: {begin, end, 0...}
+    uint32_t a, b;          // internal node: a = record index of the first child, b = number of children
+                            // leaf: a = first particle, b = one past the last particle
+    uint32_t pad[2];
 };
-static_assert(sizeof(node_rec<float>) == 64 && sizeof(node_rec<double>) == 96, "unexpected node record size");
+static_assert(sizeof(node_rec<float>) == 48 && sizeof(node_rec<double>) == 96, "unexpected node record size");
+// A stack entry packs (first child record << 3) | (number of children - 1).
+constexpr uint32_t max_list_nodes = 1u << 29;
 
 // Kernel parameter block (passed by value).
 template <typename F>

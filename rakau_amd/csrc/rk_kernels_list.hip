@@ -24,8 +24,10 @@
 namespace rk
 {
 
-constexpr int LK_STACK_CAP = 768;
-// Worst-case growth of the stack while descending depth-first from one node: 7 pending siblings per level.
+// Stack of pending sibling runs; an entry = (first child record << 3) | (number of children - 1) names up to
+// 8 candidate nodes. Popping k entries can push at most 8k (every candidate opened).
+constexpr int LK_STACK_CAP = 384;
+// Worst-case growth of the stack while descending depth-first from one entry: 7 pending entries per level.
 constexpr int LK_DFS_RESERVE = 7 * 21;
 constexpr int LK_LQ_CAP = 128;
 // Groups up to this size keep a copy of their targets in LDS for the MAC test (larger groups read them
@@ -37,7 +39,7 @@ struct lk_cfg {
     static constexpr int src_cap = sizeof(F) == 4 ? 256 : 128; // 4 KiB of sources per wave
 };
 
-// Per-wave LDS: 3 + 4 + 1 + 2 KiB = 10 KiB (fp32), i.e. 40 KiB per 4-wave block, 4 blocks per CU.
+// Per-wave LDS: 1.5 + 4 + 1 + 2 KiB = 8.5 KiB (fp32).
 template <typename F>
 struct lk_wave_lds {
     uint32_t stack[LK_STACK_CAP];
@@ -157,9 +159,17 @@ __global__ void __launch_bounds__(256) k_list(const kparams<F> P, const uint32_t
     }
 
     const F mac_value = P.mac_value, eps2 = P.eps2;
-    int size = 1, n_src = 0, n_lq = 0;
-    if (lane == 0) {
-        L.stack[0] = 0u; // root
+    int size = 0, n_src = 0, n_lq = 0;
+    {
+        // The root is an ancestor of every group (or the group itself): start from its children.
+        const node_rec<F> *root = P.node_rec;
+        const uint32_t r_nch = root->nch, r_a = root->a, r_b = root->b;
+        if (cnode != 0u && r_nch != 0u) {
+            if (lane == 0) {
+                L.stack[0] = (r_a << 3) | (r_b - 1u);
+            }
+            size = 1;
+        }
     }
     wave_sync();
 
@@ -174,23 +184,26 @@ __global__ void __launch_bounds__(256) k_list(const kparams<F> P, const uint32_t
     for (;;) {
         // ---- (1) list building: pop candidates while there is room for their worst-case output ----
         while (size > 0 && n_src + 64 <= SRC_CAP && n_lq + 64 <= LK_LQ_CAP) {
-            // Batch size: as many as keep the stack within bounds even if every popped node pushes
-            // 8 children; otherwise one node at a time (depth-first), which is bounded by LK_DFS_RESERVE.
-            int k = size < 64 ? size : 64;
+            // Number of entries to pop: up to 8 (64 candidates) while the stack stays within bounds even
+            // if every candidate is opened; otherwise one entry at a time (depth-first), whose growth is
+            // bounded by LK_DFS_RESERVE.
+            int k = size < 8 ? size : 8;
             const int room = (LK_STACK_CAP - LK_DFS_RESERVE - size) / 7;
             if (room < k) {
                 k = room > 1 ? room : 1;
             }
-            const bool active = lane < k;
-            const uint32_t node = active ? L.stack[size - 1 - lane] : 0u;
+            const int e_idx = lane >> 3, e_sub = lane & 7;
+            uint32_t entry = 0u;
+            if (e_idx < k) {
+                entry = L.stack[size - 1 - e_idx];
+            }
             size -= k;
-            // Everything about the candidate in four independent 16-byte loads (node 0 for idle lanes).
-            const node_rec<F> *rec = P.node_rec + node;
+            const bool active = e_idx < k && static_cast<uint32_t>(e_sub) <= (entry & 7u);
+            // Everything about the candidate in three independent 16-byte loads (record 0 for idle lanes).
+            const node_rec<F> *rec = P.node_rec + (active ? (entry >> 3) + static_cast<uint32_t>(e_sub) : 0u);
             const v4 com = rec->com;
             const v2 mp = rec->mac;
-            const uint32_t nch = rec->nch;
-            const uint4 lk0 = *reinterpret_cast<const uint4 *>(&rec->link[0]);
-            const uint4 lk1 = *reinterpret_cast<const uint4 *>(&rec->link[4]);
+            const uint32_t node = rec->dfs, nch = rec->nch, ra = rec->a, rb = rec->b;
             // Ancestor-or-self of the target group (tree.hpp:2828-2838 of the reference) on the depth-first
             // index interval of the subtree.
             const bool anc = active && node <= cnode && cnode <= node + nch;
@@ -237,34 +250,15 @@ __global__ void __launch_bounds__(256) k_list(const kparams<F> P, const uint32_t
             // Opened leaves -> leaf queue.
             const unsigned long long m_leaf = __builtin_amdgcn_ballot_w64(leaf);
             if (leaf) {
-                L.lq[n_lq + static_cast<int>(wave_prefix_count(m_leaf))] = make_uint2(lk0.x, lk0.y);
+                L.lq[n_lq + static_cast<int>(wave_prefix_count(m_leaf))] = make_uint2(ra, rb);
             }
             n_lq += __builtin_popcountll(m_leaf);
-            // Opened internal nodes -> children onto the stack.
+            // Opened internal nodes -> their run of children onto the stack.
             const unsigned long long m_exp = __builtin_amdgcn_ballot_w64(expand);
-            if (m_exp != 0ull) {
-                const uint32_t ch[8] = {lk0.x, lk0.y, lk0.z, lk0.w, lk1.x, lk1.y, lk1.z, lk1.w};
-                unsigned nc = 0;
-                if (expand) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        nc += ch[i] != 0u;
-                    }
-                }
-                const unsigned incl = wave_incl_scan(nc);
-                const int total = __builtin_amdgcn_readlane(static_cast<int>(incl), 63);
-                if (expand) {
-                    // Children are stored so that the first child of the first expanding lane ends on top.
-                    const int base = size + total - static_cast<int>(incl);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        if (static_cast<unsigned>(i) < nc) {
-                            L.stack[base + static_cast<int>(nc) - 1 - i] = ch[i];
-                        }
-                    }
-                }
-                size += total;
+            if (expand) {
+                L.stack[size + static_cast<int>(wave_prefix_count(m_exp))] = (ra << 3) | (rb - 1u);
             }
+            size += __builtin_popcountll(m_exp);
             wave_sync();
         }
 

@@ -214,24 +214,36 @@ void create_impl(rk_state &s, const void *const parts[4], int64_t nparts, const 
         }
     }
 
-    // All-in-one records for the list kernel.
+    // Records for the list kernel in sibling order: record 0 is the root; walking the depth-first array,
+    // every internal node gets the next free run of records for its children.
     std::vector<rk::node_rec<F>> recs(nn);
-    for (size_t i = 0; i < nn; ++i) {
-        auto &r = recs[i];
-        r.com = com[i];
-        r.mac = macp[i];
-        r.nch = topo[i].x;
-        r.pad = 0;
-        for (auto &l : r.link) {
-            l = 0;
-        }
-        if (topo[i].x) {
-            for (int k = 0; k < 8; ++k) {
-                r.link[k] = child[static_cast<size_t>(topo[i].w) * 8 + k];
+    {
+        std::vector<uint32_t> rec_of(nn, 0u); // depth-first index -> record index
+        uint32_t next = nn ? 1u : 0u;
+        for (size_t i = 0; i < nn; ++i) {
+            auto &r = recs[rec_of[i]];
+            r.com = com[i];
+            r.mac = macp[i];
+            r.dfs = static_cast<uint32_t>(i);
+            r.nch = topo[i].x;
+            r.pad[0] = r.pad[1] = 0;
+            if (topo[i].x) {
+                const uint32_t *ch = &child[static_cast<size_t>(topo[i].w) * 8];
+                uint32_t cnt = 0;
+                while (cnt < 8 && ch[cnt]) {
+                    rec_of[ch[cnt]] = next + cnt;
+                    ++cnt;
+                }
+                r.a = next;
+                r.b = cnt;
+                next += cnt;
+            } else {
+                r.a = topo[i].y;
+                r.b = topo[i].z;
             }
-        } else {
-            r.link[0] = topo[i].y;
-            r.link[1] = topo[i].z;
+        }
+        if (nn && next != nn) {
+            throw rk::error(RK_EINVAL, "inconsistent tree: not every node is reachable from the root");
         }
     }
 
@@ -490,6 +502,10 @@ int rk_state_create(rk_state **out, int fp, int mac, int device, const void *con
         }
         if (!ncrit) {
             throw rk::error(RK_EINVAL, "ncrit must be nonzero");
+        }
+        if (static_cast<uint64_t>(tree_size) >= rk::max_list_nodes) {
+            throw rk::error(RK_EOVERFLOW, "The number of tree nodes (" + std::to_string(tree_size)
+                                              + ") exceeds the 2^29 limit of the traversal kernel's node references");
         }
         check_device(device);
         device_guard dg(device);
