@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librakau_amd.so")
+# RAKAU_AMD_LIB selects an alternative build of the same library (diagnostic builds).
+LIB_PATH = os.environ.get("RAKAU_AMD_LIB") or os.path.join(_HERE, "lib", "librakau_amd.so")
 
 RK_F32, RK_F64 = 0, 1
 RK_MAC_BH, RK_MAC_BH_GEOM = 0, 1

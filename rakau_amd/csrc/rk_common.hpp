@@ -97,11 +97,13 @@ struct kparams {
     const uint4 *node_topo;             // {n_children, begin, end, child-table slot}
     const uint4 *crit;                  // target groups: {begin, end, node index, size}
     const uint32_t *child_tab;          // 8 child node indices per internal node (0 = none)
-    const node_rec<F> *node_rec;        // all-in-one records (list kernel)
+    const node_rec<F> *node_rec;        // sibling-ordered records (list kernel)
+    const typename vt<F>::v4 *crit_box; // per target group: {min x,y,z, -}, {max x,y,z, -} of its particles
     uint32_t n_nodes;
     F mac_value, eps2, G;
     F *out[4];
     uint32_t out_sub; // value subtracted from the particle index when writing (compact output)
+    unsigned long long *dbg; // diagnostic builds only (RK_STAMPS): per-section cycle totals
 };
 
 struct error : std::runtime_error {
@@ -121,7 +123,7 @@ struct error : std::runtime_error {
 } // namespace rk
 
 // Device buffer indices in rk_state::buf (also the export order).
-enum { RK_BUF_PART4 = 0, RK_BUF_NODE_COM, RK_BUF_NODE_MAC, RK_BUF_NODE_TOPO, RK_BUF_CRIT, RK_BUF_CHILD, RK_BUF_CLASS, RK_BUF_NODE_REC, RK_NBUF };
+enum { RK_BUF_PART4 = 0, RK_BUF_NODE_COM, RK_BUF_NODE_MAC, RK_BUF_NODE_TOPO, RK_BUF_CRIT, RK_BUF_CHILD, RK_BUF_CLASS, RK_BUF_NODE_REC, RK_BUF_CRIT_BOX, RK_NBUF };
 
 struct rk_state {
     int fp = 0, mac = 0, device = 0;

@@ -43,6 +43,15 @@ __device__ __forceinline__ double rk_min(double a, double b)
     return __builtin_fmin(a, b);
 }
 
+__device__ __forceinline__ float rk_max3(float a, float b, float c)
+{
+    return __builtin_fmaxf(__builtin_fmaxf(a, b), c); // folds to v_max3_f32
+}
+__device__ __forceinline__ double rk_max3(double a, double b, double c)
+{
+    return __builtin_fmax(__builtin_fmax(a, b), c);
+}
+
 template <typename F>
 __device__ __forceinline__ F mac_lhs(int mac, typename vt<F>::v2 mp, F mac_value)
 {

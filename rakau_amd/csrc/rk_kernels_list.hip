@@ -24,28 +24,53 @@
 namespace rk
 {
 
+#ifdef RK_STAMPS
+// Diagnostic build: wave-lifetime cycles per section (s_memtime), summed over waves into P.dbg[].
+#define RK_STAMP_DECL unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define RK_STAMP(i)                                                                                                    \
+    {                                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        const unsigned long long st_t1 = __builtin_amdgcn_s_memtime();                                                 \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        st_acc[i] += st_t1 - st_t0;                                                                                    \
+        st_t0 = st_t1;                                                                                                 \
+    }
+#define RK_STAMP_FLUSH                                                                                                 \
+    if (lane == 0 && P.dbg) {                                                                                          \
+        for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&P.dbg[i_], st_acc[i_]);                                              \
+    }
+#else
+#define RK_STAMP_DECL
+#define RK_STAMP(i)
+#define RK_STAMP_FLUSH
+#endif
+
 // Stack of pending sibling runs; an entry = (first child record << 3) | (number of children - 1) names up to
 // 8 candidate nodes. Popping k entries can push at most 8k (every candidate opened).
-constexpr int LK_STACK_CAP = 384;
+constexpr int LK_STACK_CAP = 512;
 // Worst-case growth of the stack while descending depth-first from one entry: 7 pending entries per level.
 constexpr int LK_DFS_RESERVE = 7 * 21;
 constexpr int LK_LQ_CAP = 128;
 // Groups up to this size keep a copy of their targets in LDS for the MAC test (larger groups read them
 // through the scalar cache instead).
 constexpr int LK_TGT_CAP = 128;
+// Queue of candidates left undecided by the bounding-box / probe tests.
+constexpr int LK_UQ_CAP = 128;
 
 template <typename F>
 struct lk_cfg {
     static constexpr int src_cap = sizeof(F) == 4 ? 256 : 128; // 4 KiB of sources per wave
 };
 
-// Per-wave LDS: 1.5 + 4 + 1 + 2 KiB = 8.5 KiB (fp32).
+// Per-wave LDS: 2 + 4 + 1 + 2 + 0.5 KiB = 9.5 KiB (fp32).
 template <typename F>
 struct lk_wave_lds {
     uint32_t stack[LK_STACK_CAP];
     typename vt<F>::v4 src[lk_cfg<F>::src_cap];
     uint2 lq[LK_LQ_CAP];
     typename vt<F>::v4 tgt[LK_TGT_CAP];
+    uint32_t uq[LK_UQ_CAP]; // records whose MAC test needs the exact all-targets loop
 };
 
 // Blocks are dealt round-robin to the 8 XCDs; give each XCD a contiguous slice of the (Morton-ordered)
@@ -83,6 +108,9 @@ __device__ __forceinline__ void lk_eval_tile(const typename vt<F>::v4 *__restric
                                              F (&acc)[R][nres_of(Q)], F eps2, const int (&tidx)[R])
 {
     using v4 = typename vt<F>::v4;
+#ifdef RK_ABLATE_DENSE
+    return; // diagnostic build: list building only
+#endif
     // Keep about four interactions in flight per lane whatever R is.
     constexpr int UNR = R >= 4 ? 1 : (R == 2 ? 2 : 4);
     const int full = n_src / ns, rem = n_src - full * ns;
@@ -159,7 +187,11 @@ __global__ void __launch_bounds__(256) k_list(const kparams<F> P, const uint32_t
     }
 
     const F mac_value = P.mac_value, eps2 = P.eps2;
-    int size = 0, n_src = 0, n_lq = 0;
+    // Bounding box of the group's particles and two probe targets (first and last): wave-uniform.
+    const v4 blo = P.crit_box[2u * g], bhi = P.crit_box[2u * g + 1u];
+    const v4 pr0 = P.part4[tb], pr1 = P.part4[te - 1u];
+    RK_STAMP_DECL
+    int size = 0, n_src = 0, n_lq = 0, n_uq = 0;
     {
         // The root is an ancestor of every group (or the group itself): start from its children.
         const node_rec<F> *root = P.node_rec;
@@ -173,97 +205,20 @@ __global__ void __launch_bounds__(256) k_list(const kparams<F> P, const uint32_t
     }
     wave_sync();
 
-    auto flush = [&]() {
+    auto flush = [&]() __attribute__((always_inline)) {
         if (n_src > 0) {
+            RK_STAMP(7)
             lk_eval_tile<F, Q, R, false>(L.src, n_src, sp, NS, lane_on, tp, acc, eps2, tidx);
             n_src = 0;
             wave_sync();
+            RK_STAMP(4)
         }
     };
 
-    for (;;) {
-        // ---- (1) list building: pop candidates while there is room for their worst-case output ----
-        while (size > 0 && n_src + 64 <= SRC_CAP && n_lq + 64 <= LK_LQ_CAP) {
-            // Number of entries to pop: up to 8 (64 candidates) while the stack stays within bounds even
-            // if every candidate is opened; otherwise one entry at a time (depth-first), whose growth is
-            // bounded by LK_DFS_RESERVE.
-            int k = size < 8 ? size : 8;
-            const int room = (LK_STACK_CAP - LK_DFS_RESERVE - size) / 7;
-            if (room < k) {
-                k = room > 1 ? room : 1;
-            }
-            const int e_idx = lane >> 3, e_sub = lane & 7;
-            uint32_t entry = 0u;
-            if (e_idx < k) {
-                entry = L.stack[size - 1 - e_idx];
-            }
-            size -= k;
-            const bool active = e_idx < k && static_cast<uint32_t>(e_sub) <= (entry & 7u);
-            // Everything about the candidate in three independent 16-byte loads (record 0 for idle lanes).
-            const node_rec<F> *rec = P.node_rec + (active ? (entry >> 3) + static_cast<uint32_t>(e_sub) : 0u);
-            const v4 com = rec->com;
-            const v2 mp = rec->mac;
-            const uint32_t node = rec->dfs, nch = rec->nch, ra = rec->a, rb = rec->b;
-            // Ancestor-or-self of the target group (tree.hpp:2828-2838 of the reference) on the depth-first
-            // index interval of the subtree.
-            const bool anc = active && node <= cnode && cnode <= node + nch;
-            const bool self = anc && node == cnode;
-            const bool test = active && !anc;
-            const F mac_lh = mac_lhs<F>(MAC, mp, mac_value);
-            // min over the targets of the unsoftened squared distance to the node's centre of mass.
-            F mind2 = std::numeric_limits<F>::infinity();
-            if (tgt_in_lds) {
-#pragma unroll 2
-                for (int t = 0; t < T4; t += 4) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const v4 tg = L.tgt[t + u];
-                        const F dx = com.x - tg.x, dy = com.y - tg.y, dz = com.z - tg.z;
-                        const F d2 = rk_fma(dz, dz, rk_fma(dy, dy, dx * dx));
-                        mind2 = rk_min(mind2, d2);
-                    }
-                }
-            } else {
-                for (int t = 0; t < T; t += 4) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int ti = (t + u < T) ? t + u : T - 1;
-                        const v4 tg = P.part4[tb + static_cast<uint32_t>(ti)];
-                        const F dx = com.x - tg.x, dy = com.y - tg.y, dz = com.z - tg.z;
-                        const F d2 = rk_fma(dz, dz, rk_fma(dy, dy, dx * dx));
-                        mind2 = rk_min(mind2, d2);
-                    }
-                }
-            }
-            const bool fail = mac_lh >= mind2;
-            const bool accept = test && !fail;
-            const bool open = (test && fail) || (anc && !self);
-            const bool leaf = open && nch == 0u;
-            const bool expand = open && nch != 0u;
-
-            // Accepted nodes -> source tile.
-            const unsigned long long m_acc = __builtin_amdgcn_ballot_w64(accept);
-            if (accept) {
-                L.src[n_src + static_cast<int>(wave_prefix_count(m_acc))] = com;
-            }
-            n_src += __builtin_popcountll(m_acc);
-            // Opened leaves -> leaf queue.
-            const unsigned long long m_leaf = __builtin_amdgcn_ballot_w64(leaf);
-            if (leaf) {
-                L.lq[n_lq + static_cast<int>(wave_prefix_count(m_leaf))] = make_uint2(ra, rb);
-            }
-            n_lq += __builtin_popcountll(m_leaf);
-            // Opened internal nodes -> their run of children onto the stack.
-            const unsigned long long m_exp = __builtin_amdgcn_ballot_w64(expand);
-            if (expand) {
-                L.stack[size + static_cast<int>(wave_prefix_count(m_exp))] = (ra << 3) | (rb - 1u);
-            }
-            size += __builtin_popcountll(m_exp);
-            wave_sync();
-        }
-
-        // ---- gather the particles of the opened leaves into the tile, evaluating when it fills ----
+    // Gather the particles of the queued leaves into the source tile, evaluating the tile when it fills.
+    auto drain_leaves = [&]() __attribute__((always_inline)) {
         while (n_lq > 0) {
+            RK_STAMP(7)
             const int free_slots = SRC_CAP - n_src;
             uint2 lf = make_uint2(0u, 0u);
             if (lane < n_lq) {
@@ -292,10 +247,23 @@ __global__ void __launch_bounds__(256) k_list(const kparams<F> P, const uint32_t
                 flush();
                 continue;
             }
-            if (fits) {
-                const int dst = n_src + static_cast<int>(incl - cnt);
-                for (unsigned j = 0; j < cnt; ++j) {
-                    L.src[dst + static_cast<int>(j)] = P.part4[lf.x + j];
+            // Lane l copies the particles of leaf l, eight loads in flight at a time.
+            const unsigned mycnt = fits ? cnt : 0u;
+            const int dst = n_src + static_cast<int>(incl - cnt);
+            for (unsigned j0 = 0; __builtin_amdgcn_ballot_w64(j0 < mycnt) != 0ull; j0 += 8u) {
+                v4 tmp[8];
+                // Unconditional loads (index clamped into the leaf; particle 0 for idle lanes).
+                const uint32_t lbase = mycnt ? lf.x : 0u, llast = mycnt ? mycnt - 1u : 0u;
+#pragma unroll
+                for (unsigned u = 0; u < 8u; ++u) {
+                    const uint32_t jj = j0 + u < llast ? j0 + u : llast;
+                    tmp[u] = P.part4[lbase + jj];
+                }
+#pragma unroll
+                for (unsigned u = 0; u < 8u; ++u) {
+                    if (j0 + u < mycnt) {
+                        L.src[dst + static_cast<int>(j0 + u)] = tmp[u];
+                    }
                 }
             }
             n_src += __builtin_amdgcn_readlane(static_cast<int>(incl), m - 1);
@@ -315,20 +283,206 @@ __global__ void __launch_bounds__(256) k_list(const kparams<F> P, const uint32_t
                 wave_sync();
             }
             n_lq = tail;
+            RK_STAMP(3)
             if (n_src + 64 > SRC_CAP) {
                 flush();
             }
         }
+    };
 
+    // A batch of up to 64 candidate nodes held in registers (lane = candidate).
+    struct batch_t {
+        bool active;
+        v4 com;
+        v2 mp;
+        uint32_t node, nch, ra, rb, rec;
+    };
+    // Pop up to 8 sibling runs and issue the loads of their records. `pending` = number of entries that
+    // batches already in flight may still push. Returns the number of entries popped.
+    auto pop_and_load = [&](batch_t &bt, int pending, bool allow_dfs) __attribute__((always_inline)) -> int {
         if (size == 0) {
+            return 0;
+        }
+        int k = size < 8 ? size : 8;
+        // Keep the stack within bounds even if every candidate is opened (8 pushes per popped entry);
+        // otherwise fall back to one entry at a time (depth-first), whose growth is bounded by
+        // LK_DFS_RESERVE -- only when nothing else is in flight.
+        const int room = (LK_STACK_CAP - LK_DFS_RESERVE - pending - n_uq - size) / 7;
+        if (room < k) {
+            if (room >= 1) {
+                k = room;
+            } else if (allow_dfs) {
+                k = 1;
+            } else {
+                return 0;
+            }
+        }
+        const int e_idx = lane >> 3, e_sub = lane & 7;
+        uint32_t entry = 0u;
+        if (e_idx < k) {
+            entry = L.stack[size - 1 - e_idx];
+        }
+        size -= k;
+        bt.active = e_idx < k && static_cast<uint32_t>(e_sub) <= (entry & 7u);
+        // Everything about the candidate in three independent 16-byte loads (record 0 for idle lanes).
+        bt.rec = bt.active ? (entry >> 3) + static_cast<uint32_t>(e_sub) : 0u;
+        const node_rec<F> *rec = P.node_rec + bt.rec;
+        bt.com = rec->com;
+        bt.mp = rec->mac;
+        bt.node = rec->dfs;
+        bt.nch = rec->nch;
+        bt.ra = rec->a;
+        bt.rb = rec->b;
+        return k;
+    };
+
+    // Route classified candidates: accepted nodes go to the source tile, opened leaves to the leaf queue,
+    // opened internal nodes push their run of children, undecided ones go to the exact-test queue.
+    auto route = [&](bool accept, bool open, bool undecided, const batch_t &bt) __attribute__((always_inline)) {
+        const bool leaf = open && bt.nch == 0u;
+        const bool expand = open && bt.nch != 0u;
+        const unsigned long long m_acc = __builtin_amdgcn_ballot_w64(accept);
+        if (accept) {
+            L.src[n_src + static_cast<int>(wave_prefix_count(m_acc))] = bt.com;
+        }
+        n_src += __builtin_popcountll(m_acc);
+        const unsigned long long m_leaf = __builtin_amdgcn_ballot_w64(leaf);
+        if (leaf) {
+            L.lq[n_lq + static_cast<int>(wave_prefix_count(m_leaf))] = make_uint2(bt.ra, bt.rb);
+        }
+        n_lq += __builtin_popcountll(m_leaf);
+        const unsigned long long m_exp = __builtin_amdgcn_ballot_w64(expand);
+        if (expand) {
+            L.stack[size + static_cast<int>(wave_prefix_count(m_exp))] = (bt.ra << 3) | (bt.rb - 1u);
+        }
+        size += __builtin_popcountll(m_exp);
+        const unsigned long long m_und = __builtin_amdgcn_ballot_w64(undecided);
+        if (undecided) {
+            L.uq[n_uq + static_cast<int>(wave_prefix_count(m_und))] = bt.rec;
+        }
+        n_uq += __builtin_popcountll(m_und);
+        wave_sync();
+    };
+
+    // First-stage MAC test of one batch. The reference's criterion is "every target t of the group has
+    // d2(t) > mac_lh" with d2(t) the squared distance from target t to the node's centre of mass
+    // (tree.hpp:2662-2672). Two cheap tests reproduce that decision for most candidates:
+    //  * accept if the squared distance from the centre of mass to the group's bounding box exceeds mac_lh
+    //    by a margin (1e-5 relative, far above the ~1e-6 rounding of either quantity): every d2(t) is larger;
+    //  * open if one of two probe targets already violates the criterion (same formula as the exact test).
+    // The rest is queued for the exact all-targets loop, so every decision equals the reference's.
+    auto process = [&](const batch_t &bt) __attribute__((always_inline)) {
+        const v4 com = bt.com;
+        // Ancestor-or-self of the target group (tree.hpp:2828-2838 of the reference) on the depth-first
+        // index interval of the subtree.
+        const bool anc = bt.active && bt.node <= cnode && cnode <= bt.node + bt.nch;
+        const bool self = anc && bt.node == cnode;
+        const bool test = bt.active && !anc;
+        const F mac_lh = mac_lhs<F>(MAC, bt.mp, mac_value);
+#ifdef RK_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st_acc[6] += 1;
+#endif
+        RK_STAMP(0)
+        const F bx = rk_max3(blo.x - com.x, com.x - bhi.x, F(0)), by = rk_max3(blo.y - com.y, com.y - bhi.y, F(0)),
+                bz = rk_max3(blo.z - com.z, com.z - bhi.z, F(0));
+        const F dbox2 = rk_fma(bz, bz, rk_fma(by, by, bx * bx));
+        const bool box_accept = dbox2 > mac_lh * F(1.00001);
+        const F p0x = com.x - pr0.x, p0y = com.y - pr0.y, p0z = com.z - pr0.z;
+        const F p1x = com.x - pr1.x, p1y = com.y - pr1.y, p1z = com.z - pr1.z;
+        const F d2p0 = rk_fma(p0z, p0z, rk_fma(p0y, p0y, p0x * p0x)), d2p1 = rk_fma(p1z, p1z, rk_fma(p1y, p1y, p1x * p1x));
+        const bool probe_open = mac_lh >= rk_min(d2p0, d2p1);
+        RK_STAMP(1)
+        const bool accept = test && box_accept;
+        const bool open = (test && !box_accept && probe_open) || (anc && !self);
+        const bool undecided = test && !box_accept && !probe_open;
+        route(accept, open, undecided, bt);
+        RK_STAMP(2)
+    };
+
+    // Exact MAC test (all targets) of up to 64 queued candidates.
+    auto process_exact = [&]() __attribute__((always_inline)) {
+        const int k = n_uq < 64 ? n_uq : 64;
+        batch_t bt;
+        bt.active = lane < k;
+        bt.rec = bt.active ? L.uq[n_uq - 1 - lane] : 0u;
+        n_uq -= k;
+        const node_rec<F> *rec = P.node_rec + bt.rec;
+        bt.com = rec->com;
+        bt.mp = rec->mac;
+        bt.node = rec->dfs;
+        bt.nch = rec->nch;
+        bt.ra = rec->a;
+        bt.rb = rec->b;
+        const v4 com = bt.com;
+        const F mac_lh = mac_lhs<F>(MAC, bt.mp, mac_value);
+        // min over the targets of the unsoftened squared distance to the node's centre of mass.
+        F mind2 = std::numeric_limits<F>::infinity();
+        if (tgt_in_lds) {
+#pragma unroll 2
+            for (int t = 0; t < T4; t += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const v4 tg = L.tgt[t + u];
+                    const F dx = com.x - tg.x, dy = com.y - tg.y, dz = com.z - tg.z;
+                    const F d2 = rk_fma(dz, dz, rk_fma(dy, dy, dx * dx));
+                    mind2 = rk_min(mind2, d2);
+                }
+            }
+        } else {
+            for (int t = 0; t < T; t += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ti = (t + u < T) ? t + u : T - 1;
+                    const v4 tg = P.part4[tb + static_cast<uint32_t>(ti)];
+                    const F dx = com.x - tg.x, dy = com.y - tg.y, dz = com.z - tg.z;
+                    const F d2 = rk_fma(dz, dz, rk_fma(dy, dy, dx * dx));
+                    mind2 = rk_min(mind2, d2);
+                }
+            }
+        }
+        const bool fail = mac_lh >= mind2;
+        route(bt.active && !fail, bt.active && fail, false, bt);
+        RK_STAMP(3)
+    };
+
+    // ---- list building, software-pipelined: while batch A is tested, the records of batch B load ----
+    batch_t A, B;
+    int kA = pop_and_load(A, 0, true);
+    for (;;) {
+        // What comes next: an exact pass when 64 candidates are queued (or when nothing else is left),
+        // otherwise the first-stage test of batch A.
+        const bool finishing = kA == 0 && n_uq == 0;
+        const bool do_exact = n_uq >= 64 || (kA == 0 && n_uq > 0);
+        // Room for the worst-case output of one pass (64 sources, 64 leaves); everything is settled at the end.
+        if (n_lq + 64 > LK_LQ_CAP || finishing) {
+            drain_leaves();
+        }
+        if (n_src + 64 > SRC_CAP || finishing) {
             flush();
+        }
+        if (finishing) {
             break;
         }
-        if (n_src + 64 > SRC_CAP) {
-            flush();
+        if (do_exact) {
+            process_exact();
+            if (kA == 0) {
+                kA = pop_and_load(A, 0, true); // the exact pass may have opened new runs
+            }
+            continue;
         }
+        RK_STAMP(7)
+        // Prefetch: pop the next batch from below A's future pushes (up to 8 entries per popped run).
+        int kB = pop_and_load(B, 8 * kA, false);
+        process(A);
+        if (kB == 0) {
+            kB = pop_and_load(B, 0, true);
+        }
+        A = B;
+        kA = kB;
     }
 
+    RK_STAMP(7)
     // ---- interactions inside the group: its own particles as sources, self-pair masked ----
     for (int b0 = 0; b0 < T; b0 += SRC_CAP) {
         const int n = (T - b0) < SRC_CAP ? (T - b0) : SRC_CAP;
@@ -345,6 +499,7 @@ __global__ void __launch_bounds__(256) k_list(const kparams<F> P, const uint32_t
         wave_sync();
     }
 
+    RK_STAMP(5)
     // ---- sum the source splits in a fixed order, scale by G, write out ----
     const F G = P.G;
     if (NS > 1) {
@@ -385,6 +540,8 @@ __global__ void __launch_bounds__(256) k_list(const kparams<F> P, const uint32_t
             }
         }
     }
+    RK_STAMP(7)
+    RK_STAMP_FLUSH
 }
 
 // ------------------------------------------------------------------------------------------------

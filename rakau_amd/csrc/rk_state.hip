@@ -277,6 +277,22 @@ void create_impl(rk_state &s, const void *const parts[4], int64_t nparts, const 
         throw rk::error(RK_EINVAL, "the critical nodes derived from the tree do not cover all particles");
     }
 
+    // Tight bounding boxes of the target groups (used by the list kernel to take most MAC decisions without
+    // visiting every target).
+    std::vector<v4> boxes(crit.size() * 2);
+    for (size_t gi = 0; gi < crit.size(); ++gi) {
+        F lo[3] = {x[crit[gi].x], y[crit[gi].x], z[crit[gi].x]}, hi[3] = {lo[0], lo[1], lo[2]};
+        for (size_t i = crit[gi].x; i < crit[gi].y; ++i) {
+            const F pv[3] = {x[i], y[i], z[i]};
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = std::min(lo[k], pv[k]);
+                hi[k] = std::max(hi[k], pv[k]);
+            }
+        }
+        boxes[2 * gi].x = lo[0], boxes[2 * gi].y = lo[1], boxes[2 * gi].z = lo[2], boxes[2 * gi].w = F(0);
+        boxes[2 * gi + 1].x = hi[0], boxes[2 * gi + 1].y = hi[1], boxes[2 * gi + 1].z = hi[2], boxes[2 * gi + 1].w = F(0);
+    }
+
     build_host_mirrors(s, crit);
     s.n_internal = static_cast<int64_t>(n_internal);
     const std::vector<uint32_t> lists = concat_class_lists(s);
@@ -289,6 +305,7 @@ void create_impl(rk_state &s, const void *const parts[4], int64_t nparts, const 
     alloc_upload(s, RK_BUF_CHILD, child.data(), child.size() * sizeof(uint32_t));
     alloc_upload(s, RK_BUF_CLASS, lists.data(), lists.size() * sizeof(uint32_t));
     alloc_upload(s, RK_BUF_NODE_REC, recs.data(), recs.size() * sizeof(rk::node_rec<F>));
+    alloc_upload(s, RK_BUF_CRIT_BOX, boxes.data(), boxes.size() * sizeof(v4));
 }
 
 void check_common(int fp, int mac)
@@ -348,6 +365,7 @@ rk::kparams<F> base_params(const rk_state &s, double mac_value, double G, double
     p.crit = static_cast<const uint4 *>(s.buf[RK_BUF_CRIT]);
     p.child_tab = static_cast<const uint32_t *>(s.buf[RK_BUF_CHILD]);
     p.node_rec = static_cast<const rk::node_rec<F> *>(s.buf[RK_BUF_NODE_REC]);
+    p.crit_box = static_cast<const typename rk::vt<F>::v4 *>(s.buf[RK_BUF_CRIT_BOX]);
     p.n_nodes = static_cast<uint32_t>(s.tree_size);
     p.mac_value = static_cast<F>(mac_value);
     p.eps2 = static_cast<F>(eps2);
@@ -389,6 +407,21 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
         p.out[k] = static_cast<F *>(d_out[k]);
     }
     p.out_sub = offset_output ? 0u : static_cast<uint32_t>(p_begin);
+    p.dbg = nullptr;
+#ifdef RK_STAMPS
+    {
+        static unsigned long long *d_dbg = nullptr;
+        if (!d_dbg) {
+            RK_HIP(hipMalloc(&d_dbg, 8 * sizeof(unsigned long long)));
+        }
+        unsigned long long h[8];
+        RK_HIP(hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost));
+        fprintf(stderr, "RK_STAMPS prev: load %llu mac %llu classify %llu leaf %llu dense %llu self %llu rounds %llu other %llu\n", h[0],
+                h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+        RK_HIP(hipMemset(d_dbg, 0, sizeof(h)));
+        p.dbg = d_dbg;
+    }
+#endif
     if (!s.ev0) {
         RK_HIP(hipEventCreate(&s.ev0));
         RK_HIP(hipEventCreate(&s.ev1));
@@ -645,7 +678,7 @@ int rk_state_export(const rk_state *s, int *count, void **ptrs, int64_t *bytes, 
             bytes[i] = s->buf_bytes[i];
         }
         std::fill(meta, meta + RK_META_WORDS, int64_t(0));
-        meta[0] = 0x726b3032; // layout tag "rk02"
+        meta[0] = 0x726b3033; // layout tag "rk02"
         meta[1] = s->fp;
         meta[2] = s->mac;
         meta[3] = s->nparts;
@@ -667,7 +700,7 @@ int rk_state_import(rk_state **out, int device, int count, void *const *ptrs, co
             throw rk::error(RK_EINVAL, "null argument");
         }
         *out = nullptr;
-        if (meta[0] != 0x726b3032 || count != RK_NBUF) {
+        if (meta[0] != 0x726b3033 || count != RK_NBUF) {
             throw rk::error(RK_EINVAL, "unrecognised state layout");
         }
         check_common(static_cast<int>(meta[1]), static_cast<int>(meta[2]));
