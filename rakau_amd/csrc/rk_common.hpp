@@ -54,10 +54,10 @@ inline int class_of(int64_t size)
 // source; pick the R that minimises it (ties: fewer registers).
 inline int class2_of(int64_t size)
 {
-    if (size > 512) return 4;
+    if (size > 256) return 4;
     int best = -1;
     double best_cost = 0.;
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < 3; ++c) { // R = 1, 2, 4 (more targets per lane costs too many registers)
         const int64_t R = class_R(c), TP = (size + R - 1) / R;
         if (TP > 64) continue;
         const double cost = static_cast<double>(R) / static_cast<double>(64 / TP);

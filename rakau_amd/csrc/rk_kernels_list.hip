@@ -52,24 +52,20 @@ constexpr int LK_STACK_CAP = 512;
 // Worst-case growth of the stack while descending depth-first from one entry: 7 pending entries per level.
 constexpr int LK_DFS_RESERVE = 7 * 21;
 constexpr int LK_LQ_CAP = 128;
-// Groups up to this size keep a copy of their targets in LDS for the MAC test (larger groups read them
-// through the scalar cache instead).
-constexpr int LK_TGT_CAP = 128;
 // Queue of candidates left undecided by the bounding-box / probe tests.
 constexpr int LK_UQ_CAP = 128;
 
 template <typename F>
 struct lk_cfg {
-    static constexpr int src_cap = sizeof(F) == 4 ? 256 : 128; // 4 KiB of sources per wave
+    static constexpr int src_cap = 128; // sources per tile (2 KiB fp32, 4 KiB fp64)
 };
 
-// Per-wave LDS: 2 + 4 + 1 + 2 + 0.5 KiB = 9.5 KiB (fp32).
+// Per-wave LDS: 2 + 2 + 1 + 0.5 KiB = 5.5 KiB (fp32): 7 four-wave blocks per CU.
 template <typename F>
 struct lk_wave_lds {
     uint32_t stack[LK_STACK_CAP];
     typename vt<F>::v4 src[lk_cfg<F>::src_cap];
     uint2 lq[LK_LQ_CAP];
-    typename vt<F>::v4 tgt[LK_TGT_CAP];
     uint32_t uq[LK_UQ_CAP]; // records whose MAC test needs the exact all-targets loop
 };
 
@@ -130,7 +126,7 @@ __device__ __forceinline__ void lk_eval_tile(const typename vt<F>::v4 *__restric
 }
 
 template <typename F, int Q, int MAC, int R>
-__global__ void __launch_bounds__(256) k_list(const kparams<F> P, const uint32_t *__restrict__ list, int n_list)
+__global__ void __launch_bounds__(256, (sizeof(F) == 4 ? (R <= 2 ? 7 : 5) : 1)) k_list(const kparams<F> P, const uint32_t *__restrict__ list, int n_list)
 {
     using v4 = typename vt<F>::v4;
     using v2 = typename vt<F>::v2;
@@ -174,15 +170,6 @@ __global__ void __launch_bounds__(256) k_list(const kparams<F> P, const uint32_t
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
             acc[r][k] = F(0);
-        }
-    }
-
-    // Targets for the MAC test, padded to a multiple of 4 with copies of the last one.
-    const bool tgt_in_lds = T <= LK_TGT_CAP;
-    const int T4 = (T + 3) & ~3;
-    if (tgt_in_lds) {
-        for (int t = lane; t < T4; t += 64) {
-            L.tgt[t] = P.part4[tb + static_cast<uint32_t>(t < T ? t : T - 1)];
         }
     }
 
@@ -416,29 +403,17 @@ __global__ void __launch_bounds__(256) k_list(const kparams<F> P, const uint32_t
         bt.rb = rec->b;
         const v4 com = bt.com;
         const F mac_lh = mac_lhs<F>(MAC, bt.mp, mac_value);
-        // min over the targets of the unsoftened squared distance to the node's centre of mass.
+        // min over the targets of the unsoftened squared distance to the node's centre of mass. The target
+        // coordinates are wave-uniform: they arrive through the scalar cache as SGPR operands.
         F mind2 = std::numeric_limits<F>::infinity();
-        if (tgt_in_lds) {
-#pragma unroll 2
-            for (int t = 0; t < T4; t += 4) {
+        for (int t = 0; t < T; t += 4) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const v4 tg = L.tgt[t + u];
-                    const F dx = com.x - tg.x, dy = com.y - tg.y, dz = com.z - tg.z;
-                    const F d2 = rk_fma(dz, dz, rk_fma(dy, dy, dx * dx));
-                    mind2 = rk_min(mind2, d2);
-                }
-            }
-        } else {
-            for (int t = 0; t < T; t += 4) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int ti = (t + u < T) ? t + u : T - 1;
-                    const v4 tg = P.part4[tb + static_cast<uint32_t>(ti)];
-                    const F dx = com.x - tg.x, dy = com.y - tg.y, dz = com.z - tg.z;
-                    const F d2 = rk_fma(dz, dz, rk_fma(dy, dy, dx * dx));
-                    mind2 = rk_min(mind2, d2);
-                }
+            for (int u = 0; u < 4; ++u) {
+                const int ti = (t + u < T) ? t + u : T - 1;
+                const v4 tg = P.part4[tb + static_cast<uint32_t>(ti)];
+                const F dx = com.x - tg.x, dy = com.y - tg.y, dz = com.z - tg.z;
+                const F d2 = rk_fma(dz, dz, rk_fma(dy, dy, dx * dx));
+                mind2 = rk_min(mind2, d2);
             }
         }
         const bool fail = mac_lh >= mind2;
@@ -565,7 +540,6 @@ static void launch_list_qm(const rk_state &s, const kparams<F> &p, const int64_t
     go(std::integral_constant<int, 1>{}, 0);
     go(std::integral_constant<int, 2>{}, 1);
     go(std::integral_constant<int, 4>{}, 2);
-    go(std::integral_constant<int, 8>{}, 3);
 }
 
 template <typename F>

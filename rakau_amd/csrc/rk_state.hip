@@ -429,7 +429,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
     RK_HIP(hipEventRecord(s.ev0, stream));
     if (v2) {
         rk::launch_list<F>(s, q, p, cb, ce, stream);
-        // Groups beyond 512 particles are served by the block-per-group kernel in both variants.
+        // Groups beyond 256 particles are served by the block-per-group kernel.
         rk::launch_block<F>(s, q, p, static_cast<const uint32_t *>(s.buf[RK_BUF_CLASS]) + s.class2_off[4] + cb[4],
                             ce[4] - cb[4], stream);
     } else {
