@@ -104,6 +104,7 @@ struct kparams {
     F *out[4];
     uint32_t out_sub; // value subtracted from the particle index when writing (compact output)
     unsigned long long *dbg; // diagnostic builds only (RK_STAMPS): per-section cycle totals
+    int xcd_mode;            // block -> group-list mapping (see xcd_map_block)
 };
 
 struct error : std::runtime_error {
@@ -141,6 +142,9 @@ struct rk_state {
     void *d_out = nullptr;
     size_t d_out_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // Side streams (and fork/join events) that let the per-class kernels of one call overlap.
+    hipStream_t aux_stream[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     bool timed = false;
     int variant = 0;
 };
@@ -153,7 +157,7 @@ void launch_traversal(const rk_state &s, int q, const kparams<F> &p, const int64
                       const int64_t cls_end[n_classes], hipStream_t stream);
 template <typename F>
 void launch_list(const rk_state &s, int q, const kparams<F> &p, const int64_t cls_begin[n_classes],
-                 const int64_t cls_end[n_classes], hipStream_t stream);
+                 const int64_t cls_end[n_classes], hipStream_t const streams[3]);
 template <typename F>
 void launch_block(const rk_state &s, int q, const kparams<F> &p, const uint32_t *list, int64_t n, hipStream_t stream);
 template <typename F>

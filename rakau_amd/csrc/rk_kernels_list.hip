@@ -78,6 +78,27 @@ __device__ __forceinline__ unsigned xcd_chunked_block(unsigned b, unsigned nb)
     return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + pos;
 }
 
+// mode 0: XCD x walks chunks x, x + 8, x + 16, ... of XCD_CHUNK consecutive blocks (L2 locality inside a
+// chunk, work spread evenly over the XCDs whatever the spatial variation of the group costs);
+// mode 1: one contiguous slice per XCD; mode 2: identity (hardware round-robin).
+constexpr unsigned XCD_CHUNK = 16;
+__device__ __forceinline__ unsigned xcd_map_block(unsigned b, unsigned nb, int mode)
+{
+    if (mode == 2) {
+        return b;
+    }
+    if (mode == 1) {
+        return xcd_chunked_block(b, nb);
+    }
+    // Blocks beyond the last full round of 8 chunks keep their identity mapping.
+    const unsigned span = 8u * XCD_CHUNK, full = nb - nb % span;
+    if (b >= full) {
+        return b;
+    }
+    const unsigned xcd = b & 7u, pos = b >> 3;
+    return (pos / XCD_CHUNK * 8u + xcd) * XCD_CHUNK + pos % XCD_CHUNK;
+}
+
 template <typename F, int Q, int R, bool SELF>
 __device__ __forceinline__ void lk_interact_src(const typename vt<F>::v4 &s, int j, const typename vt<F>::v4 (&tp)[R],
                                                 F (&acc)[R][nres_of(Q)], F eps2, const int (&tidx)[R])
@@ -137,7 +158,7 @@ __global__ void __launch_bounds__(256, (sizeof(F) == 4 ? (R <= 2 ? 7 : 5) : 1)) 
 
     const int wib = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
-    const unsigned blk = xcd_chunked_block(blockIdx.x, gridDim.x);
+    const unsigned blk = xcd_map_block(blockIdx.x, gridDim.x, P.xcd_mode);
     const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(blk * 4u) + wib);
     if (wave >= n_list) {
         return;
@@ -524,7 +545,7 @@ __global__ void __launch_bounds__(256, (sizeof(F) == 4 ? (R <= 2 ? 7 : 5) : 1)) 
 // ------------------------------------------------------------------------------------------------
 template <typename F, int Q, int MAC>
 static void launch_list_qm(const rk_state &s, const kparams<F> &p, const int64_t cb[n_classes],
-                           const int64_t ce[n_classes], hipStream_t stream)
+                           const int64_t ce[n_classes], hipStream_t const streams[3])
 {
     const auto *lists = static_cast<const uint32_t *>(s.buf[RK_BUF_CLASS]);
     auto go = [&](auto Rtag, int c) {
@@ -534,7 +555,7 @@ static void launch_list_qm(const rk_state &s, const kparams<F> &p, const int64_t
             return;
         }
         const auto grid = static_cast<unsigned>((n + 3) / 4);
-        hipLaunchKernelGGL((k_list<F, Q, MAC, R>), dim3(grid), dim3(256), 0, stream, p,
+        hipLaunchKernelGGL((k_list<F, Q, MAC, R>), dim3(grid), dim3(256), 0, streams[c], p,
                            lists + s.class2_off[c] + cb[c], static_cast<int>(n));
     };
     go(std::integral_constant<int, 1>{}, 0);
@@ -544,23 +565,23 @@ static void launch_list_qm(const rk_state &s, const kparams<F> &p, const int64_t
 
 template <typename F>
 void launch_list(const rk_state &s, int q, const kparams<F> &p, const int64_t cb[n_classes],
-                 const int64_t ce[n_classes], hipStream_t stream)
+                 const int64_t ce[n_classes], hipStream_t const streams[3])
 {
     switch (q * 2 + s.mac) {
-        case 0: launch_list_qm<F, 0, 0>(s, p, cb, ce, stream); break;
-        case 1: launch_list_qm<F, 0, 1>(s, p, cb, ce, stream); break;
-        case 2: launch_list_qm<F, 1, 0>(s, p, cb, ce, stream); break;
-        case 3: launch_list_qm<F, 1, 1>(s, p, cb, ce, stream); break;
-        case 4: launch_list_qm<F, 2, 0>(s, p, cb, ce, stream); break;
-        case 5: launch_list_qm<F, 2, 1>(s, p, cb, ce, stream); break;
+        case 0: launch_list_qm<F, 0, 0>(s, p, cb, ce, streams); break;
+        case 1: launch_list_qm<F, 0, 1>(s, p, cb, ce, streams); break;
+        case 2: launch_list_qm<F, 1, 0>(s, p, cb, ce, streams); break;
+        case 3: launch_list_qm<F, 1, 1>(s, p, cb, ce, streams); break;
+        case 4: launch_list_qm<F, 2, 0>(s, p, cb, ce, streams); break;
+        case 5: launch_list_qm<F, 2, 1>(s, p, cb, ce, streams); break;
         default: throw error(RK_EINVAL, "invalid q / mac combination");
     }
     RK_HIP(hipGetLastError());
 }
 
 template void launch_list<float>(const rk_state &, int, const kparams<float> &, const int64_t[n_classes],
-                                 const int64_t[n_classes], hipStream_t);
+                                 const int64_t[n_classes], hipStream_t const[3]);
 template void launch_list<double>(const rk_state &, int, const kparams<double> &, const int64_t[n_classes],
-                                  const int64_t[n_classes], hipStream_t);
+                                  const int64_t[n_classes], hipStream_t const[3]);
 
 } // namespace rk

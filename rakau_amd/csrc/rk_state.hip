@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <memory>
@@ -70,6 +71,17 @@ void free_state(rk_state *s)
     }
     if (s->ev1) {
         (void)hipEventDestroy(s->ev1);
+    }
+    if (s->ev_fork) {
+        (void)hipEventDestroy(s->ev_fork);
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (s->ev_join[i]) {
+            (void)hipEventDestroy(s->ev_join[i]);
+        }
+        if (s->aux_stream[i]) {
+            (void)hipStreamDestroy(s->aux_stream[i]);
+        }
     }
     (void)hipSetDevice(prev);
     delete s;
@@ -408,6 +420,13 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
     }
     p.out_sub = offset_output ? 0u : static_cast<uint32_t>(p_begin);
     p.dbg = nullptr;
+    {
+        static const int xcd_mode = [] {
+            const char *e = std::getenv("RK_XCD_MODE"); // experiment knob; default 1 (contiguous slice per XCD)
+            return e ? std::atoi(e) : 1;
+        }();
+        p.xcd_mode = xcd_mode;
+    }
 #ifdef RK_STAMPS
     {
         static unsigned long long *d_dbg = nullptr;
@@ -428,7 +447,25 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
     }
     RK_HIP(hipEventRecord(s.ev0, stream));
     if (v2) {
-        rk::launch_list<F>(s, q, p, cb, ce, stream);
+        // The three per-class kernels are independent: fork them onto side streams so that the tail of one
+        // overlaps the others, then join back into the caller's stream.
+        if (!s.aux_stream[0]) {
+            for (int i = 0; i < 2; ++i) {
+                RK_HIP(hipStreamCreateWithFlags(&s.aux_stream[i], hipStreamNonBlocking));
+                RK_HIP(hipEventCreateWithFlags(&s.ev_join[i], hipEventDisableTiming));
+            }
+            RK_HIP(hipEventCreateWithFlags(&s.ev_fork, hipEventDisableTiming));
+        }
+        RK_HIP(hipEventRecord(s.ev_fork, stream));
+        const hipStream_t streams[3] = {s.aux_stream[0], stream, s.aux_stream[1]};
+        for (int i = 0; i < 2; ++i) {
+            RK_HIP(hipStreamWaitEvent(s.aux_stream[i], s.ev_fork, 0));
+        }
+        rk::launch_list<F>(s, q, p, cb, ce, streams);
+        for (int i = 0; i < 2; ++i) {
+            RK_HIP(hipEventRecord(s.ev_join[i], s.aux_stream[i]));
+            RK_HIP(hipStreamWaitEvent(stream, s.ev_join[i], 0));
+        }
         // Groups beyond 256 particles are served by the block-per-group kernel.
         rk::launch_block<F>(s, q, p, static_cast<const uint32_t *>(s.buf[RK_BUF_CLASS]) + s.class2_off[4] + cb[4],
                             ce[4] - cb[4], stream);
