@@ -62,6 +62,22 @@ def plummer_numpy(n, dtype, seed=20261002, a=1.0):
     return m, x, y, z
 
 
+def usable_cpus():
+    """Host cores this process may actually use: min(os.cpu_count(), cgroup v2 cpu.max quota)."""
+    n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(np.ceil(int(quota) / int(period)))))
+    except Exception:
+        pass
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    return n
+
+
 def shard_cuts(crit_ranges, nparts, world):
     """Contiguous Morton shards with (nearly) equal particle counts, cut at critical-node boundaries."""
     begins = crit_ranges[:, 0]
@@ -276,7 +292,7 @@ def cpu_baseline(m, x, y, z, mac, theta, eps, q, n, threads, gpu_outs, p_begin):
     inputs and tree parameters, all host cores. Bounded: critical nodes are processed until ~20 s of wall
     time have been spent (whole workload if it fits). Also cross-checks the GPU result on the sample."""
     import oracle
-    threads = threads or min(os.cpu_count() or 1, 256)
+    threads = threads or usable_cpus()
     ot = oracle.Tree(x, y, z, m, mac=mac)
     crit = ot.crit_nodes()
     ncrit = len(crit)

@@ -457,7 +457,13 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
             RK_HIP(hipEventCreateWithFlags(&s.ev_fork, hipEventDisableTiming));
         }
         RK_HIP(hipEventRecord(s.ev_fork, stream));
-        const hipStream_t streams[3] = {s.aux_stream[0], stream, s.aux_stream[1]};
+        // RK_SERIAL_CLASSES=1 keeps the class kernels on the caller's stream (one after the other), which
+        // gives per-kernel durations in a profile that add up to the step time.
+        static const bool serial = [] {
+            const char *e = std::getenv("RK_SERIAL_CLASSES");
+            return e && std::atoi(e) != 0;
+        }();
+        const hipStream_t streams[3] = {serial ? stream : s.aux_stream[0], stream, serial ? stream : s.aux_stream[1]};
         for (int i = 0; i < 2; ++i) {
             RK_HIP(hipStreamWaitEvent(s.aux_stream[i], s.ev_fork, 0));
         }

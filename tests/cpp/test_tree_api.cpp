@@ -1,0 +1,157 @@
+// Compile-and-run check of the C++17 front door (include/rakau_amd/tree.hpp): the call shapes of the
+// reference's tests (test/basic.cpp, test/readme_example.cpp, test/accuracy_acc.cpp) must compile unchanged
+// modulo the namespace, and behave the same. Usage: test_tree_api [gpu]
+//   without "gpu": constructor / accessor / error-path checks only (no device needed);
+//   with "gpu":    also runs the acc/pot overloads on device 0 and checks them against exact_*.
+#define RAKAU_AMD_DROP_IN
+#include "../../include/rakau_amd/tree.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <random>
+#include <vector>
+
+using namespace rakau;
+using namespace rakau::kwargs;
+
+static int failures = 0;
+#define CHECK(cond)                                                                                                    \
+    do {                                                                                                               \
+        if (!(cond)) {                                                                                                 \
+            std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond);                                              \
+            ++failures;                                                                                                \
+        }                                                                                                              \
+    } while (0)
+#define CHECK_THROWS(expr, ExcType, needle)                                                                            \
+    do {                                                                                                               \
+        bool ok_ = false;                                                                                              \
+        try {                                                                                                          \
+            expr;                                                                                                      \
+        } catch (const ExcType &e_) {                                                                                  \
+            ok_ = std::strstr(e_.what(), needle) != nullptr;                                                           \
+            if (!ok_) std::printf("  message was: %s\n", e_.what());                                                   \
+        } catch (...) {                                                                                                \
+        }                                                                                                              \
+        if (!ok_) {                                                                                                    \
+            std::printf("FAILED %s:%d: %s did not throw %s(\"%s\")\n", __FILE__, __LINE__, #expr, #ExcType, needle);   \
+            ++failures;                                                                                                \
+        }                                                                                                              \
+    } while (0)
+
+template <typename F>
+static std::vector<F> uniform_particles(std::size_t n, F size, std::mt19937 &rng)
+{
+    std::vector<F> v(n * 4);
+    std::uniform_real_distribution<F> md(F(0), F(1)), rd(-size / F(2), size / F(2));
+    for (std::size_t i = 0; i < n; ++i) v[i] = md(rng);
+    for (std::size_t i = n; i < 4 * n; ++i) v[i] = rd(rng);
+    return v;
+}
+
+template <typename F, mac M>
+static void host_checks()
+{
+    std::mt19937 rng(7);
+    const std::size_t s = 3000;
+    auto parts = uniform_particles<F>(s, F(1), rng);
+    // Iterators + nparts (test/accuracy_acc.cpp:63-71).
+    octree<F, M> t{x_coords = parts.begin() + s, y_coords = parts.begin() + 2 * s, z_coords = parts.begin() + 3 * s,
+                   masses = parts.begin(),       nparts = s,                      box_size = F(1),
+                   max_leaf_n = 8,               ncrit = 64};
+    CHECK(t.nparts() == s);
+    CHECK(t.box_size() == F(1) && !t.box_size_deduced());
+    CHECK(t.max_leaf_n() == 8u && t.ncrit() == 64u);
+    CHECK(t.nodes().size() > 1 && t.nodes()[0].code == 1u && t.nodes()[0].n_children == t.nodes().size() - 1);
+    // perm / inv_perm are inverse permutations; p_its_o gives back the original order.
+    for (std::size_t i = 0; i < s; i += 97) {
+        CHECK(t.inv_perm()[t.perm()[i]] == i);
+        CHECK(t.p_its_o()[0][static_cast<std::ptrdiff_t>(i)] == parts[s + i]);
+        CHECK(t.p_its_u()[3][t.inv_perm()[i]] == parts[i]);
+    }
+    // Ranges (vectors) without nparts; deduced box.
+    std::vector<F> xs(parts.begin() + s, parts.begin() + 2 * s), ys(parts.begin() + 2 * s, parts.begin() + 3 * s),
+        zs(parts.begin() + 3 * s, parts.end()), ms(parts.begin(), parts.begin() + s);
+    octree<F, M> t2{x_coords = xs, y_coords = ys, z_coords = zs, masses = ms};
+    CHECK(t2.nparts() == s && t2.box_size_deduced() && t2.box_size() > F(0.9));
+    // Copy / move.
+    octree<F, M> t3(t2), t4(std::move(t2));
+    CHECK(t3.nodes().size() == t4.nodes().size() && t2.nparts() == 0);
+    // Error paths (messages of tree.hpp:1350-1362, 1644-1658, 3364-3370).
+    CHECK_THROWS((octree<F, M>{x_coords = xs, y_coords = ys, z_coords = zs, masses = ms, max_leaf_n = 0}),
+                 std::invalid_argument, "maximum number of particles per leaf must be nonzero");
+    CHECK_THROWS((octree<F, M>{x_coords = xs, y_coords = ys, z_coords = zs, masses = ms, ncrit = 0}),
+                 std::invalid_argument, "critical number of particles");
+    CHECK_THROWS((octree<F, M>{x_coords = xs, y_coords = ys, z_coords = zs, masses = ms, box_size = -1}),
+                 std::invalid_argument, "box size must be a finite non-negative value");
+    std::vector<F> shorter(xs.begin(), xs.end() - 1);
+    CHECK_THROWS((octree<F, M>{x_coords = shorter, y_coords = ys, z_coords = zs, masses = ms}), std::invalid_argument,
+                 "inconsistent sizes");
+    std::array<std::vector<F>, 3> accs;
+    CHECK_THROWS(t.accs_u(accs, F(0)), std::domain_error, "MAC value must be finite and positive");
+    CHECK_THROWS(t.accs_u(accs, F(0.5), eps = -1), std::domain_error, "softening length must be finite");
+    CHECK_THROWS(t.accs_u({accs[0].data(), accs[1].data()}, F(0.5)), std::invalid_argument,
+                 "iterators is required instead");
+    CHECK_THROWS(t.accs_u(accs, F(0.5), split = std::vector<double>{0., 0.}), std::invalid_argument,
+                 "cannot all be zero");
+    // exact_* are host computations.
+    const auto ea = t.exact_acc_u(5), eo = t.exact_acc_o(t.perm()[5]);
+    CHECK(ea[0] == eo[0] && ea[1] == eo[1] && ea[2] == eo[2]);
+}
+
+template <typename F, mac M>
+static void gpu_checks()
+{
+    std::mt19937 rng(11);
+    const std::size_t s = 2000;
+    auto parts = uniform_particles<F>(s, F(1), rng);
+    octree<F, M> t{x_coords = parts.data() + s, y_coords = parts.data() + 2 * s, z_coords = parts.data() + 3 * s,
+                   masses = parts.data(),       nparts = s,                      box_size = F(2)};
+    const F theta = F(0.001);
+    const double tol = std::is_same_v<F, double> ? 5e-10 : 5e-2;
+    std::array<std::vector<F>, 3> accs;
+    t.accs_o(accs, theta);
+    CHECK(accs[0].size() == s);
+    std::vector<F> pots;
+    t.pots_o(pots, theta, G = F(2));
+    std::array<std::vector<F>, 4> ap;
+    t.accs_pots_u(ap, theta, eps = F(0.01));
+    for (std::size_t i = 0; i < s; i += 101) {
+        const auto e = t.exact_acc_o(i);
+        for (int k = 0; k < 3; ++k) CHECK(std::abs((e[k] - accs[k][i]) / e[k]) < tol);
+        CHECK(std::abs((t.exact_pot_o(i, G = F(2)) - pots[i]) / pots[i]) < tol);
+        const auto e2 = t.exact_acc_pot_u(i, eps = F(0.01));
+        for (int k = 0; k < 4; ++k) CHECK(std::abs((e2[k] - ap[k][i]) / e2[k]) < tol);
+    }
+    // Iterator-array and initializer-list outputs; G = 0 gives exact zeros (test/g_constant_acc.cpp:66-70).
+    std::vector<F> ax(s), ay(s), az(s);
+    t.accs_u(std::array{ax.begin(), ay.begin(), az.begin()}, F(0.75));
+    std::vector<F> bx(s), by(s), bz(s);
+    t.accs_u({bx.data(), by.data(), bz.data()}, F(0.75), split = std::vector<double>{0.5, 0.5});
+    CHECK(ax == bx && ay == by && az == bz);
+    t.accs_u({bx.data(), by.data(), bz.data()}, F(0.75), G = 0);
+    for (std::size_t i = 0; i < s; ++i) CHECK(bx[i] == F(0) && by[i] == F(0) && bz[i] == F(0));
+    // update_particles_o: shift everything; accelerations are translation invariant up to rounding.
+    t.update_particles_o([s](const auto &its) {
+        for (std::size_t i = 0; i < s; ++i) its[0][static_cast<std::ptrdiff_t>(i)] += F(0.125);
+    });
+    std::array<std::vector<F>, 3> acc2;
+    t.accs_o(acc2, theta);
+    for (std::size_t i = 0; i < s; i += 53) {
+        CHECK(std::abs((acc2[0][i] - accs[0][i]) / accs[0][i]) < (std::is_same_v<F, double> ? 1e-9 : 1e-1));
+    }
+}
+
+int main(int argc, char **argv)
+{
+    const bool gpu = argc > 1 && std::strcmp(argv[1], "gpu") == 0;
+    host_checks<float, mac::bh>();
+    host_checks<double, mac::bh_geom>();
+    if (gpu) {
+        gpu_checks<float, mac::bh>();
+        gpu_checks<double, mac::bh>();
+        gpu_checks<double, mac::bh_geom>();
+    }
+    std::printf("%s: %d failure(s)\n", gpu ? "gpu+host checks" : "host checks", failures);
+    return failures ? 1 : 0;
+}

@@ -1,0 +1,34 @@
+"""The C++17 drop-in header (include/rakau_amd/tree.hpp) compiled and exercised the way the reference's
+Catch tests use rakau::octree (tests/cpp/test_tree_api.cpp)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "cpp", "test_tree_api.cpp")
+EXE = os.path.join(ROOT, "tests", "build", "test_tree_api")
+
+
+def build():
+    os.makedirs(os.path.dirname(EXE), exist_ok=True)
+    deps = [SRC, os.path.join(ROOT, "include", "rakau_amd", "tree.hpp"), os.path.join(ROOT, "include", "rakau_amd", "kwargs.hpp")]
+    if os.path.exists(EXE) and all(os.path.getmtime(EXE) >= os.path.getmtime(d) for d in deps):
+        return
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", SRC, "-o", EXE, "-L" + os.path.join(ROOT, "rakau_amd", "lib"),
+                           "-lrakau_amd", "-Wl,-rpath," + os.path.join(ROOT, "rakau_amd", "lib")])
+
+
+def test_header_host_side():
+    build()
+    out = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "0 failure(s)" in out.stdout
+
+
+@pytest.mark.gpu
+def test_header_on_gpu():
+    build()
+    out = subprocess.run([EXE, "gpu"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "gpu+host checks: 0 failure(s)" in out.stdout
