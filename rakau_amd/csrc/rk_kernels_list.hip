@@ -21,6 +21,23 @@
 #include "rk_common.hpp"
 #include "rk_device.hpp"
 
+// Tuning knobs (defaults chosen by measurement on MI355X).
+#ifndef RK_UNR1
+#define RK_UNR1 4 // sources in flight per lane in the dense loop, R = 1
+#endif
+#ifndef RK_UNR2
+#define RK_UNR2 2 // R = 2
+#endif
+#ifndef RK_UNR4
+#define RK_UNR4 1 // R = 4
+#endif
+#ifndef RK_W12
+#define RK_W12 7 // waves per SIMD the R <= 2 kernels are compiled for
+#endif
+#ifndef RK_W4
+#define RK_W4 5 // R = 4
+#endif
+
 namespace rk
 {
 
@@ -129,7 +146,7 @@ __device__ __forceinline__ void lk_eval_tile(const typename vt<F>::v4 *__restric
     return; // diagnostic build: list building only
 #endif
     // Keep about four interactions in flight per lane whatever R is.
-    constexpr int UNR = R >= 4 ? 1 : (R == 2 ? 2 : 4);
+    constexpr int UNR = R >= 4 ? RK_UNR4 : (R == 2 ? RK_UNR2 : RK_UNR1);
     const int full = n_src / ns, rem = n_src - full * ns;
     const v4 *p = src + sp;
     int j = sp;
@@ -147,7 +164,7 @@ __device__ __forceinline__ void lk_eval_tile(const typename vt<F>::v4 *__restric
 }
 
 template <typename F, int Q, int MAC, int R>
-__global__ void __launch_bounds__(256, (sizeof(F) == 4 ? (R <= 2 ? 7 : 5) : 1)) k_list(const kparams<F> P, const uint32_t *__restrict__ list, int n_list)
+__global__ void __launch_bounds__(256, (sizeof(F) == 4 ? (R <= 2 ? RK_W12 : RK_W4) : 1)) k_list(const kparams<F> P, const uint32_t *__restrict__ list, int n_list)
 {
     using v4 = typename vt<F>::v4;
     using v2 = typename vt<F>::v2;
