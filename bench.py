@@ -123,12 +123,19 @@ def main():
                              % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    dev = local_rank if world > 1 else 0
+    # RK_BENCH_SINGLE_DEVICE=1 + RK_BENCH_BACKEND=gloo: rehearsal of the multi-rank code path on a 1-GPU box
+    # (all ranks share GPU 0, buffers are replicated through host memory). The real path is nccl (= RCCL).
+    backend = os.environ.get("RK_BENCH_BACKEND", "nccl")
+    single_dev = os.environ.get("RK_BENCH_SINGLE_DEVICE", "0") == "1"
+    dev = local_rank if (world > 1 and not single_dev) else 0
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
 
     lib = _capi.lib()
     mac = "bh"
@@ -161,7 +168,12 @@ def main():
             for t, p, b in zip(bufs, ptrs, nbytes):
                 _capi.check(lib.rk_device_memcpy(t.data_ptr(), p, b, dev))
         for t in bufs:
-            dist.broadcast(t, src=0)  # RCCL over xGMI
+            if backend == "nccl":
+                dist.broadcast(t, src=0)  # RCCL over xGMI
+            else:
+                h = t.cpu()
+                dist.broadcast(h, src=0)
+                t.copy_(h)
         torch.cuda.synchronize()
         t_replicate = time.perf_counter() - t0
         if rank != 0:
@@ -187,6 +199,7 @@ def main():
                              offset_output=False, stream=stream)
 
     def barrier():
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -211,10 +224,11 @@ def main():
     inter_local = census["com"] + census["pp"] + census["self"]
 
     if dist is not None:
-        red = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+        rdev = "cuda" if backend == "nccl" else "cpu"
+        red = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=rdev)
         dist.all_reduce(red, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms_max = float(red[0]), float(red[1])
-        tot = torch.tensor([float(inter_local), float(census["mac"])], dtype=torch.float64, device="cuda")
+        tot = torch.tensor([float(inter_local), float(census["mac"])], dtype=torch.float64, device=rdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         inter_total, mac_total = float(tot[0]), float(tot[1])
     else:
