@@ -249,6 +249,15 @@ def main():
     n_nodes = state.tree_size
     bytes_launch = n_local * (4 * fsz + nres * fsz) + n_nodes * (5 * fsz + 12)
     hbm_gbs = bytes_launch / (kernel_ms * 1e-3) / 1e9
+    # HBM bytes per step from PMC counters (tools/measure_traffic.sh; separate rocprofv3 --pmc passes of this very
+    # command, gfx950 correction applied), if a measurement for this workload has been committed.
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if tj.get("workload") == args.workload and world == 1 and not args.nparts:
+            traffic = int(tj["hbm_bytes_per_step"])
+    except Exception:
+        pass
     line = {
         "metric": "Mparticles/s, accs_u() 4M Plummer fp32 theta=0.75" if args.workload == "plummer4m_f32"
         else "Mparticles/s, %s" % wl["desc"],
@@ -272,7 +281,7 @@ def main():
         "mac_evals_per_particle": round(mac_total / n, 2),
         "roofline": {
             "bound": "valu", "achieved": round(achieved_tflops, 3), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
-            "frac": round(achieved_tflops / PEAK_TFLOPS[dtype], 4), "traffic": None,
+            "frac": round(achieved_tflops / PEAK_TFLOPS[dtype], 4), "traffic": traffic,
             "flop_per_interaction": flop_per_inter, "interactions_per_launch": int(inter_local),
             "kernel_ms": round(kernel_ms, 4),
             "hbm": {"achieved": round(hbm_gbs, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
