@@ -37,6 +37,9 @@
 #ifndef RK_W4
 #define RK_W4 5 // R = 4
 #endif
+#ifndef RK_PREFETCH_MIN
+#define RK_PREFETCH_MIN 100000 // stack entries required before the next batch is popped ahead of time; >= 1000 compiles the software prefetch out (measured best at 7 waves/SIMD: no spills)
+#endif
 
 namespace rk
 {
@@ -460,7 +463,11 @@ __global__ void __launch_bounds__(256, (sizeof(F) == 4 ? (R <= 2 ? RK_W12 : RK_W
     };
 
     // ---- list building, software-pipelined: while batch A is tested, the records of batch B load ----
+#if RK_PREFETCH_MIN < 1000
     batch_t A, B;
+#else
+    batch_t A;
+#endif
     int kA = pop_and_load(A, 0, true);
     for (;;) {
         // What comes next: an exact pass when 64 candidates are queued (or when nothing else is left),
@@ -485,14 +492,22 @@ __global__ void __launch_bounds__(256, (sizeof(F) == 4 ? (R <= 2 ? RK_W12 : RK_W
             continue;
         }
         RK_STAMP(7)
-        // Prefetch: pop the next batch from below A's future pushes (up to 8 entries per popped run).
-        int kB = pop_and_load(B, 8 * kA, false);
+#if RK_PREFETCH_MIN < 1000
+        // Prefetch: pop the next batch from below A's future pushes (up to 8 entries per popped run) -- but only
+        // a full batch; a short stack is better refilled by A's pushes first (fewer, fuller rounds).
+        int kB = size >= RK_PREFETCH_MIN ? pop_and_load(B, 8 * kA, false) : 0;
         process(A);
         if (kB == 0) {
             kB = pop_and_load(B, 0, true);
         }
         A = B;
         kA = kB;
+#else
+        // No software prefetch: with 6-7 resident waves per SIMD the hardware hides the record-load latency,
+        // and the registers of a second batch are better spent on occupancy.
+        process(A);
+        kA = pop_and_load(A, 0, true);
+#endif
     }
 
     RK_STAMP(7)
