@@ -143,6 +143,31 @@ RK_EXPORT int rk_state_export(const rk_state *s, int *count, void **ptrs, int64_
 RK_EXPORT int rk_state_import(rk_state **out, int device, int count, void *const *ptrs, const int64_t *bytes,
                               const int64_t meta[RK_META_WORDS]);
 
+/*
+ * Device-side tree construction: what rakau::tree's constructor does on the
+ * host -- box-size deduction, discretisation + Morton encoding, indirect sort, permutation, node build, node
+ * properties, critical nodes (include/rakau/tree.hpp:1330-1487, 932-1111, 1116-1237) -- executed on `device`;
+ * the result is a traversal state like rk_state_create()'s, without any host tree.
+ *  parts        {x, y, z, m}: HOST arrays of nparts values of type F in the caller's ORIGINAL order.
+ *  box_size     0 = deduce from the data (2 * max|coord| * 1.05), otherwise the domain size.
+ *  max_leaf_n, ncrit   tree parameters (rakau defaults 16 and 128).
+ * Errors and messages follow the reference's constructor (invalid_argument for coordinates outside the box...).
+ * Node centres of mass are aggregated child -> parent, so they agree with the host builder to rounding.
+ */
+RK_EXPORT int rk_state_build(rk_state **out, int fp, int mac, int device, const void *const parts[4], int64_t nparts,
+                             double box_size, uint64_t max_leaf_n, uint64_t ncrit);
+
+/* *box_size = domain size; info[0..3] = box deduced, max_leaf_n, built on device (0/1), number of internal nodes. */
+RK_EXPORT int rk_state_tree_info(const rk_state *s, double *box_size, int64_t info[4]);
+
+/*
+ * Copy a piece of the resident tree to the host. what: 0..3 = x, y, z, masses in Morton order (p_its_u);
+ * 4 = sorted Morton codes (uint64); 5 = perm() as uint64 (original index of the particle at Morton position i);
+ * 6 = nodes() in the reference's record layout (stride 64/80 B for bh fp32/fp64, 64/88 for bh_geom);
+ * 7 = critical nodes as {code, begin, end} uint64 triples. 4..7 need a state made by rk_state_build().
+ */
+RK_EXPORT int rk_state_download(const rk_state *s, int what, void *dst);
+
 /* Device-to-device copy on `device` (plumbing for rk_state_export/import users that stage through their
  * own device buffers). */
 RK_EXPORT int rk_device_memcpy(void *dst, const void *src, int64_t bytes, int device);

@@ -22,7 +22,8 @@ _EXC = {1: ValueError, 2: ArithmeticError, 3: OverflowError, 4: RuntimeError, 5:
 SYMBOLS = [
     "rk_last_error", "rk_min_size", "rk_has_accelerator", "rk_device_count", "rk_state_create", "rk_state_destroy",
     "rk_state_info", "rk_state_crit_ranges", "rk_acc_pot", "rk_acc_pot_device", "rk_last_kernel_ms", "rk_state_export",
-    "rk_state_import", "rk_set_kernel_variant", "rk_device_memcpy", "rk_count_interactions",
+    "rk_state_import", "rk_set_kernel_variant", "rk_device_memcpy", "rk_count_interactions", "rk_state_build",
+    "rk_state_tree_info", "rk_state_download",
     # host-side tree builder (include/rakau_amd_tree.h)
     "rk_tree_create", "rk_tree_destroy", "rk_tree_info", "rk_tree_get", "rk_tree_nodes", "rk_tree_state",
     "rk_tree_acc_pot", "rk_tree_exact", "rk_tree_update_particles",
@@ -56,6 +57,9 @@ def lib():
     L.rk_set_kernel_variant.argtypes = [vp, ci]
     L.rk_device_memcpy.argtypes = [vp, vp, i64, ci]
     L.rk_count_interactions.argtypes = [vp, i64, i64, dbl, C.POINTER(u64)]
+    L.rk_state_build.argtypes = [C.POINTER(vp), ci, ci, ci, C.POINTER(vp), i64, dbl, u64, u64]
+    L.rk_state_tree_info.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64)]
+    L.rk_state_download.argtypes = [vp, ci, vp]
     if hasattr(L, "rk_tree_create"):
         L.rk_tree_create.argtypes = [C.POINTER(vp), ci, ci, vp, vp, vp, vp, i64, dbl, u64, u64, ci]
         L.rk_tree_destroy.argtypes = [vp]

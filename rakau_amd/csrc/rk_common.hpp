@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -147,6 +148,13 @@ struct rk_state {
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     bool timed = false;
     int variant = 0;
+    // Filled by the device-side tree build (rk_state_build); null for states created from a host tree.
+    void *bld_codes = nullptr;     // uint64 sorted Morton codes [nparts]
+    void *bld_perm = nullptr;      // uint32 original index of the particle at Morton position i [nparts]
+    void *bld_node_code = nullptr; // uint64 nodal codes in depth-first order [tree_size]
+    double box_size = 0.;
+    bool box_deduced = false;
+    uint64_t max_leaf_n = 0;
 };
 
 namespace rk
@@ -160,6 +168,9 @@ void launch_list(const rk_state &s, int q, const kparams<F> &p, const int64_t cl
                  const int64_t cls_end[n_classes], hipStream_t const streams[3]);
 template <typename F>
 void launch_block(const rk_state &s, int q, const kparams<F> &p, const uint32_t *list, int64_t n, hipStream_t stream);
+template <typename F>
+void build_device(rk_state &s, const void *const parts[4], int64_t nparts, double box_size, uint64_t max_leaf_n,
+                  std::string &bad_coord_msg);
 template <typename F>
 void launch_census(const rk_state &s, const kparams<F> &p, int64_t g_begin, int64_t g_end,
                    unsigned long long *d_counts, hipStream_t stream);

@@ -66,6 +66,11 @@ void free_state(rk_state *s)
     if (s->d_out) {
         (void)hipFree(s->d_out);
     }
+    for (void *b : {s->bld_codes, s->bld_perm, s->bld_node_code}) {
+        if (b) {
+            (void)hipFree(b);
+        }
+    }
     if (s->ev0) {
         (void)hipEventDestroy(s->ev0);
     }
@@ -779,6 +784,158 @@ int rk_state_import(rk_state **out, int device, int count, void *const *ptrs, co
         }
         build_host_mirrors(*s, crit);
         *out = s.release();
+    });
+}
+
+int rk_state_build(rk_state **out, int fp, int mac, int device, const void *const parts[4], int64_t nparts,
+                   double box_size, uint64_t max_leaf_n, uint64_t ncrit)
+{
+    return guard([&] {
+        if (!out) {
+            throw rk::error(RK_EINVAL, "null output pointer");
+        }
+        *out = nullptr;
+        check_common(fp, mac);
+        if (nparts < 0 || (nparts > 0 && (!parts || !parts[0] || !parts[1] || !parts[2] || !parts[3]))) {
+            throw rk::error(RK_EINVAL, "null particle array");
+        }
+        if (static_cast<uint64_t>(nparts) >= 0x7fffffffull) {
+            throw rk::error(RK_EOVERFLOW, "The number of particles (" + std::to_string(nparts)
+                                              + ") is too large for the 32-bit device indices");
+        }
+        // Parameter checks and messages of tree.hpp:1350-1362 of the reference.
+        if (!std::isfinite(box_size) || box_size < 0.) {
+            throw rk::error(RK_EINVAL, "The box size must be a finite non-negative value, but it is "
+                                           + std::to_string(box_size) + " instead");
+        }
+        if (!max_leaf_n) {
+            throw rk::error(RK_EINVAL, "The maximum number of particles per leaf must be nonzero");
+        }
+        if (!ncrit) {
+            throw rk::error(RK_EINVAL, "The critical number of particles for the vectorised computation of the "
+                                       "potentials/accelerations must be nonzero");
+        }
+        check_device(device);
+        device_guard dg(device);
+        state_ptr s(new rk_state);
+        s->fp = fp;
+        s->mac = mac;
+        s->device = device;
+        s->nparts = nparts;
+        s->ncrit = ncrit;
+        s->max_leaf_n = max_leaf_n;
+        s->box_size = box_size;
+        s->box_deduced = box_size == 0.;
+        if (nparts > 0) {
+            std::string msg;
+            if (fp == RK_F32) {
+                rk::build_device<float>(*s, parts, nparts, box_size, max_leaf_n, msg);
+            } else {
+                rk::build_device<double>(*s, parts, nparts, box_size, max_leaf_n, msg);
+            }
+            // Host mirrors + class lists from the critical-node array.
+            std::vector<uint4> crit(static_cast<size_t>(s->buf_bytes[RK_BUF_CRIT]) / sizeof(uint4));
+            if (!crit.empty()) {
+                RK_HIP(hipMemcpy(crit.data(), s->buf[RK_BUF_CRIT], crit.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+            }
+            build_host_mirrors(*s, crit);
+            const std::vector<uint32_t> lists = concat_class_lists(*s);
+            alloc_upload(*s, RK_BUF_CLASS, lists.data(), lists.size() * sizeof(uint32_t));
+        }
+        *out = s.release();
+    });
+}
+
+int rk_state_tree_info(const rk_state *s, double *box_size, int64_t info[4])
+{
+    return guard([&] {
+        if (!s || !box_size || !info) {
+            throw rk::error(RK_EINVAL, "null argument");
+        }
+        *box_size = s->box_size;
+        info[0] = s->box_deduced;
+        info[1] = static_cast<int64_t>(s->max_leaf_n);
+        info[2] = s->bld_codes != nullptr;
+        info[3] = s->n_internal;
+    });
+}
+
+int rk_state_download(const rk_state *s, int what, void *dst)
+{
+    return guard([&] {
+        if (!s || !dst) {
+            throw rk::error(RK_EINVAL, "null argument");
+        }
+        if (!s->nparts) {
+            return;
+        }
+        device_guard dg(s->device);
+        const size_t fsz = s->fp == RK_F32 ? 4 : 8, n = static_cast<size_t>(s->nparts),
+                     nn = static_cast<size_t>(s->tree_size);
+        auto fetch = [&](const void *dev, size_t bytes) {
+            std::vector<unsigned char> h(bytes);
+            RK_HIP(hipMemcpy(h.data(), dev, bytes, hipMemcpyDeviceToHost));
+            return h;
+        };
+        if (what >= 0 && what <= 3) {
+            const auto h = fetch(s->buf[RK_BUF_PART4], n * 4 * fsz);
+            for (size_t i = 0; i < n; ++i) {
+                std::memcpy(static_cast<unsigned char *>(dst) + i * fsz, h.data() + (i * 4 + static_cast<size_t>(what)) * fsz,
+                            fsz);
+            }
+            return;
+        }
+        if ((what == 4 || what == 5 || what == 6 || what == 7) && !s->bld_codes) {
+            throw rk::error(RK_EINVAL, "this state was created from a host tree: codes, permutation and nodal codes "
+                                       "live in the caller's tree");
+        }
+        if (what == 4) {
+            RK_HIP(hipMemcpy(dst, s->bld_codes, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        } else if (what == 5) {
+            const auto h = fetch(s->bld_perm, n * sizeof(uint32_t));
+            auto *o = static_cast<uint64_t *>(dst);
+            for (size_t i = 0; i < n; ++i) {
+                uint32_t v;
+                std::memcpy(&v, h.data() + i * 4, 4);
+                o[i] = v;
+            }
+        } else if (what == 6) {
+            // Node array in the reference's record layout (tree_fwd.hpp:77-116): begin, end, n_children, code, level,
+            // props[4], dim2 | dim, delta.
+            const auto topo = fetch(s->buf[RK_BUF_NODE_TOPO], nn * sizeof(uint4));
+            const auto com = fetch(s->buf[RK_BUF_NODE_COM], nn * 4 * fsz);
+            const auto macp = fetch(s->buf[RK_BUF_NODE_MAC], nn * 2 * fsz);
+            const auto code = fetch(s->bld_node_code, nn * sizeof(uint64_t));
+            const size_t off_props = 40, off_dim = off_props + 4 * fsz;
+            const size_t stride = ((off_dim + (s->mac == RK_MAC_BH ? 1 : 2) * fsz + 7) / 8) * 8;
+            auto *o = static_cast<unsigned char *>(dst);
+            std::memset(o, 0, nn * stride);
+            for (size_t i = 0; i < nn; ++i) {
+                uint4 t;
+                std::memcpy(&t, topo.data() + i * sizeof(uint4), sizeof(uint4));
+                uint64_t c;
+                std::memcpy(&c, code.data() + i * 8, 8);
+                const uint64_t hdr[5] = {t.y, t.z, t.x, c, (63u - static_cast<unsigned>(__builtin_clzll(c))) / 3u};
+                std::memcpy(o + i * stride, hdr, sizeof(hdr));
+                std::memcpy(o + i * stride + off_props, com.data() + i * 4 * fsz, 4 * fsz);
+                std::memcpy(o + i * stride + off_dim, macp.data() + i * 2 * fsz, (s->mac == RK_MAC_BH ? 1 : 2) * fsz);
+            }
+        } else if (what == 7) {
+            // Critical nodes as {code, begin, end} triples.
+            const auto code = fetch(s->bld_node_code, nn * sizeof(uint64_t));
+            std::vector<uint4> crit(static_cast<size_t>(s->n_crit));
+            RK_HIP(hipMemcpy(crit.data(), s->buf[RK_BUF_CRIT], crit.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+            auto *o = static_cast<uint64_t *>(dst);
+            for (size_t g = 0; g < crit.size(); ++g) {
+                uint64_t c;
+                std::memcpy(&c, code.data() + static_cast<size_t>(crit[g].z) * 8, 8);
+                o[3 * g] = c;
+                o[3 * g + 1] = crit[g].x;
+                o[3 * g + 2] = crit[g].y;
+            }
+        } else {
+            throw rk::error(RK_EINVAL, "invalid selector for rk_state_download");
+        }
     });
 }
 

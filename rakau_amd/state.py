@@ -51,6 +51,42 @@ class State:
         self._read_info()
 
     @classmethod
+    def build(cls, x, y, z, m, box_size=None, max_leaf_n=16, ncrit=128, mac="bh", device=0):
+        """Device-side tree construction (rk_state_build): particles in the caller's original order."""
+        x, y, z, m = (np.ascontiguousarray(v) for v in (x, y, z, m))
+        dtype = x.dtype
+        if dtype not in _FP or any(v.dtype != dtype for v in (y, z, m)):
+            raise TypeError("x, y, z, m must share a float32 or float64 dtype")
+        if not (x.size == y.size == z.size == m.size):
+            raise ValueError("The input ranges for the particle coordinates have inconsistent sizes")
+        h = C.c_void_p()
+        parts = (C.c_void_p * 4)(x.ctypes.data, y.ctypes.data, z.ctypes.data, m.ctypes.data)
+        _capi.check(_capi.lib().rk_state_build(C.byref(h), _FP[dtype], _MAC[mac], device, parts, x.size,
+                                               0.0 if box_size is None else float(box_size), max_leaf_n, ncrit))
+        return cls._from_handle(h, dtype, mac)
+
+    def tree_info(self):
+        box = C.c_double()
+        info = (C.c_int64 * 4)()
+        _capi.check(_capi.lib().rk_state_tree_info(self._h, C.byref(box), info))
+        return dict(box_size=box.value, box_deduced=bool(info[0]), max_leaf_n=int(info[1]), device_built=bool(info[2]),
+                    n_internal=int(info[3]))
+
+    def download(self, what):
+        """what: 'x','y','z','m' (Morton order), 'codes', 'perm', 'nodes' (reference record layout), 'crit'."""
+        sel = {"x": 0, "y": 1, "z": 2, "m": 3, "codes": 4, "perm": 5, "nodes": 6, "crit": 7}[what]
+        if sel <= 3:
+            out = np.empty(self.nparts, dtype=self.dtype)
+        elif sel in (4, 5):
+            out = np.empty(self.nparts, dtype=np.uint64)
+        elif sel == 6:
+            out = np.zeros(self.tree_size, dtype=node_dtype(self.dtype, self.mac))
+        else:
+            out = np.empty((self.n_crit, 3), dtype=np.uint64)
+        _capi.check(_capi.lib().rk_state_download(self._h, sel, out.ctypes.data))
+        return out
+
+    @classmethod
     def _from_handle(cls, handle, dtype, mac):
         self = cls.__new__(cls)
         self._h = handle
