@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--workload", default="plummer4m_f32", choices=sorted(WORKLOADS))
     ap.add_argument("--nparts", type=int, default=None, help="override the particle count of the workload")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 = default)")
+    ap.add_argument("--builder", default="host", choices=["device", "host"],
+                    help="where the tree of the timed state is built (host = the C++ header's builder, whose trees are "
+                         "bit-identical to the CPU oracle's; device = rk_state_build, centres of mass differ by rounding)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all host cores)")
     args = ap.parse_args()
@@ -147,13 +150,25 @@ def main():
     tree = None
     if rank == 0:
         m, x, y, z = plummer_numpy(n, dtype)
+        if args.builder == "device":
+            rakau_amd.Octree(x[:1024], y[:1024], z[:1024], m[:1024], mac=mac, builder="device").close()  # warm up
         t0 = time.perf_counter()
-        tree = rakau_amd.Octree(x, y, z, m, mac=mac)
+        tree = rakau_amd.Octree(x, y, z, m, mac=mac, builder=args.builder)
         t_build = time.perf_counter() - t0
         t0 = time.perf_counter()
         state = tree.state()
         torch.cuda.synchronize()
         t_upload = time.perf_counter() - t0
+        # Device-side construction of the same tree, timed for the record.
+        t_dev_build = None
+        try:
+            rakau_amd.State.build(x[:1024], y[:1024], z[:1024], m[:1024], mac=mac).close()
+            t0 = time.perf_counter()
+            sb = rakau_amd.State.build(x, y, z, m, mac=mac)
+            t_dev_build = time.perf_counter() - t0
+            sb.close()
+        except Exception as e:  # pragma: no cover
+            t_dev_build = str(e)
     if world > 1:
         payload = [None]
         if rank == 0:
@@ -287,8 +302,9 @@ def main():
             "hbm": {"achieved": round(hbm_gbs, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(hbm_gbs / PEAK_HBM_GBS, 5), "algorithmic_bytes_per_launch": int(bytes_launch)},
         },
-        "host": {"tree_build_s": round(t_build, 3), "upload_s": round(t_upload, 3),
-                 "replicate_s": round(t_replicate, 4)},
+        "host": {"builder": args.builder, "tree_build_s": round(t_build, 3), "upload_s": round(t_upload, 3),
+                 "replicate_s": round(t_replicate, 4),
+                 "device_build_s": round(t_dev_build, 4) if isinstance(t_dev_build, float) else t_dev_build},
         "reference_published": {"best_cpu_2xXeon6148_Mps": 48.8, "V100_Mps": 42.1, "RX570_rocm_path_Mps": 15.6,
                                 "note": "README.md:42-49 of the reference, single cold calls on other hardware"},
     }

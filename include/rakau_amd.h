@@ -164,7 +164,8 @@ RK_EXPORT int rk_state_tree_info(const rk_state *s, double *box_size, int64_t in
  * Copy a piece of the resident tree to the host. what: 0..3 = x, y, z, masses in Morton order (p_its_u);
  * 4 = sorted Morton codes (uint64); 5 = perm() as uint64 (original index of the particle at Morton position i);
  * 6 = nodes() in the reference's record layout (stride 64/80 B for bh fp32/fp64, 64/88 for bh_geom);
- * 7 = critical nodes as {code, begin, end} uint64 triples. 4..7 need a state made by rk_state_build().
+ * 7 = critical nodes as {code, begin, end} uint64 triples; 8 = the particles as {x, y, z, m} records
+ * (4 * nparts values, Morton order). 4..7 need a state made by rk_state_build().
  */
 RK_EXPORT int rk_state_download(const rk_state *s, int what, void *dst);
 

@@ -143,6 +143,8 @@ struct eps_tag {
 };
 struct split_tag {
 };
+struct device_build_tag {
+};
 
 // Tree construction.
 inline constexpr kw_detail::name<box_size_tag> box_size{};
@@ -159,6 +161,9 @@ inline constexpr kw_detail::name<nparts_tag> nparts{};
 inline constexpr kw_detail::name<G_tag> G{};
 inline constexpr kw_detail::name<eps_tag> eps{};
 inline constexpr kw_detail::name<split_tag> split{};
+// Extension (not in rakau): device_build = true runs the tree construction itself on the GPU
+// (rk_state_build) and only downloads the arrays the host-side accessors need.
+inline constexpr kw_detail::name<device_build_tag> device_build{};
 
 } // namespace kwargs
 } // namespace rakau_amd

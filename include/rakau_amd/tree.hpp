@@ -805,10 +805,80 @@ private:
         v = std::move(nv);
     }
 
+    // Device-side construction (rk_state_build): the GPU encodes, sorts and builds; the host receives the arrays its
+    // accessors expose (particles in Morton order, codes, permutation, nodes, critical nodes) and keeps the resulting
+    // traversal state as the replica of device 0.
+    void sort_and_build_on_device()
+    {
+        const size_type np = m_parts[0].size();
+        const void *parts[4] = {m_parts[0].data(), m_parts[1].data(), m_parts[2].data(), m_parts[3].data()};
+        detail::device_state ds;
+        throw_status(rk_state_build(&ds.h, std::is_same_v<F, float> ? RK_F32 : RK_F64,
+                                    MAC == mac::bh ? RK_MAC_BH : RK_MAC_BH_GEOM, 0, parts, static_cast<std::int64_t>(np),
+                                    m_box_size_deduced ? 0. : static_cast<double>(m_box_size), m_max_leaf_n, m_ncrit));
+        std::int64_t info[8], tinfo[4];
+        double box = 0.;
+        throw_status(rk_state_info(ds.h, info));
+        throw_status(rk_state_tree_info(ds.h, &box, tinfo));
+        m_box_size = static_cast<F>(box);
+        {
+            // One transfer of the {x, y, z, m} records, de-interleaved by the host threads.
+            std::vector<F> aos(static_cast<std::size_t>(np) * 4u);
+            if (np) {
+                throw_status(rk_state_download(ds.h, 8, aos.data()));
+            }
+            parallel_blocks(np, 1u << 16, [&](std::size_t b, std::size_t e) {
+                for (std::size_t i = b; i < e; ++i) {
+                    for (std::size_t j = 0; j < 4; ++j) {
+                        m_parts[j][i] = aos[4u * i + j];
+                    }
+                }
+            });
+        }
+        m_codes.resize(np);
+        std::vector<std::uint64_t> order(np);
+        m_tree.resize(static_cast<std::size_t>(info[1]));
+        std::vector<std::uint64_t> crit(static_cast<std::size_t>(info[2]) * 3u);
+        if (np) {
+            throw_status(rk_state_download(ds.h, 4, m_codes.data()));
+            throw_status(rk_state_download(ds.h, 5, order.data()));
+            throw_status(rk_state_download(ds.h, 6, m_tree.data()));
+            throw_status(rk_state_download(ds.h, 7, crit.data()));
+        }
+        m_crit_nodes.resize(crit.size() / 3u);
+        for (std::size_t i = 0; i < m_crit_nodes.size(); ++i) {
+            m_crit_nodes[i] = cnode_type{static_cast<UInt>(crit[3 * i]), static_cast<size_type>(crit[3 * i + 1]),
+                                         static_cast<size_type>(crit[3 * i + 2])};
+        }
+        // order[i] = index (in the order before this build) of the particle now at Morton position i.
+        std::vector<size_type> new_perm(np);
+        m_last_perm.resize(np);
+        m_inv_perm.resize(np);
+        parallel_blocks(np, 1u << 16, [&](std::size_t b, std::size_t e) {
+            for (std::size_t i = b; i < e; ++i) {
+                m_last_perm[i] = static_cast<size_type>(order[i]);
+                new_perm[i] = m_perm[m_last_perm[i]];
+            }
+        });
+        m_perm = std::move(new_perm);
+        parallel_blocks(np, 1u << 16, [&](std::size_t b, std::size_t e) {
+            for (std::size_t i = b; i < e; ++i) {
+                m_inv_perm[m_perm[i]] = i;
+            }
+        });
+        std::lock_guard<std::mutex> lk(m_dev_mutex);
+        m_dev.clear();
+        m_dev.emplace_back(std::move(ds));
+    }
+
     // Re-establish codes, Morton order, permutations and the tree for the current particle data
     // (construction: tree.hpp:1435-1486; after an update: tree.hpp:3678-3743).
     void sort_and_build()
     {
+        if (m_device_build && rk_has_accelerator()) {
+            sort_and_build_on_device();
+            return;
+        }
         const size_type np = m_parts[0].size();
         if (m_box_size_deduced) {
             m_box_size = determine_box_size(p_its_u(), np);
@@ -914,6 +984,9 @@ public:
             box_size = checked_cast<F>(p(kwargs::box_size));
             deduced = false;
         }
+        if constexpr (P::has(kwargs::device_build)) {
+            m_device_build = static_cast<bool>(p(kwargs::device_build));
+        }
         size_type max_leaf_n = default_max_leaf_n, ncrit = default_ncrit;
         if constexpr (P::has(kwargs::max_leaf_n)) {
             max_leaf_n = checked_cast<size_type>(p(kwargs::max_leaf_n));
@@ -965,13 +1038,14 @@ public:
     // (the reference re-creates its accelerator views after every copy/move, tree.hpp:1742-1824).
     tree(const tree &o)
         : m_box_size(o.m_box_size), m_box_size_deduced(o.m_box_size_deduced), m_max_leaf_n(o.m_max_leaf_n),
-          m_ncrit(o.m_ncrit), m_parts(o.m_parts), m_codes(o.m_codes), m_perm(o.m_perm), m_last_perm(o.m_last_perm),
+          m_ncrit(o.m_ncrit), m_device_build(o.m_device_build), m_parts(o.m_parts), m_codes(o.m_codes), m_perm(o.m_perm),
+          m_last_perm(o.m_last_perm),
           m_inv_perm(o.m_inv_perm), m_tree(o.m_tree), m_crit_nodes(o.m_crit_nodes)
     {
     }
     tree(tree &&o) noexcept
         : m_box_size(o.m_box_size), m_box_size_deduced(o.m_box_size_deduced), m_max_leaf_n(o.m_max_leaf_n),
-          m_ncrit(o.m_ncrit), m_parts(std::move(o.m_parts)), m_codes(std::move(o.m_codes)),
+          m_ncrit(o.m_ncrit), m_device_build(o.m_device_build), m_parts(std::move(o.m_parts)), m_codes(std::move(o.m_codes)),
           m_perm(std::move(o.m_perm)), m_last_perm(std::move(o.m_last_perm)), m_inv_perm(std::move(o.m_inv_perm)),
           m_tree(std::move(o.m_tree)), m_crit_nodes(std::move(o.m_crit_nodes)), m_dev(std::move(o.m_dev))
     {
@@ -993,6 +1067,7 @@ public:
             m_box_size_deduced = o.m_box_size_deduced;
             m_max_leaf_n = o.m_max_leaf_n;
             m_ncrit = o.m_ncrit;
+            m_device_build = o.m_device_build;
             m_parts = std::move(o.m_parts);
             m_codes = std::move(o.m_codes);
             m_perm = std::move(o.m_perm);
@@ -1490,6 +1565,10 @@ public:
     {
         return m_box_size_deduced;
     }
+    bool device_build() const
+    {
+        return m_device_build;
+    }
     size_type max_leaf_n() const
     {
         return m_max_leaf_n;
@@ -1588,6 +1667,8 @@ private:
     bool m_box_size_deduced;
     size_type m_max_leaf_n;
     size_type m_ncrit;
+    // Extension: build (and rebuild after updates) on the GPU instead of the host.
+    bool m_device_build = false;
     // Particles in Morton order: x, y, z, masses.
     std::array<f_vector<F>, NDim + 1u> m_parts;
     std::vector<UInt> m_codes;

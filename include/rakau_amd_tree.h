@@ -16,7 +16,8 @@ extern "C" {
 typedef struct rk_tree rk_tree;
 
 /* octree<F, MAC>{x_coords, y_coords, z_coords, masses, nparts, [box_size], max_leaf_n, ncrit}.
- * box_size == 0 -> deduced from the data. flags: reserved, pass 0. */
+ * box_size == 0 -> deduced from the data. flags: bit 0 = build (and rebuild) the tree on the GPU
+ * (kwargs::device_build, rk_state_build). */
 RK_EXPORT int rk_tree_create(rk_tree **out, int fp, int mac, const void *x, const void *y, const void *z,
                              const void *m, int64_t nparts, double box_size, uint64_t max_leaf_n, uint64_t ncrit,
                              int flags);

@@ -885,6 +885,11 @@ int rk_state_download(const rk_state *s, int what, void *dst)
             }
             return;
         }
+        if (what == 8) {
+            // Particles as stored: {x, y, z, m} records in Morton order.
+            RK_HIP(hipMemcpy(dst, s->buf[RK_BUF_PART4], n * 4 * fsz, hipMemcpyDeviceToHost));
+            return;
+        }
         if ((what == 4 || what == 5 || what == 6 || what == 7) && !s->bld_codes) {
             throw rk::error(RK_EINVAL, "this state was created from a host tree: codes, permutation and nodal codes "
                                        "live in the caller's tree");

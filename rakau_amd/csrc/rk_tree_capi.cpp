@@ -59,7 +59,7 @@ struct fp_of<tree<3, F, std::size_t, M>> {
 
 template <typename F, mac M>
 octree<F, M> make_tree(const void *x, const void *y, const void *z, const void *m, std::int64_t n, double box,
-                       std::uint64_t max_leaf_n, std::uint64_t ncrit)
+                       std::uint64_t max_leaf_n, std::uint64_t ncrit, bool dev)
 {
     const auto *xs = static_cast<const F *>(x), *ys = static_cast<const F *>(y), *zs = static_cast<const F *>(z),
                *ms = static_cast<const F *>(m);
@@ -67,11 +67,11 @@ octree<F, M> make_tree(const void *x, const void *y, const void *z, const void *
         return octree<F, M>{kwargs::x_coords = xs,         kwargs::y_coords = ys,
                             kwargs::z_coords = zs,         kwargs::masses = ms,
                             kwargs::nparts = n,            kwargs::max_leaf_n = max_leaf_n,
-                            kwargs::ncrit = ncrit};
+                            kwargs::ncrit = ncrit,         kwargs::device_build = dev};
     }
     return octree<F, M>{kwargs::x_coords = xs,         kwargs::y_coords = ys, kwargs::z_coords = zs,
                         kwargs::masses = ms,           kwargs::nparts = n,    kwargs::box_size = box,
-                        kwargs::max_leaf_n = max_leaf_n, kwargs::ncrit = ncrit};
+                        kwargs::max_leaf_n = max_leaf_n, kwargs::ncrit = ncrit, kwargs::device_build = dev};
 }
 
 } // namespace
@@ -79,7 +79,7 @@ octree<F, M> make_tree(const void *x, const void *y, const void *z, const void *
 extern "C" {
 
 int rk_tree_create(rk_tree **out, int fp, int mac_kind, const void *x, const void *y, const void *z, const void *m,
-                   int64_t nparts, double box_size, uint64_t max_leaf_n, uint64_t ncrit, int)
+                   int64_t nparts, double box_size, uint64_t max_leaf_n, uint64_t ncrit, int flags)
 {
     return guard([&] {
         if (!out) {
@@ -90,20 +90,21 @@ int rk_tree_create(rk_tree **out, int fp, int mac_kind, const void *x, const voi
             throw std::invalid_argument("invalid particle arrays");
         }
         const int key = fp * 2 + mac_kind;
+        const bool dev = (flags & 1) != 0;
         std::unique_ptr<rk_tree> t;
         switch (key) {
             case 0:
-                t.reset(new rk_tree{make_tree<float, mac::bh>(x, y, z, m, nparts, box_size, max_leaf_n, ncrit)});
+                t.reset(new rk_tree{make_tree<float, mac::bh>(x, y, z, m, nparts, box_size, max_leaf_n, ncrit, dev)});
                 break;
             case 1:
-                t.reset(new rk_tree{make_tree<float, mac::bh_geom>(x, y, z, m, nparts, box_size, max_leaf_n, ncrit)});
+                t.reset(new rk_tree{make_tree<float, mac::bh_geom>(x, y, z, m, nparts, box_size, max_leaf_n, ncrit, dev)});
                 break;
             case 2:
-                t.reset(new rk_tree{make_tree<double, mac::bh>(x, y, z, m, nparts, box_size, max_leaf_n, ncrit)});
+                t.reset(new rk_tree{make_tree<double, mac::bh>(x, y, z, m, nparts, box_size, max_leaf_n, ncrit, dev)});
                 break;
             case 3:
                 t.reset(
-                    new rk_tree{make_tree<double, mac::bh_geom>(x, y, z, m, nparts, box_size, max_leaf_n, ncrit)});
+                    new rk_tree{make_tree<double, mac::bh_geom>(x, y, z, m, nparts, box_size, max_leaf_n, ncrit, dev)});
                 break;
             default:
                 throw std::invalid_argument("invalid fp / mac selector");

@@ -17,7 +17,8 @@ _MAC = {"bh": _capi.RK_MAC_BH, "bh_geom": _capi.RK_MAC_BH_GEOM}
 
 
 class Octree:
-    def __init__(self, x_coords, y_coords, z_coords, masses, box_size=None, max_leaf_n=16, ncrit=128, mac="bh"):
+    def __init__(self, x_coords, y_coords, z_coords, masses, box_size=None, max_leaf_n=16, ncrit=128, mac="bh",
+                 builder="host"):
         x, y, z, m = (np.ascontiguousarray(v) for v in (x_coords, y_coords, z_coords, masses))
         self.dtype = x.dtype
         if self.dtype not in _FP or any(v.dtype != self.dtype for v in (y, z, m)):
@@ -34,7 +35,8 @@ class Octree:
             box_size = float(np.finfo(self.dtype).tiny)
         _capi.check(_capi.lib().rk_tree_create(C.byref(self._h), _FP[self.dtype], _MAC[mac], x.ctypes.data,
                                                y.ctypes.data, z.ctypes.data, m.ctypes.data, x.size,
-                                               0.0 if box_size is None else float(box_size), max_leaf_n, ncrit, 0))
+                                               0.0 if box_size is None else float(box_size), max_leaf_n, ncrit,
+                                               1 if builder == "device" else 0))
         self._refresh()
 
     def _refresh(self):

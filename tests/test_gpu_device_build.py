@@ -129,3 +129,45 @@ def test_build_time_4m():
     # (fp32 coordinates of magnitude ~2000 carry ~1e-4 of absolute rounding in a centre of mass, whichever order the
     # particles are summed in: near-field monopoles move by ~1e-4 relative.)
     assert np.median(e) < 1e-5 and e.max() < 5e-2 and n_off < 4000
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_octree_device_builder_front_door(dtype):
+    """kwargs::device_build through the C++ header (Octree(builder="device")): accessors, ordered outputs against the
+    direct sum (test/ordering_acc.cpp:93-97 bounds) and update_particles_u (rebuild on the GPU) behave like the host
+    builder's."""
+    rng = oracle.Rng(2)
+    s = 10000
+    m, x, y, z = rng.uniform_particles(s, 1.0, dtype)
+    td = rakau_amd.Octree(x, y, z, m, box_size=4.0, builder="device")
+    th = rakau_amd.Octree(x, y, z, m, box_size=4.0)
+    assert (td.n_nodes, td.n_crit, td.box_size) == (th.n_nodes, th.n_crit, th.box_size)
+    for a, b in ((td.perm(), th.perm()), (td.inv_perm(), th.inv_perm()), (td.last_perm(), th.last_perm()),
+                 (td.c_it_u(), th.c_it_u()), (td.crit_nodes(), th.crit_nodes())):
+        assert np.array_equal(a, b)
+    for a, b in zip(td.p_its_u(), th.p_its_u()):
+        assert np.array_equal(a, b)
+    nd, nh = td.nodes(), th.nodes()
+    for k in ("begin", "end", "n_children", "code", "level"):
+        assert np.array_equal(nd[k], nh[k])
+    tol = 2e-3 if dtype == np.float32 else 2e-11
+
+    def check(t):
+        res = t.accs_o(0.01)
+        for i in range(0, s, 997):
+            ex = t.exact_acc_o(i).astype(np.float64)
+            got = np.array([r[i] for r in res], dtype=np.float64)
+            assert abs(np.linalg.norm(ex) - np.linalg.norm(got)) / np.linalg.norm(ex) <= tol
+
+    check(td)
+    c, sn = dtype(np.cos(0.7)), dtype(np.sin(0.7))
+
+    def rot(a):
+        ax, ay = a[0].copy(), a[1].copy()
+        a[0][:], a[1][:] = c * ax - sn * ay, sn * ax + c * ay
+
+    td.update_particles_u(rot)
+    th.update_particles_u(rot)
+    assert np.array_equal(td.perm(), th.perm()) and np.array_equal(td.last_perm(), th.last_perm())
+    assert np.array_equal(td.inv_perm()[td.perm()], np.arange(s, dtype=np.uint64))
+    check(td)
