@@ -37,10 +37,22 @@ __host__ __device__ constexpr int nres_of(int q)
 
 // Target groups (critical nodes) are binned by the number of targets each lane of a wave holds:
 // class c holds groups with size <= 64 * R(c); the last class is served by the block-per-group kernel.
-constexpr int n_classes = 5;
+constexpr int n_classes = 7;  // classes 0..5 are served by wave kernels, the last one by the block-per-group kernel
+constexpr int big_class = n_classes - 1;
+constexpr int n_list_R = 6;   // variant 2: class c keeps R = c + 1 targets per lane
 __host__ __device__ constexpr int class_R(int c)
 {
     return c == 0 ? 1 : (c == 1 ? 2 : (c == 2 ? 4 : 8));
+}
+// Largest number of targets per lane used by the list kernel. Measured on MI355X (4M Plummer): 4 -> 2.58 ms, 5 -> 2.85 ms,
+// 6 -> 2.79 ms: beyond 4 the registers cost more occupancy than the better lane packing returns.
+#ifndef RK_MAX_R
+#define RK_MAX_R 4
+#endif
+// Targets per lane of the variant-2 (list kernel) classes.
+__host__ __device__ constexpr int class2_R(int c)
+{
+    return c + 1;
 }
 inline int class_of(int64_t size)
 {
@@ -48,18 +60,18 @@ inline int class_of(int64_t size)
     if (size <= 128) return 1;
     if (size <= 256) return 2;
     if (size <= 512) return 3;
-    return 4;
+    return big_class;
 }
 // Variant 2 (LDS interaction lists): each lane holds R targets, TP = ceil(T / R) target slots and
 // NS = floor(64 / TP) source splits share the wave. The dense phase costs R / NS lane-iterations per
 // source; pick the R that minimises it (ties: fewer registers).
 inline int class2_of(int64_t size)
 {
-    if (size > 256) return 4;
+    if (size > 64 * RK_MAX_R) return big_class;
     int best = -1;
     double best_cost = 0.;
-    for (int c = 0; c < 3; ++c) { // R = 1, 2, 4 (more targets per lane costs too many registers)
-        const int64_t R = class_R(c), TP = (size + R - 1) / R;
+    for (int c = 0; c < RK_MAX_R; ++c) { // R = 1 .. RK_MAX_R
+        const int64_t R = class2_R(c), TP = (size + R - 1) / R;
         if (TP > 64) continue;
         const double cost = static_cast<double>(R) / static_cast<double>(64 / TP);
         if (best < 0 || cost < best_cost - 1e-12) {
@@ -88,6 +100,8 @@ struct node_rec {
 static_assert(sizeof(node_rec<float>) == 48 && sizeof(node_rec<double>) == 96, "unexpected node record size");
 // A stack entry packs (first child record << 3) | (number of children - 1).
 constexpr uint32_t max_list_nodes = 1u << 29;
+// Capacities of the per-supergroup lists written by the pre-pass kernel.
+constexpr uint32_t SUP_CAPC = 1536, SUP_CAPR = 512;
 
 // Kernel parameter block (passed by value).
 template <typename F>
@@ -106,6 +120,14 @@ struct kparams {
     uint32_t out_sub; // value subtracted from the particle index when writing (compact output)
     unsigned long long *dbg; // diagnostic builds only (RK_STAMPS): per-section cycle totals
     int xcd_mode;            // block -> group-list mapping (see xcd_map_block)
+    // Supergroup pre-pass (k_super): K consecutive target groups share the upper part of list building.
+    // super_k == 0 disables it. Per supergroup S: sup_common[S * SUP_CAPC ...] = sources {x, y, z, m} accepted for every
+    // member group; sup_resid[S * SUP_CAPR ...] = node records every member still has to test itself;
+    // sup_cnt[S] = {number of common sources, number of residual records | overflow flag in bit 31}.
+    uint32_t super_k, n_crit;
+    typename vt<F>::v4 *sup_common;
+    uint32_t *sup_resid;
+    uint2 *sup_cnt;
 };
 
 struct error : std::runtime_error {
@@ -144,10 +166,14 @@ struct rk_state {
     size_t d_out_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // Side streams (and fork/join events) that let the per-class kernels of one call overlap.
-    hipStream_t aux_stream[2] = {nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    hipStream_t aux_stream[rk::n_list_R] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[rk::n_list_R] = {};
     bool timed = false;
     int variant = 0;
+    // Scratch of the supergroup pre-pass (allocated on first use).
+    void *sup_common = nullptr, *sup_resid = nullptr, *sup_cnt = nullptr;
+    int64_t sup_alloc = 0; // number of supergroups the scratch was sized for
+    int super_k = -1;      // -1 = not initialised (read RK_SUPER_K, default 8)
     // Filled by the device-side tree build (rk_state_build); null for states created from a host tree.
     void *bld_codes = nullptr;     // uint64 sorted Morton codes [nparts]
     void *bld_perm = nullptr;      // uint32 original index of the particle at Morton position i [nparts]
@@ -165,7 +191,9 @@ void launch_traversal(const rk_state &s, int q, const kparams<F> &p, const int64
                       const int64_t cls_end[n_classes], hipStream_t stream);
 template <typename F>
 void launch_list(const rk_state &s, int q, const kparams<F> &p, const int64_t cls_begin[n_classes],
-                 const int64_t cls_end[n_classes], hipStream_t const streams[3]);
+                 const int64_t cls_end[n_classes], hipStream_t const streams[n_list_R]);
+template <typename F>
+void launch_super(const rk_state &s, const kparams<F> &p, int64_t s_begin, int64_t s_end, hipStream_t stream);
 template <typename F>
 void launch_block(const rk_state &s, int q, const kparams<F> &p, const uint32_t *list, int64_t n, hipStream_t stream);
 template <typename F>

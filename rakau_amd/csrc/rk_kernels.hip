@@ -327,10 +327,10 @@ static void launch_qm(const rk_state &s, const kparams<F> &p, const int64_t cb[n
     wave_launch(std::integral_constant<int, 4>{}, 2);
     wave_launch(std::integral_constant<int, 8>{}, 3);
     {
-        const int64_t n = ce[4] - cb[4];
+        const int64_t n = ce[big_class] - cb[big_class];
         if (n > 0) {
             hipLaunchKernelGGL((k_dfs_block<F, Q, MAC>), dim3(static_cast<unsigned>(n)), dim3(256), 0, stream, p,
-                               lists + s.class_off[4] + cb[4], static_cast<int>(n));
+                               lists + s.class_off[big_class] + cb[big_class], static_cast<int>(n));
         }
     }
 }

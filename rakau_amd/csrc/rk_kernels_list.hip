@@ -28,18 +28,28 @@
 #ifndef RK_UNR2
 #define RK_UNR2 2 // R = 2
 #endif
+#ifndef RK_UNR3
+#define RK_UNR3 1 // R = 3
+#endif
 #ifndef RK_UNR4
 #define RK_UNR4 1 // R = 4
 #endif
 #ifndef RK_W12
 #define RK_W12 7 // waves per SIMD the R <= 2 kernels are compiled for
 #endif
+#ifndef RK_W3
+#define RK_W3 6 // R = 3
+#endif
 #ifndef RK_W4
 #define RK_W4 5 // R = 4
 #endif
-#ifndef RK_PREFETCH_MIN
-#define RK_PREFETCH_MIN 100000 // stack entries required before the next batch is popped ahead of time; >= 1000 compiles the software prefetch out (measured best at 7 waves/SIMD: no spills)
+#ifndef RK_W5
+#define RK_W5 4 // R = 5
 #endif
+#ifndef RK_W6
+#define RK_W6 3 // R = 6
+#endif
+
 
 namespace rk
 {
@@ -149,7 +159,8 @@ __device__ __forceinline__ void lk_eval_tile(const typename vt<F>::v4 *__restric
     return; // diagnostic build: list building only
 #endif
     // Keep about four interactions in flight per lane whatever R is.
-    constexpr int UNR = R >= 4 ? RK_UNR4 : (R == 2 ? RK_UNR2 : RK_UNR1);
+    constexpr int UNR = R >= 4 ? RK_UNR4 : (R == 3 ? RK_UNR3 : (R == 2 ? RK_UNR2 : RK_UNR1));
+    static_assert(R <= 6);
     const int full = n_src / ns, rem = n_src - full * ns;
     const v4 *p = src + sp;
     int j = sp;
@@ -167,7 +178,7 @@ __device__ __forceinline__ void lk_eval_tile(const typename vt<F>::v4 *__restric
 }
 
 template <typename F, int Q, int MAC, int R>
-__global__ void __launch_bounds__(256, (sizeof(F) == 4 ? (R <= 2 ? RK_W12 : RK_W4) : 1)) k_list(const kparams<F> P, const uint32_t *__restrict__ list, int n_list)
+__global__ void __launch_bounds__(256, (sizeof(F) == 4 ? (R <= 2 ? RK_W12 : (R == 3 ? RK_W3 : (R == 4 ? RK_W4 : (R == 5 ? RK_W5 : RK_W6)))) : 1)) k_list(const kparams<F> P, const uint32_t *__restrict__ list, int n_list)
 {
     using v4 = typename vt<F>::v4;
     using v2 = typename vt<F>::v2;
@@ -220,7 +231,19 @@ __global__ void __launch_bounds__(256, (sizeof(F) == 4 ? (R <= 2 ? RK_W12 : RK_W
     const v4 pr0 = P.part4[tb], pr1 = P.part4[te - 1u];
     RK_STAMP_DECL
     int size = 0, n_src = 0, n_lq = 0, n_uq = 0;
-    {
+    // Supergroup pre-pass results for this group's supergroup (if enabled and not overflowed).
+    uint32_t sup_S = 0, sup_ncommon = 0, sup_nresid = 0, sup_rpos = 0;
+    bool from_root = true;
+    if (P.super_k != 0u) {
+        sup_S = g / P.super_k;
+        const uint2 cnt = P.sup_cnt[sup_S];
+        if ((cnt.y >> 31) == 0u) {
+            from_root = false;
+            sup_ncommon = cnt.x;
+            sup_nresid = cnt.y;
+        }
+    }
+    if (from_root) {
         // The root is an ancestor of every group (or the group itself): start from its children.
         const node_rec<F> *root = P.node_rec;
         const uint32_t r_nch = root->nch, r_a = root->a, r_b = root->b;
@@ -463,51 +486,76 @@ __global__ void __launch_bounds__(256, (sizeof(F) == 4 ? (R <= 2 ? RK_W12 : RK_W
     };
 
     // ---- list building, software-pipelined: while batch A is tested, the records of batch B load ----
-#if RK_PREFETCH_MIN < 1000
-    batch_t A, B;
-#else
-    batch_t A;
-#endif
-    int kA = pop_and_load(A, 0, true);
+    // Sources accepted for the whole supergroup: stream them from the pre-pass list through the tile.
+    {
+        const v4 *common = P.sup_common + static_cast<size_t>(sup_S) * SUP_CAPC;
+        for (uint32_t base = 0; base < sup_ncommon;) {
+            const uint32_t room = static_cast<uint32_t>(SRC_CAP - n_src), left = sup_ncommon - base;
+            const uint32_t take = left < room ? left : room;
+            for (uint32_t j = lane; j < take; j += 64u) {
+                L.src[n_src + static_cast<int>(j)] = common[base + j];
+            }
+            n_src += static_cast<int>(take);
+            base += take;
+            wave_sync();
+            if (n_src == SRC_CAP) {
+                flush();
+            }
+        }
+    }
+    // Candidates the pre-pass left to the member groups: taken 64 at a time whenever the stack runs empty.
+    auto resid_load = [&](batch_t &bt) __attribute__((always_inline)) -> int {
+        if (sup_rpos >= sup_nresid) {
+            return 0;
+        }
+        const uint32_t left = sup_nresid - sup_rpos, k = left < 64u ? left : 64u;
+        bt.active = static_cast<uint32_t>(lane) < k;
+        bt.rec = bt.active ? P.sup_resid[static_cast<size_t>(sup_S) * SUP_CAPR + sup_rpos + static_cast<uint32_t>(lane)] : 0u;
+        sup_rpos += k;
+        const node_rec<F> *rec = P.node_rec + bt.rec;
+        bt.com = rec->com;
+        bt.mp = rec->mac;
+        bt.node = rec->dfs;
+        bt.nch = rec->nch;
+        bt.ra = rec->a;
+        bt.rb = rec->b;
+        return 1;
+    };
+    auto next_batch = [&](batch_t &bt) __attribute__((always_inline)) -> int {
+        const int k = pop_and_load(bt, 0, true);
+        return k ? k : resid_load(bt);
+    };
+    // ---- list building ----
+    // Queues are settled BEFORE the next batch of records is fetched, so that no candidate registers are live
+    // across the dense phase (register pressure decides the occupancy of this kernel).
+    bool done = false;
     for (;;) {
-        // What comes next: an exact pass when 64 candidates are queued (or when nothing else is left),
-        // otherwise the first-stage test of batch A.
-        const bool finishing = kA == 0 && n_uq == 0;
-        const bool do_exact = n_uq >= 64 || (kA == 0 && n_uq > 0);
         // Room for the worst-case output of one pass (64 sources, 64 leaves); everything is settled at the end.
-        if (n_lq + 64 > LK_LQ_CAP || finishing) {
+        if (n_lq + 64 > LK_LQ_CAP || done) {
             drain_leaves();
         }
-        if (n_src + 64 > SRC_CAP || finishing) {
+        if (n_src + 64 > SRC_CAP || done) {
             flush();
         }
-        if (finishing) {
+        if (done) {
             break;
         }
-        if (do_exact) {
+        if (n_uq >= 64) {
             process_exact();
-            if (kA == 0) {
-                kA = pop_and_load(A, 0, true); // the exact pass may have opened new runs
-            }
             continue;
         }
         RK_STAMP(7)
-#if RK_PREFETCH_MIN < 1000
-        // Prefetch: pop the next batch from below A's future pushes (up to 8 entries per popped run) -- but only
-        // a full batch; a short stack is better refilled by A's pushes first (fewer, fuller rounds).
-        int kB = size >= RK_PREFETCH_MIN ? pop_and_load(B, 8 * kA, false) : 0;
-        process(A);
-        if (kB == 0) {
-            kB = pop_and_load(B, 0, true);
+        batch_t A;
+        if (next_batch(A) == 0) {
+            // Stack and residual list exhausted: settle the undecided candidates (they may open new runs).
+            if (n_uq > 0) {
+                process_exact();
+            } else {
+                done = true;
+            }
+            continue;
         }
-        A = B;
-        kA = kB;
-#else
-        // No software prefetch: with 6-7 resident waves per SIMD the hardware hides the record-load latency,
-        // and the registers of a second batch are better spent on occupancy.
         process(A);
-        kA = pop_and_load(A, 0, true);
-#endif
     }
 
     RK_STAMP(7)
@@ -573,11 +621,152 @@ __global__ void __launch_bounds__(256, (sizeof(F) == 4 ? (R <= 2 ? RK_W12 : RK_W
 }
 
 // ------------------------------------------------------------------------------------------------
+// Supergroup pre-pass. K consecutive target groups (a "supergroup" S) visit almost the same upper part of the
+// tree. One wavefront per S walks it once with tests that are valid for EVERY member group:
+//   * a node whose squared distance to the union of the members' bounding boxes exceeds mac_lh (with the 1e-5
+//     margin) passes the reference's criterion for every particle of every member  -> common source list;
+//   * a node whose FARTHEST box corner is still within mac_lh fails it for every particle -> opened here;
+//   * common strict ancestors of all members are opened here;
+//   * everything else (including nodes that contain some member) is left to the members: residual list.
+// Each member then streams the common list through its dense phase and starts its own list building from the
+// residual list. The per-group decisions, hence the interaction lists, are unchanged.
+// ------------------------------------------------------------------------------------------------
+constexpr int SUP_STACK_CAP = 512;
+
+template <typename F, int MAC>
+__global__ void __launch_bounds__(256) k_super(const kparams<F> P, uint32_t s_begin, uint32_t s_end)
+{
+    using v4 = typename vt<F>::v4;
+    using v2 = typename vt<F>::v2;
+    __shared__ uint32_t s_stack[4][SUP_STACK_CAP];
+    const int wib = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const uint32_t S = __builtin_amdgcn_readfirstlane(s_begin + blockIdx.x * 4u + static_cast<uint32_t>(wib));
+    if (S >= s_end) {
+        return;
+    }
+    uint32_t *stack = s_stack[wib];
+    const uint32_t K = P.super_k;
+    const uint32_t g0 = S * K, g1 = (g0 + K < P.n_crit) ? g0 + K : P.n_crit;
+    // Union of the members' boxes (wave-uniform after the reduction) and the depth-first span of the members.
+    F lo[3], hi[3];
+    {
+        const uint32_t gl = g0 + static_cast<uint32_t>(lane) < g1 ? g0 + static_cast<uint32_t>(lane) : g1 - 1u;
+        const v4 a = P.crit_box[2u * gl], b = P.crit_box[2u * gl + 1u];
+        lo[0] = a.x, lo[1] = a.y, lo[2] = a.z, hi[0] = b.x, hi[1] = b.y, hi[2] = b.z;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = rk_min(lo[k], __shfl_xor(lo[k], d, 64));
+                hi[k] = -rk_min(-hi[k], -__shfl_xor(hi[k], d, 64));
+            }
+        }
+    }
+    const uint32_t c_first = P.crit[g0].z, c_last = P.crit[g1 - 1u].z;
+    const uint32_t c_last_end = c_last + P.node_topo[c_last].x;
+    const F mac_value = P.mac_value;
+    v4 *common = P.sup_common + static_cast<size_t>(S) * SUP_CAPC;
+    uint32_t *resid = P.sup_resid + static_cast<size_t>(S) * SUP_CAPR;
+    uint32_t n_common = 0, n_resid = 0;
+    bool overflow = false;
+    int size = 0;
+    {
+        const node_rec<F> *root = P.node_rec;
+        const uint32_t r_nch = root->nch, r_a = root->a, r_b = root->b;
+        // c_first == 0: the root itself is the (only) target group; nothing to traverse.
+        if (c_first != 0u && r_nch != 0u) {
+            if (lane == 0) {
+                stack[0] = (r_a << 3) | (r_b - 1u);
+            }
+            size = 1;
+        }
+    }
+    wave_sync();
+    while (size > 0) {
+        if (n_common + 64u > SUP_CAPC || n_resid + 64u > SUP_CAPR) {
+            overflow = true;
+            break;
+        }
+        int k = size < 8 ? size : 8;
+        const int room = (SUP_STACK_CAP - LK_DFS_RESERVE - size) / 7;
+        if (room < k) {
+            k = room > 1 ? room : 1;
+        }
+        const int e_idx = lane >> 3, e_sub = lane & 7;
+        uint32_t entry = 0u;
+        if (e_idx < k) {
+            entry = stack[size - 1 - e_idx];
+        }
+        size -= k;
+        const bool active = e_idx < k && static_cast<uint32_t>(e_sub) <= (entry & 7u);
+        const uint32_t recidx = active ? (entry >> 3) + static_cast<uint32_t>(e_sub) : 0u;
+        const node_rec<F> *rec = P.node_rec + recidx;
+        const v4 com = rec->com;
+        const v2 mp = rec->mac;
+        const uint32_t dfs = rec->dfs, nch = rec->nch, ra = rec->a, rb = rec->b;
+        const F mac_lh = mac_lhs<F>(MAC, mp, mac_value);
+        // Relation of the node's subtree [dfs, dfs + nch] to the members' span [c_first, c_last_end].
+        const bool touches = dfs <= c_last_end && dfs + nch >= c_first;
+        const bool common_anc = dfs < c_first && dfs + nch >= c_last_end;
+        const F nx = rk_max3(lo[0] - com.x, com.x - hi[0], F(0)), ny = rk_max3(lo[1] - com.y, com.y - hi[1], F(0)),
+                nz = rk_max3(lo[2] - com.z, com.z - hi[2], F(0));
+        const F dnear2 = rk_fma(nz, nz, rk_fma(ny, ny, nx * nx));
+        const F fx = -rk_min(-(com.x - lo[0]), -(hi[0] - com.x)), fy = -rk_min(-(com.y - lo[1]), -(hi[1] - com.y)),
+                fz = -rk_min(-(com.z - lo[2]), -(hi[2] - com.z)); // distance to the farthest face per axis
+        const F dfar2 = rk_fma(fz, fz, rk_fma(fy, fy, fx * fx));
+        const bool acc_all = active && !touches && dnear2 > mac_lh * F(1.00001);
+        const bool open_all = active && ((touches && common_anc) || (!touches && !acc_all && dfar2 * F(1.00001) <= mac_lh))
+                              && nch != 0u;
+        const bool to_resid = active && !acc_all && !open_all;
+        const unsigned long long m_acc = __builtin_amdgcn_ballot_w64(acc_all);
+        if (acc_all) {
+            common[n_common + wave_prefix_count(m_acc)] = com;
+        }
+        n_common += static_cast<uint32_t>(__builtin_popcountll(m_acc));
+        const unsigned long long m_res = __builtin_amdgcn_ballot_w64(to_resid);
+        if (to_resid) {
+            resid[n_resid + wave_prefix_count(m_res)] = recidx;
+        }
+        n_resid += static_cast<uint32_t>(__builtin_popcountll(m_res));
+        const unsigned long long m_exp = __builtin_amdgcn_ballot_w64(open_all);
+        if (open_all) {
+            stack[size + static_cast<int>(wave_prefix_count(m_exp))] = (ra << 3) | (rb - 1u);
+        }
+        size += __builtin_popcountll(m_exp);
+        wave_sync();
+    }
+    if (lane == 0) {
+        P.sup_cnt[S] = make_uint2(n_common, n_resid | (overflow ? 0x80000000u : 0u));
+    }
+}
+
+template <typename F>
+void launch_super(const rk_state &s, const kparams<F> &p, int64_t s_begin, int64_t s_end, hipStream_t stream)
+{
+    const int64_t n = s_end - s_begin;
+    if (n <= 0 || !p.super_k) {
+        return;
+    }
+    const auto grid = static_cast<unsigned>((n + 3) / 4);
+    if (s.mac == RK_MAC_BH) {
+        hipLaunchKernelGGL((k_super<F, 0>), dim3(grid), dim3(256), 0, stream, p, static_cast<uint32_t>(s_begin),
+                           static_cast<uint32_t>(s_end));
+    } else {
+        hipLaunchKernelGGL((k_super<F, 1>), dim3(grid), dim3(256), 0, stream, p, static_cast<uint32_t>(s_begin),
+                           static_cast<uint32_t>(s_end));
+    }
+    RK_HIP(hipGetLastError());
+}
+template void launch_super<float>(const rk_state &, const kparams<float> &, int64_t, int64_t, hipStream_t);
+template void launch_super<double>(const rk_state &, const kparams<double> &, int64_t, int64_t, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------
 // Launch.
 // ------------------------------------------------------------------------------------------------
 template <typename F, int Q, int MAC>
 static void launch_list_qm(const rk_state &s, const kparams<F> &p, const int64_t cb[n_classes],
-                           const int64_t ce[n_classes], hipStream_t const streams[3])
+                           const int64_t ce[n_classes], hipStream_t const streams[n_list_R])
 {
     const auto *lists = static_cast<const uint32_t *>(s.buf[RK_BUF_CLASS]);
     auto go = [&](auto Rtag, int c) {
@@ -590,14 +779,17 @@ static void launch_list_qm(const rk_state &s, const kparams<F> &p, const int64_t
         hipLaunchKernelGGL((k_list<F, Q, MAC, R>), dim3(grid), dim3(256), 0, streams[c], p,
                            lists + s.class2_off[c] + cb[c], static_cast<int>(n));
     };
+    go(std::integral_constant<int, 5>{}, 4);
+    go(std::integral_constant<int, 3>{}, 2);
     go(std::integral_constant<int, 1>{}, 0);
     go(std::integral_constant<int, 2>{}, 1);
-    go(std::integral_constant<int, 4>{}, 2);
+    go(std::integral_constant<int, 6>{}, 5);
+    go(std::integral_constant<int, 4>{}, 3);
 }
 
 template <typename F>
 void launch_list(const rk_state &s, int q, const kparams<F> &p, const int64_t cb[n_classes],
-                 const int64_t ce[n_classes], hipStream_t const streams[3])
+                 const int64_t ce[n_classes], hipStream_t const streams[n_list_R])
 {
     switch (q * 2 + s.mac) {
         case 0: launch_list_qm<F, 0, 0>(s, p, cb, ce, streams); break;
@@ -612,8 +804,8 @@ void launch_list(const rk_state &s, int q, const kparams<F> &p, const int64_t cb
 }
 
 template void launch_list<float>(const rk_state &, int, const kparams<float> &, const int64_t[n_classes],
-                                 const int64_t[n_classes], hipStream_t const[3]);
+                                 const int64_t[n_classes], hipStream_t const[n_list_R]);
 template void launch_list<double>(const rk_state &, int, const kparams<double> &, const int64_t[n_classes],
-                                  const int64_t[n_classes], hipStream_t const[3]);
+                                  const int64_t[n_classes], hipStream_t const[n_list_R]);
 
 } // namespace rk

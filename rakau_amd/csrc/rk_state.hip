@@ -66,7 +66,7 @@ void free_state(rk_state *s)
     if (s->d_out) {
         (void)hipFree(s->d_out);
     }
-    for (void *b : {s->bld_codes, s->bld_perm, s->bld_node_code}) {
+    for (void *b : {s->bld_codes, s->bld_perm, s->bld_node_code, s->sup_common, s->sup_resid, s->sup_cnt}) {
         if (b) {
             (void)hipFree(b);
         }
@@ -80,7 +80,7 @@ void free_state(rk_state *s)
     if (s->ev_fork) {
         (void)hipEventDestroy(s->ev_fork);
     }
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < rk::n_list_R; ++i) {
         if (s->ev_join[i]) {
             (void)hipEventDestroy(s->ev_join[i]);
         }
@@ -451,11 +451,50 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
         RK_HIP(hipEventCreate(&s.ev1));
     }
     RK_HIP(hipEventRecord(s.ev0, stream));
+    p.super_k = 0;
+    p.n_crit = static_cast<uint32_t>(s.n_crit);
+    p.sup_common = nullptr;
+    p.sup_resid = nullptr;
+    p.sup_cnt = nullptr;
     if (v2) {
-        // The three per-class kernels are independent: fork them onto side streams so that the tail of one
+        // Supergroup pre-pass: K consecutive groups share the upper part of list building (0 disables).
+        if (s.super_k < 0) {
+            const char *e = std::getenv("RK_SUPER_K");
+            s.super_k = e ? std::atoi(e) : 16;
+            if (s.super_k < 0 || s.super_k > 64) {
+                s.super_k = 16;
+            }
+        }
+        if (s.super_k > 0 && s.n_crit > 0) {
+            const int64_t n_super = (s.n_crit + s.super_k - 1) / s.super_k;
+            if (s.sup_alloc < n_super) {
+                for (void **b : {&s.sup_common, &s.sup_resid, &s.sup_cnt}) {
+                    if (*b) {
+                        RK_HIP(hipFree(*b));
+                        *b = nullptr;
+                    }
+                }
+                s.sup_alloc = 0;
+                RK_HIP(hipMalloc(&s.sup_common, static_cast<size_t>(n_super) * rk::SUP_CAPC * sizeof(typename rk::vt<F>::v4)));
+                RK_HIP(hipMalloc(&s.sup_resid, static_cast<size_t>(n_super) * rk::SUP_CAPR * sizeof(uint32_t)));
+                RK_HIP(hipMalloc(&s.sup_cnt, static_cast<size_t>(n_super) * sizeof(uint2)));
+                s.sup_alloc = n_super;
+            }
+            p.super_k = static_cast<uint32_t>(s.super_k);
+            p.sup_common = static_cast<typename rk::vt<F>::v4 *>(s.sup_common);
+            p.sup_resid = static_cast<uint32_t *>(s.sup_resid);
+            p.sup_cnt = static_cast<uint2 *>(s.sup_cnt);
+            // Supergroups touched by the groups of [p_begin, p_end).
+            const auto g0 = std::lower_bound(s.crit_begin.begin(), s.crit_begin.end(), p_begin) - s.crit_begin.begin();
+            const auto g1 = std::lower_bound(s.crit_begin.begin(), s.crit_begin.end(), p_end) - s.crit_begin.begin();
+            if (g1 > g0) {
+                rk::launch_super<F>(s, p, g0 / s.super_k, (g1 - 1) / s.super_k + 1, stream);
+            }
+        }
+        // The per-class kernels are independent: fork them onto side streams so that the tail of one
         // overlaps the others, then join back into the caller's stream.
         if (!s.aux_stream[0]) {
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < rk::n_list_R - 1; ++i) {
                 RK_HIP(hipStreamCreateWithFlags(&s.aux_stream[i], hipStreamNonBlocking));
                 RK_HIP(hipEventCreateWithFlags(&s.ev_join[i], hipEventDisableTiming));
             }
@@ -468,18 +507,21 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
             const char *e = std::getenv("RK_SERIAL_CLASSES");
             return e && std::atoi(e) != 0;
         }();
-        const hipStream_t streams[3] = {serial ? stream : s.aux_stream[0], stream, serial ? stream : s.aux_stream[1]};
-        for (int i = 0; i < 2; ++i) {
+        hipStream_t streams[rk::n_list_R];
+        for (int i = 0; i < rk::n_list_R; ++i) {
+            streams[i] = (serial || i == 0) ? stream : s.aux_stream[i - 1];
+        }
+        for (int i = 0; i < rk::n_list_R - 1; ++i) {
             RK_HIP(hipStreamWaitEvent(s.aux_stream[i], s.ev_fork, 0));
         }
         rk::launch_list<F>(s, q, p, cb, ce, streams);
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < rk::n_list_R - 1; ++i) {
             RK_HIP(hipEventRecord(s.ev_join[i], s.aux_stream[i]));
             RK_HIP(hipStreamWaitEvent(stream, s.ev_join[i], 0));
         }
-        // Groups beyond 256 particles are served by the block-per-group kernel.
-        rk::launch_block<F>(s, q, p, static_cast<const uint32_t *>(s.buf[RK_BUF_CLASS]) + s.class2_off[4] + cb[4],
-                            ce[4] - cb[4], stream);
+        // Groups too large for the wave kernels are served by the block-per-group kernel.
+        rk::launch_block<F>(s, q, p, static_cast<const uint32_t *>(s.buf[RK_BUF_CLASS]) + s.class2_off[rk::big_class] + cb[rk::big_class],
+                            ce[rk::big_class] - cb[rk::big_class], stream);
     } else {
         rk::launch_traversal<F>(s, q, p, cb, ce, stream);
     }

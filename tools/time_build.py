@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rakau_amd
 from bench import plummer_numpy
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
