@@ -168,6 +168,16 @@ struct rk_state {
     // Side streams (and fork/join events) that let the per-class kernels of one call overlap.
     hipStream_t aux_stream[rk::n_list_R] = {};
     hipEvent_t ev_fork = nullptr, ev_join[rk::n_list_R] = {};
+    // hipGraph of the launch sequence of the last call (replayed when a call repeats it).
+    struct graph_key {
+        int q, offset_output, super_k, pad;
+        int64_t p_begin, p_end;
+        double mac_value, G, eps2;
+        void *out[4];
+    };
+    graph_key gkey{};
+    hipGraphExec_t graph_exec = nullptr;
+    hipStream_t cap_stream = nullptr;
     bool timed = false;
     int variant = 0;
     // Scratch of the supergroup pre-pass (allocated on first use).

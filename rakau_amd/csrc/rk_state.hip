@@ -80,6 +80,12 @@ void free_state(rk_state *s)
     if (s->ev_fork) {
         (void)hipEventDestroy(s->ev_fork);
     }
+    if (s->graph_exec) {
+        (void)hipGraphExecDestroy(s->graph_exec);
+    }
+    if (s->cap_stream) {
+        (void)hipStreamDestroy(s->cap_stream);
+    }
     for (int i = 0; i < rk::n_list_R; ++i) {
         if (s->ev_join[i]) {
             (void)hipEventDestroy(s->ev_join[i]);
@@ -484,44 +490,93 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
             p.sup_common = static_cast<typename rk::vt<F>::v4 *>(s.sup_common);
             p.sup_resid = static_cast<uint32_t *>(s.sup_resid);
             p.sup_cnt = static_cast<uint2 *>(s.sup_cnt);
-            // Supergroups touched by the groups of [p_begin, p_end).
-            const auto g0 = std::lower_bound(s.crit_begin.begin(), s.crit_begin.end(), p_begin) - s.crit_begin.begin();
-            const auto g1 = std::lower_bound(s.crit_begin.begin(), s.crit_begin.end(), p_end) - s.crit_begin.begin();
-            if (g1 > g0) {
-                rk::launch_super<F>(s, p, g0 / s.super_k, (g1 - 1) / s.super_k + 1, stream);
-            }
         }
-        // The per-class kernels are independent: fork them onto side streams so that the tail of one
-        // overlaps the others, then join back into the caller's stream.
+        // Side streams / events of the fork-join (created once, outside any capture).
         if (!s.aux_stream[0]) {
             for (int i = 0; i < rk::n_list_R - 1; ++i) {
                 RK_HIP(hipStreamCreateWithFlags(&s.aux_stream[i], hipStreamNonBlocking));
                 RK_HIP(hipEventCreateWithFlags(&s.ev_join[i], hipEventDisableTiming));
             }
             RK_HIP(hipEventCreateWithFlags(&s.ev_fork, hipEventDisableTiming));
+            RK_HIP(hipStreamCreateWithFlags(&s.cap_stream, hipStreamNonBlocking));
         }
-        RK_HIP(hipEventRecord(s.ev_fork, stream));
-        // RK_SERIAL_CLASSES=1 keeps the class kernels on the caller's stream (one after the other), which
-        // gives per-kernel durations in a profile that add up to the step time.
         static const bool serial = [] {
+            // RK_SERIAL_CLASSES=1 keeps the class kernels on one stream (one after the other), which gives
+            // per-kernel durations in a profile that add up to the step time.
             const char *e = std::getenv("RK_SERIAL_CLASSES");
             return e && std::atoi(e) != 0;
         }();
-        hipStream_t streams[rk::n_list_R];
-        for (int i = 0; i < rk::n_list_R; ++i) {
-            streams[i] = (serial || i == 0) ? stream : s.aux_stream[i - 1];
+        static const bool use_graph = [] {
+            const char *e = std::getenv("RK_GRAPH"); // 0 disables the hipGraph replay of a repeated call
+            return !(e && std::atoi(e) == 0);
+        }();
+        const int64_t g_lo = std::lower_bound(s.crit_begin.begin(), s.crit_begin.end(), p_begin) - s.crit_begin.begin();
+        const int64_t g_hi = std::lower_bound(s.crit_begin.begin(), s.crit_begin.end(), p_end) - s.crit_begin.begin();
+        // The launch sequence of one call: pre-pass, then the per-class kernels forked onto side streams (so that
+        // the tail of one overlaps the others), joined back, then the big-group fallback. Stream-ordered work only,
+        // so it can be recorded into a hipGraph.
+        auto enqueue = [&](hipStream_t st) {
+            if (p.super_k && g_hi > g_lo) {
+                rk::launch_super<F>(s, p, g_lo / s.super_k, (g_hi - 1) / s.super_k + 1, st);
+            }
+            hipStream_t streams[rk::n_list_R];
+            for (int i = 0; i < rk::n_list_R; ++i) {
+                streams[i] = (serial || i == 0) ? st : s.aux_stream[i - 1];
+            }
+            if (!serial) {
+                RK_HIP(hipEventRecord(s.ev_fork, st));
+                for (int i = 0; i < rk::n_list_R - 1; ++i) {
+                    RK_HIP(hipStreamWaitEvent(s.aux_stream[i], s.ev_fork, 0));
+                }
+            }
+            rk::launch_list<F>(s, q, p, cb, ce, streams);
+            if (!serial) {
+                for (int i = 0; i < rk::n_list_R - 1; ++i) {
+                    RK_HIP(hipEventRecord(s.ev_join[i], s.aux_stream[i]));
+                    RK_HIP(hipStreamWaitEvent(st, s.ev_join[i], 0));
+                }
+            }
+            // Groups too large for the wave kernels are served by the block-per-group kernel.
+            rk::launch_block<F>(s, q, p,
+                                static_cast<const uint32_t *>(s.buf[RK_BUF_CLASS]) + s.class2_off[rk::big_class]
+                                    + cb[rk::big_class],
+                                ce[rk::big_class] - cb[rk::big_class], st);
+        };
+        if (use_graph) {
+            // A call that repeats the previous one (same range, outputs, parameters) replays a captured graph:
+            // one hipGraphLaunch instead of ~20 runtime calls.
+            rk_state::graph_key key{};
+            key.q = q, key.p_begin = p_begin, key.p_end = p_end, key.mac_value = mac_value, key.G = G, key.eps2 = eps2;
+            key.offset_output = offset_output, key.super_k = s.super_k;
+            for (int k = 0; k < rk::nres_of(q); ++k) {
+                key.out[k] = d_out[k];
+            }
+            if (!s.graph_exec || std::memcmp(&key, &s.gkey, sizeof(key)) != 0) {
+                if (s.graph_exec) {
+                    RK_HIP(hipGraphExecDestroy(s.graph_exec));
+                    s.graph_exec = nullptr;
+                }
+                hipGraph_t graph = nullptr;
+                RK_HIP(hipStreamBeginCapture(s.cap_stream, hipStreamCaptureModeThreadLocal));
+                try {
+                    enqueue(s.cap_stream);
+                } catch (...) {
+                    (void)hipStreamEndCapture(s.cap_stream, &graph);
+                    if (graph) {
+                        (void)hipGraphDestroy(graph);
+                    }
+                    throw;
+                }
+                RK_HIP(hipStreamEndCapture(s.cap_stream, &graph));
+                const hipError_t ie = hipGraphInstantiate(&s.graph_exec, graph, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(graph);
+                RK_HIP(ie);
+                s.gkey = key;
+            }
+            RK_HIP(hipGraphLaunch(s.graph_exec, stream));
+        } else {
+            enqueue(stream);
         }
-        for (int i = 0; i < rk::n_list_R - 1; ++i) {
-            RK_HIP(hipStreamWaitEvent(s.aux_stream[i], s.ev_fork, 0));
-        }
-        rk::launch_list<F>(s, q, p, cb, ce, streams);
-        for (int i = 0; i < rk::n_list_R - 1; ++i) {
-            RK_HIP(hipEventRecord(s.ev_join[i], s.aux_stream[i]));
-            RK_HIP(hipStreamWaitEvent(stream, s.ev_join[i], 0));
-        }
-        // Groups too large for the wave kernels are served by the block-per-group kernel.
-        rk::launch_block<F>(s, q, p, static_cast<const uint32_t *>(s.buf[RK_BUF_CLASS]) + s.class2_off[rk::big_class] + cb[rk::big_class],
-                            ce[rk::big_class] - cb[rk::big_class], stream);
     } else {
         rk::launch_traversal<F>(s, q, p, cb, ce, stream);
     }
