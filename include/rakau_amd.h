@@ -43,6 +43,8 @@ extern "C" {
 enum { RK_F32 = 0, RK_F64 = 1 };
 /* Multipole acceptance criterion (rakau::mac, include/rakau/detail/tree_fwd.hpp:46). */
 enum { RK_MAC_BH = 0, RK_MAC_BH_GEOM = 1 };
+/* Output addressing flags of rk_acc_pot / rk_acc_pot_device. */
+enum { RK_OUT_COMPACT = 0, RK_OUT_OFFSET = 1, RK_OUT_ORDERED = 2 };
 /* Status codes; the C++ header rethrows them as the exception types listed. */
 enum {
     RK_OK = 0,
@@ -108,9 +110,12 @@ RK_EXPORT int rk_state_crit_ranges(const rk_state *s, int64_t *begin_end);
  *  mac_value      theta^-2 (bh) or theta^-1 (bh_geom), as computed at tree.hpp:3303-3312.
  *  G              gravitational constant, applied as the final multiply (tree.hpp:2986-3002).
  *  eps2           square of the softening length (tree.hpp:3268-3281).
- *  offset_output  nonzero: out[j] addresses element 0 of a full-size array and results are written
- *                 at out[j] + p_begin; zero: out[j] is a compact array of p_end - p_begin values
+ *  offset_output  bit 0 (RK_OUT_OFFSET): out[j] addresses element 0 of a full-size array and results are written
+ *                 at out[j] + p_begin; clear: out[j] is a compact array of p_end - p_begin values
  *                 (same meaning as in src/rakau_rocm.cpp:114-116).
+ *                 bit 1 (RK_OUT_ORDERED, rk_acc_pot_device only): original-order output -- the result of the
+ *                 particle at Morton position i goes to out[j][perm[i]] (the accs_o/pots_o scatter of
+ *                 tree.hpp:3320-3330 done in the kernel epilogue); out[j] are full-size arrays.
  */
 RK_EXPORT int rk_acc_pot(rk_state *s, int q, int64_t p_begin, int64_t p_end, void *const *out, double mac_value,
                          double G, double eps2, int offset_output);
@@ -156,6 +161,28 @@ RK_EXPORT int rk_state_import(rk_state **out, int device, int count, void *const
  */
 RK_EXPORT int rk_state_build(rk_state **out, int fp, int mac, int device, const void *const parts[4], int64_t nparts,
                              double box_size, uint64_t max_leaf_n, uint64_t ncrit);
+
+/* Same, with x, y, z, m already resident on `device` (DEVICE pointers): no host transfer at all. */
+RK_EXPORT int rk_state_build_device(rk_state **out, int fp, int mac, int device, const void *const d_parts[4],
+                                    int64_t nparts, double box_size, uint64_t max_leaf_n, uint64_t ncrit);
+
+/* Rebuild the tree of an existing state in place from new device-resident particles (tree::update_particles_u(),
+ * tree.hpp:3560-3640 of the reference: the particles moved, sort again and rebuild). fp, mac, max_leaf_n and ncrit
+ * are kept; streams, events and scratch are reused and device memory is recycled through the library's block cache,
+ * so a time-stepping loop rebuilds without touching the driver allocator. box_size 0 = deduce again. After a
+ * failure the state is empty (nparts 0) but valid. */
+RK_EXPORT int rk_state_rebuild_device(rk_state *s, const void *const d_parts[4], int64_t nparts, double box_size);
+
+/* Return the blocks cached by the library's device allocator to the driver (all devices). */
+RK_EXPORT void rk_pool_trim(void);
+
+/* Give a state created from a host tree the permutation tree::perm() (host array of nparts uint64), which the
+ * original-order output mode needs. States built on the device have it already. */
+RK_EXPORT int rk_state_set_perm(rk_state *s, const uint64_t *perm);
+
+/* Device address and size of a resident array: 0 = particles {x, y, z, m} in Morton order, 1 = perm (uint32),
+ * 2 = sorted Morton codes (uint64). For callers that keep their own data on the GPU (gather / scatter). */
+RK_EXPORT int rk_state_device_ptr(const rk_state *s, int what, void **ptr, int64_t *bytes);
 
 /* *box_size = domain size; info[0..3] = box deduced, max_leaf_n, built on device (0/1), number of internal nodes. */
 RK_EXPORT int rk_state_tree_info(const rk_state *s, double *box_size, int64_t info[4]);

@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("RAKAU_AMD_LIB") or os.path.join(_HERE, "lib", "librak
 
 RK_F32, RK_F64 = 0, 1
 RK_MAC_BH, RK_MAC_BH_GEOM = 0, 1
+RK_OUT_COMPACT, RK_OUT_OFFSET, RK_OUT_ORDERED = 0, 1, 2
 RK_MAX_BUFFERS, RK_META_WORDS = 16, 32
 
 # Status code -> Python exception mirroring the C++ exception types of the reference
@@ -23,13 +24,38 @@ SYMBOLS = [
     "rk_last_error", "rk_min_size", "rk_has_accelerator", "rk_device_count", "rk_state_create", "rk_state_destroy",
     "rk_state_info", "rk_state_crit_ranges", "rk_acc_pot", "rk_acc_pot_device", "rk_last_kernel_ms", "rk_state_export",
     "rk_state_import", "rk_set_kernel_variant", "rk_device_memcpy", "rk_count_interactions", "rk_state_build",
-    "rk_state_tree_info", "rk_state_download",
+    "rk_state_tree_info", "rk_state_download", "rk_state_build_device", "rk_state_set_perm", "rk_state_device_ptr",
+    "rk_state_rebuild_device", "rk_pool_trim",
     # host-side tree builder (include/rakau_amd_tree.h)
     "rk_tree_create", "rk_tree_destroy", "rk_tree_info", "rk_tree_get", "rk_tree_nodes", "rk_tree_state",
     "rk_tree_acc_pot", "rk_tree_exact", "rk_tree_update_particles",
 ]
 
 _lib = None
+
+
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process. PyTorch-ROCm wheels bundle their own libamdhip64.so / libhsa-runtime64.so (same
+    sonames as /opt/rocm's, requested by torch under the unversioned file names). If librakau_amd.so pulls in the system
+    runtime first, a later `import torch` maps a SECOND runtime and its device initialisation fails ("No HIP GPUs are
+    available"); loaded in the other order the dynamic linker resolves our libamdhip64.so.7 to torch's copy and both
+    share it. So when a torch with bundled runtime is installed (and not yet imported), map its runtime first -- without
+    importing torch. RAKAU_AMD_SYSTEM_HIP=1 opts out."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("RAKAU_AMD_SYSTEM_HIP"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
 
 
 def lib():
@@ -40,6 +66,7 @@ def lib():
         raise ImportError(
             "rakau_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C rakau_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     vp, i64, u64, dbl, ci = C.c_void_p, C.c_int64, C.c_uint64, C.c_double, C.c_int
     L.rk_last_error.restype = C.c_char_p
@@ -60,6 +87,12 @@ def lib():
     L.rk_state_build.argtypes = [C.POINTER(vp), ci, ci, ci, C.POINTER(vp), i64, dbl, u64, u64]
     L.rk_state_tree_info.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64)]
     L.rk_state_download.argtypes = [vp, ci, vp]
+    L.rk_state_build_device.argtypes = [C.POINTER(vp), ci, ci, ci, C.POINTER(vp), i64, dbl, u64, u64]
+    L.rk_state_set_perm.argtypes = [vp, vp]
+    L.rk_state_rebuild_device.argtypes = [vp, C.POINTER(vp), i64, dbl]
+    L.rk_pool_trim.argtypes = []
+    L.rk_pool_trim.restype = None
+    L.rk_state_device_ptr.argtypes = [vp, ci, C.POINTER(vp), C.POINTER(i64)]
     if hasattr(L, "rk_tree_create"):
         L.rk_tree_create.argtypes = [C.POINTER(vp), ci, ci, vp, vp, vp, vp, i64, dbl, u64, u64, ci]
         L.rk_tree_destroy.argtypes = [vp]

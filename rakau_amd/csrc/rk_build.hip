@@ -74,9 +74,6 @@ __global__ void k_maxabs(const F *x, const F *y, const F *z, uint32_t n, unsigne
         bad |= !(isfinite(a) && isfinite(b) && isfinite(c));
         mx = fmax(mx, fmax(a, fmax(b, c)));
     }
-    if (bad) {
-        atomicOr(err, 1);
-    }
     // Non-negative IEEE values order like their bit patterns.
     unsigned long long bits;
     if constexpr (sizeof(F) == 4) {
@@ -84,7 +81,19 @@ __global__ void k_maxabs(const F *x, const F *y, const F *z, uint32_t n, unsigne
     } else {
         bits = static_cast<unsigned long long>(__double_as_longlong(static_cast<double>(mx)));
     }
-    atomicMax(out_bits, bits);
+    // One atomic per wavefront.
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(bits, o, 64);
+        bits = other > bits ? other : bits;
+    }
+    const bool any_bad = __ballot(bad) != 0ull;
+    if ((threadIdx.x & 63u) == 0u) {
+        if (any_bad) {
+            atomicOr(err, 1);
+        }
+        atomicMax(out_bits, bits);
+    }
 }
 
 // ---- discretise + encode ----------------------------------------------------------------------------------
@@ -160,8 +169,15 @@ __device__ inline void narrow(const uint64_t *codes, uint32_t i, unsigned lvl, u
     hi = a;
 }
 
-__global__ void k_leaf_levels(const uint64_t *codes, uint32_t n, uint32_t max_leaf_n, uint8_t *leaf, uint8_t *ldiv,
-                              uint32_t *cnt)
+// Number of leading 3-bit digits (levels) two codes share: 0..CBITS. Codes use bits 0..62.
+__device__ inline unsigned common_levels(uint64_t a, uint64_t b)
+{
+    const uint64_t xr = a ^ b;
+    return xr ? (static_cast<unsigned>(__clzll(static_cast<long long>(xr))) - 1u) / 3u : CBITS;
+}
+
+// Depth of the leaf holding each particle, by search (any max_leaf_n): descend while the cell holds too many.
+__global__ void k_leaf_levels_search(const uint64_t *codes, uint32_t n, uint32_t max_leaf_n, uint8_t *leaf)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) {
@@ -173,21 +189,53 @@ __global__ void k_leaf_levels(const uint64_t *codes, uint32_t n, uint32_t max_le
         ++lvl;
         narrow(codes, i, lvl, lo, hi);
     }
-    unsigned dv = 1;
-    if (i > 0) {
-        const uint64_t xr = codes[i - 1] ^ codes[i];
-        // Codes use bits 0..62: common leading 3-bit digits = (clz - 1) / 3; identical codes never start a node.
-        dv = xr ? 1u + (static_cast<unsigned>(__clzll(static_cast<long long>(xr))) - 1u) / 3u : CBITS + 1u;
-    }
     leaf[i] = static_cast<uint8_t>(lvl);
+}
+
+// Same result without searching, for small max_leaf_n = m: the level-L cell of particle i holds more than m
+// particles iff some window of m + 1 consecutive (sorted) particles containing i shares its first L digits, so
+//   leaf(i) = min(CBITS, 1 + max_{j in [i-m, i], j+m < n} common_levels(c[j], c[j+m]))      (0 without windows).
+// win[j] = common_levels(c[j], c[j+m]) + 1 for a valid window, 0 otherwise.
+__global__ void k_windows(const uint64_t *codes, uint32_t n, uint32_t m, uint8_t *win)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) {
+        return;
+    }
+    win[j] = (m < n && j < n - m) ? static_cast<uint8_t>(common_levels(codes[j], codes[j + m]) + 1u) : uint8_t(0);
+}
+__global__ void k_leaf_levels_windows(const uint8_t *win, uint32_t n, uint32_t m, uint8_t *leaf)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    unsigned best = 0;
+    for (uint32_t j = i >= m ? i - m : 0u; j <= i; ++j) {
+        best = max(best, static_cast<unsigned>(win[j]));
+    }
+    leaf[i] = static_cast<uint8_t>(min(best, CBITS));
+}
+
+// ldiv[i] = first level at which c[i] leaves the cell of c[i-1]; cnt[i] = number of nodes whose first particle is i.
+__global__ void k_node_counts(const uint64_t *codes, uint32_t n, const uint8_t *leaf, uint8_t *ldiv, uint32_t *cnt)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    // Identical codes never start a node.
+    const unsigned dv = i > 0 ? common_levels(codes[i - 1], codes[i]) + 1u : 1u;
+    const unsigned lvl = leaf[i];
     ldiv[i] = static_cast<uint8_t>(dv);
     cnt[i] = dv <= lvl ? lvl - dv + 1u : 0u;
 }
 
 // Emit the nodes whose first particle is i. off[] = exclusive scan of cnt[] (off[n] = number of non-root nodes).
-__global__ void k_emit_nodes(const uint64_t *codes, uint32_t n, uint32_t max_leaf_n, const uint8_t *leaf,
-                             const uint8_t *ldiv, const uint32_t *off, uint4 *topo, uint64_t *ncode,
-                             uint32_t *parent)
+// The nodes starting at i are nested (levels ldiv(i)..leaf(i)); their ends are found deepest first by galloping
+// from the end of the child, so a leaf of a dozen particles costs a handful of probes.
+__global__ void k_emit_nodes(const uint64_t *codes, uint32_t n, const uint8_t *leaf, const uint8_t *ldiv,
+                             const uint32_t *off, uint4 *topo, uint64_t *ncode, uint32_t *parent)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) {
@@ -202,17 +250,52 @@ __global__ void k_emit_nodes(const uint64_t *codes, uint32_t n, uint32_t max_lea
     if (dv > lf) {
         return;
     }
-    uint32_t lo = 0, hi = n, plo = 0; // plo: first particle of the parent node
-    for (unsigned lvl = 1; lvl <= lf; ++lvl) {
-        plo = lo;
-        narrow(codes, i, lvl, lo, hi);
-        if (lvl >= dv) {
-            const uint32_t dfs = 1u + off[i] + (lvl - dv);
-            const uint32_t next = 1u + off[hi]; // depth-first index of the first node starting at or after hi
-            topo[dfs] = make_uint4(next - dfs - 1u, i, hi, 0u);
-            ncode[dfs] = (1ull << (3u * lvl)) | (codes[i] >> (3u * (CBITS - lvl)));
-            parent[dfs] = lvl == 1u ? 0u : 1u + off[plo] + (lvl - 1u - ldiv[plo]);
+    const uint64_t ci = codes[i];
+    const uint32_t base_dfs = 1u + off[i];
+    uint32_t hi = i + 1u; // every particle in [i, hi) is known to lie in the current node
+    for (unsigned lvl = lf; lvl >= dv; --lvl) {
+        const unsigned shift = 3u * (CBITS - lvl);
+        const uint64_t p = ci >> shift;
+        // Smallest j >= hi with j == n or a different level-lvl prefix.
+        uint32_t a = hi, b, step = 1u;
+        for (;;) {
+            b = a + (step - 1u);
+            if (b >= n || b < a) {
+                b = n;
+                break;
+            }
+            if ((codes[b] >> shift) != p) {
+                break;
+            }
+            a = b + 1u;
+            step <<= 1;
         }
+        while (a < b) {
+            const uint32_t mid = a + (b - a) / 2u;
+            if ((codes[mid] >> shift) == p) {
+                a = mid + 1u;
+            } else {
+                b = mid;
+            }
+        }
+        hi = a;
+        const uint32_t dfs = base_dfs + (lvl - dv);
+        const uint32_t next = 1u + off[hi]; // depth-first index of the first node starting at or after hi
+        topo[dfs] = make_uint4(next - dfs - 1u, i, hi, 0u);
+        ncode[dfs] = (1ull << (3u * lvl)) | p;
+    }
+}
+
+// parent[] of every non-root node, written by the parent (children of k: k + 1, then skipping subtrees).
+__global__ void k_parents(const uint4 *topo, uint32_t n_nodes, uint32_t *parent)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_nodes) {
+        return;
+    }
+    const uint32_t last = k + topo[k].x;
+    for (uint32_t c = k + 1u; c <= last; c += topo[c].x + 1u) {
+        parent[c] = k;
     }
 }
 
@@ -403,7 +486,7 @@ struct dev_free {
     void operator()(void *p) const
     {
         if (p) {
-            (void)hipFree(p);
+            pool_free(p);
         }
     }
 };
@@ -412,9 +495,7 @@ using dptr = std::unique_ptr<T, dev_free>;
 template <typename T>
 dptr<T> dalloc(size_t count)
 {
-    void *p = nullptr;
-    RK_HIP(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
-    return dptr<T>(static_cast<T *>(p));
+    return dptr<T>(static_cast<T *>(pool_alloc(std::max<size_t>(count, 1) * sizeof(T))));
 }
 
 inline unsigned nblk(size_t n, unsigned bs = 256)
@@ -438,8 +519,8 @@ void exclusive_scan(const uint32_t *in, uint32_t *out, size_t n, hipStream_t st)
 
 // Builds the tree and fills `s` (buffers, sizes). Host inputs in the caller's original order.
 template <typename F>
-void build_device(rk_state &s, const void *const parts[4], int64_t nparts, double box_size_in, uint64_t max_leaf_n,
-                  std::string &bad_coord_msg)
+void build_device(rk_state &s, const void *const parts[4], bool parts_on_device, int64_t nparts, double box_size_in,
+                  uint64_t max_leaf_n, std::string &bad_coord_msg)
 {
     using namespace bld;
     using v4 = typename vt<F>::v4;
@@ -448,11 +529,26 @@ void build_device(rk_state &s, const void *const parts[4], int64_t nparts, doubl
     const auto n = static_cast<uint32_t>(nparts);
     const size_t fb = static_cast<size_t>(n) * sizeof(F);
 
-    auto dx = dalloc<F>(n), dy = dalloc<F>(n), dz = dalloc<F>(n), dm = dalloc<F>(n);
-    RK_HIP(hipMemcpyAsync(dx.get(), parts[0], fb, hipMemcpyHostToDevice, st));
-    RK_HIP(hipMemcpyAsync(dy.get(), parts[1], fb, hipMemcpyHostToDevice, st));
-    RK_HIP(hipMemcpyAsync(dz.get(), parts[2], fb, hipMemcpyHostToDevice, st));
-    RK_HIP(hipMemcpyAsync(dm.get(), parts[3], fb, hipMemcpyHostToDevice, st));
+    // Inputs: copied from the host, or used in place when they already live on this device.
+    dptr<F> own[4];
+    const F *in[4];
+    for (int k = 0; k < 4; ++k) {
+        if (parts_on_device) {
+            in[k] = static_cast<const F *>(parts[k]);
+        } else {
+            own[k] = dalloc<F>(n);
+            RK_HIP(hipMemcpyAsync(own[k].get(), parts[k], fb, hipMemcpyHostToDevice, st));
+            in[k] = own[k].get();
+        }
+    }
+    struct view {
+        const F *p;
+        const F *get() const
+        {
+            return p;
+        }
+    };
+    const view dx{in[0]}, dy{in[1]}, dz{in[2]}, dm{in[3]};
 
     auto d_err = dalloc<int>(1);
     auto d_bits = dalloc<unsigned long long>(1);
@@ -503,7 +599,8 @@ void build_device(rk_state &s, const void *const parts[4], int64_t nparts, doubl
     if (first_bad != 0xffffffffu) {
         // Rebuild the reference's message (tree.hpp:398-413) for the first offending coordinate.
         for (int k = 0; k < 3; ++k) {
-            const F xv = static_cast<const F *>(parts[k])[first_bad];
+            F xv;
+            RK_HIP(hipMemcpy(&xv, in[k] + first_bad, sizeof(F), hipMemcpyDeviceToHost));
             F tmp = std::fma(xv, inv_box, F(1) / F(2));
             tmp *= F(1u << CBITS);
             if (!std::isfinite(tmp)) {
@@ -535,14 +632,15 @@ void build_device(rk_state &s, const void *const parts[4], int64_t nparts, doubl
     vals_in.reset();
 
     // ---- particles in Morton order ----
-    void *p4 = nullptr;
-    RK_HIP(hipMalloc(&p4, std::max<size_t>(n, 1) * sizeof(v4)));
+    void *p4 = pool_alloc(std::max<size_t>(n, 1) * sizeof(v4));
     s.buf[RK_BUF_PART4] = p4;
     s.buf_bytes[RK_BUF_PART4] = static_cast<int64_t>(n * sizeof(v4));
     hipLaunchKernelGGL((k_permute<F>), dim3(nblk(n)), dim3(256), 0, st, dx.get(), dy.get(), dz.get(), dm.get(),
                        vals_out.get(), n, static_cast<v4 *>(p4));
     RK_HIP(hipStreamSynchronize(st));
-    dx.reset(), dy.reset(), dz.reset(), dm.reset();
+    for (auto &o : own) {
+        o.reset();
+    }
     s.bld_codes = keys_out.release();
     s.bld_perm = vals_out.release();
     const auto *codes = static_cast<const uint64_t *>(s.bld_codes);
@@ -552,7 +650,14 @@ void build_device(rk_state &s, const void *const parts[4], int64_t nparts, doubl
     auto leaf = dalloc<uint8_t>(n), ldiv = dalloc<uint8_t>(n);
     auto cnt = dalloc<uint32_t>(static_cast<size_t>(n) + 1), off = dalloc<uint32_t>(static_cast<size_t>(n) + 1);
     RK_HIP(hipMemsetAsync(cnt.get() + n, 0, sizeof(uint32_t), st));
-    hipLaunchKernelGGL(k_leaf_levels, dim3(nblk(n)), dim3(256), 0, st, codes, n, mln, leaf.get(), ldiv.get(), cnt.get());
+    if (mln <= 64u) {
+        // ldiv doubles as the window scratch until k_node_counts fills it.
+        hipLaunchKernelGGL(k_windows, dim3(nblk(n)), dim3(256), 0, st, codes, n, mln, ldiv.get());
+        hipLaunchKernelGGL(k_leaf_levels_windows, dim3(nblk(n)), dim3(256), 0, st, ldiv.get(), n, mln, leaf.get());
+    } else {
+        hipLaunchKernelGGL(k_leaf_levels_search, dim3(nblk(n)), dim3(256), 0, st, codes, n, mln, leaf.get());
+    }
+    hipLaunchKernelGGL(k_node_counts, dim3(nblk(n)), dim3(256), 0, st, codes, n, leaf.get(), ldiv.get(), cnt.get());
     exclusive_scan(cnt.get(), off.get(), n, st);
     uint32_t n_nonroot = 0;
     RK_HIP(hipMemcpy(&n_nonroot, off.get() + n, sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -563,7 +668,7 @@ void build_device(rk_state &s, const void *const parts[4], int64_t nparts, doubl
     }
     s.tree_size = static_cast<int64_t>(nn);
     auto alloc_buf = [&](int which, size_t bytes) {
-        RK_HIP(hipMalloc(&s.buf[which], std::max<size_t>(bytes, 16)));
+        s.buf[which] = pool_alloc(std::max<size_t>(bytes, 16));
         s.buf_bytes[which] = static_cast<int64_t>(bytes);
         return s.buf[which];
     };
@@ -571,11 +676,12 @@ void build_device(rk_state &s, const void *const parts[4], int64_t nparts, doubl
     auto *node_com = static_cast<v4 *>(alloc_buf(RK_BUF_NODE_COM, nn * sizeof(v4)));
     auto *node_mac = static_cast<v2 *>(alloc_buf(RK_BUF_NODE_MAC, nn * sizeof(v2)));
     auto *recs = static_cast<node_rec<F> *>(alloc_buf(RK_BUF_NODE_REC, nn * sizeof(node_rec<F>)));
-    RK_HIP(hipMalloc(&s.bld_node_code, nn * sizeof(uint64_t)));
+    s.bld_node_code = pool_alloc(nn * sizeof(uint64_t));
     auto *ncode = static_cast<uint64_t *>(s.bld_node_code);
     auto parent = dalloc<uint32_t>(nn);
-    hipLaunchKernelGGL(k_emit_nodes, dim3(nblk(n)), dim3(256), 0, st, codes, n, mln, leaf.get(), ldiv.get(), off.get(), topo,
+    hipLaunchKernelGGL(k_emit_nodes, dim3(nblk(n)), dim3(256), 0, st, codes, n, leaf.get(), ldiv.get(), off.get(), topo,
                        ncode, parent.get());
+    hipLaunchKernelGGL(k_parents, dim3(nblk(nn)), dim3(256), 0, st, topo, static_cast<uint32_t>(nn), parent.get());
     leaf.reset(), ldiv.reset(), cnt.reset(), off.reset();
 
     // ---- node properties ----
@@ -635,7 +741,7 @@ void build_device(rk_state &s, const void *const parts[4], int64_t nparts, doubl
     RK_HIP(hipGetLastError());
 }
 
-template void build_device<float>(rk_state &, const void *const[4], int64_t, double, uint64_t, std::string &);
-template void build_device<double>(rk_state &, const void *const[4], int64_t, double, uint64_t, std::string &);
+template void build_device<float>(rk_state &, const void *const[4], bool, int64_t, double, uint64_t, std::string &);
+template void build_device<double>(rk_state &, const void *const[4], bool, int64_t, double, uint64_t, std::string &);
 
 } // namespace rk

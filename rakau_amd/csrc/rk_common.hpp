@@ -65,7 +65,7 @@ inline int class_of(int64_t size)
 // Variant 2 (LDS interaction lists): each lane holds R targets, TP = ceil(T / R) target slots and
 // NS = floor(64 / TP) source splits share the wave. The dense phase costs R / NS lane-iterations per
 // source; pick the R that minimises it (ties: fewer registers).
-inline int class2_of(int64_t size)
+inline int class2_of_compute(int64_t size)
 {
     if (size > 64 * RK_MAX_R) return big_class;
     int best = -1;
@@ -80,6 +80,21 @@ inline int class2_of(int64_t size)
         }
     }
     return best;
+}
+
+inline int class2_of(int64_t size)
+{
+    struct table {
+        signed char v[64 * RK_MAX_R + 1];
+        table()
+        {
+            for (int i = 0; i <= 64 * RK_MAX_R; ++i) {
+                v[i] = static_cast<signed char>(class2_of_compute(i ? i : 1));
+            }
+        }
+    };
+    static const table t;
+    return size > 64 * RK_MAX_R ? big_class : t.v[size];
 }
 
 // Node records of the list kernel, stored in SIBLING order: the children of a node occupy consecutive
@@ -118,6 +133,7 @@ struct kparams {
     F mac_value, eps2, G;
     F *out[4];
     uint32_t out_sub; // value subtracted from the particle index when writing (compact output)
+    const uint32_t *perm; // non-null: original-order output, results of Morton particle i go to out[perm[i]]
     unsigned long long *dbg; // diagnostic builds only (RK_STAMPS): per-section cycle totals
     int xcd_mode;            // block -> group-list mapping (see xcd_map_block)
     // Supergroup pre-pass (k_super): K consecutive target groups share the upper part of list building.
@@ -130,10 +146,26 @@ struct kparams {
     uint2 *sup_cnt;
 };
 
+// Index of the output element of Morton particle i.
+template <typename F>
+__device__ __forceinline__ uint32_t out_index(const kparams<F> &P, uint32_t i)
+{
+    return P.perm ? P.perm[i] : i - P.out_sub;
+}
+
 struct error : std::runtime_error {
     int code;
     error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
 };
+
+// Device memory for states and build temporaries comes from a per-device cache of freed blocks (rk_pool.hip):
+// rebuilding a tree every time step would otherwise pay hipMalloc/hipFree (implicit device syncs, ~0.1-1 ms each)
+// dozens of times. Blocks are handed back to the driver by pool_trim() (rk_pool_trim()). RK_POOL=0 disables caching.
+// Reuse is safe because every producer/consumer of a recycled block is ordered on the null stream or fenced by a
+// device synchronisation in pool_release_sync().
+void *pool_alloc(size_t bytes);
+void pool_free(void *p) noexcept;
+void pool_trim() noexcept;
 
 #define RK_HIP(expr)                                                                                                   \
     do {                                                                                                               \
@@ -176,6 +208,8 @@ struct rk_state {
         void *out[4];
     };
     graph_key gkey{};
+    graph_key last_key{}; // key of the previous call: a graph is only captured when a call repeats
+    bool have_last_key = false;
     hipGraphExec_t graph_exec = nullptr;
     hipStream_t cap_stream = nullptr;
     bool timed = false;
@@ -207,8 +241,8 @@ void launch_super(const rk_state &s, const kparams<F> &p, int64_t s_begin, int64
 template <typename F>
 void launch_block(const rk_state &s, int q, const kparams<F> &p, const uint32_t *list, int64_t n, hipStream_t stream);
 template <typename F>
-void build_device(rk_state &s, const void *const parts[4], int64_t nparts, double box_size, uint64_t max_leaf_n,
-                  std::string &bad_coord_msg);
+void build_device(rk_state &s, const void *const parts[4], bool parts_on_device, int64_t nparts, double box_size,
+                  uint64_t max_leaf_n, std::string &bad_coord_msg);
 template <typename F>
 void launch_census(const rk_state &s, const kparams<F> &p, int64_t g_begin, int64_t g_end,
                    unsigned long long *d_counts, hipStream_t stream);

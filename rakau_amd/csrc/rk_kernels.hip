@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(256) k_dfs_wave(const kparams<F> P, const uint
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         if (valid[r]) {
-            const uint32_t o = tb + lane + 64u * r - P.out_sub;
+            const uint32_t o = out_index(P, tb + lane + 64u * r);
 #pragma unroll
             for (int k = 0; k < NR; ++k) {
                 P.out[k][o] = acc[r][k] * G;
@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(256) k_dfs_block(const kparams<F> P, const uin
     const uint32_t tid = threadIdx.x;
     for (uint32_t i = tb + tid; i < te; i += 256u) {
         for (int k = 0; k < NR; ++k) {
-            P.out[k][i - P.out_sub] = F(0);
+            P.out[k][out_index(P, i)] = F(0);
         }
     }
     const uint32_t n_nodes = P.n_nodes;
@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(256) k_dfs_block(const kparams<F> P, const uin
                     const v4 t = P.part4[i];
                     F acc[NR];
                     for (int k = 0; k < NR; ++k) {
-                        acc[k] = P.out[k][i - P.out_sub];
+                        acc[k] = P.out[k][out_index(P, i)];
                     }
                     for (uint32_t j = topo.y; j < topo.z; ++j) {
                         const v4 s = P.part4[j];
@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(256) k_dfs_block(const kparams<F> P, const uin
                         interact<F, Q>(acc, ex, ey, ez, e2, s.w, t.w);
                     }
                     for (int k = 0; k < NR; ++k) {
-                        P.out[k][i - P.out_sub] = acc[k];
+                        P.out[k][out_index(P, i)] = acc[k];
                     }
                 }
             }
@@ -188,13 +188,13 @@ __global__ void __launch_bounds__(256) k_dfs_block(const kparams<F> P, const uin
                 const v4 t = P.part4[i];
                 F acc[NR];
                 for (int k = 0; k < NR; ++k) {
-                    acc[k] = P.out[k][i - P.out_sub];
+                    acc[k] = P.out[k][out_index(P, i)];
                 }
                 const F dx = com.x - t.x, dy = com.y - t.y, dz = com.z - t.z;
                 const F d2 = rk_fma(dz, dz, rk_fma(dy, dy, dx * dx));
                 interact<F, Q>(acc, dx, dy, dz, d2 + eps2, com.w, t.w);
                 for (int k = 0; k < NR; ++k) {
-                    P.out[k][i - P.out_sub] = acc[k];
+                    P.out[k][out_index(P, i)] = acc[k];
                 }
             }
             idx += nch + 1u;
@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(256) k_dfs_block(const kparams<F> P, const uin
         const v4 t = P.part4[i];
         F acc[NR];
         for (int k = 0; k < NR; ++k) {
-            acc[k] = P.out[k][i - P.out_sub];
+            acc[k] = P.out[k][out_index(P, i)];
         }
         for (uint32_t j = tb; j < te; ++j) {
             const v4 s = P.part4[j];
@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(256) k_dfs_block(const kparams<F> P, const uin
             interact<F, Q>(acc, ex, ey, ez, e2, self ? F(0) : s.w, t.w);
         }
         for (int k = 0; k < NR; ++k) {
-            P.out[k][i - P.out_sub] = acc[k] * G;
+            P.out[k][out_index(P, i)] = acc[k] * G;
         }
     }
 }

@@ -608,7 +608,7 @@ __global__ void __launch_bounds__(256, (sizeof(F) == 4 ? (R <= 2 ? RK_W12 : (R =
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if (tidx[r] >= 0) {
-                const uint32_t o = tb + static_cast<uint32_t>(tidx[r]) - P.out_sub;
+                const uint32_t o = out_index(P, tb + static_cast<uint32_t>(tidx[r]));
 #pragma unroll
                 for (int k = 0; k < NR; ++k) {
                     P.out[k][o] = acc[r][k] * G;

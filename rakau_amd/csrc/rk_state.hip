@@ -2,6 +2,7 @@
 #include "rk_common.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -50,6 +51,28 @@ struct device_guard {
     int cur = 0;
 };
 
+// Give the tree-dependent device buffers back to the pool (after a device sync: traversal kernels on other
+// streams may still be reading them) and forget everything derived from them. Streams, events and the output /
+// supergroup scratch survive, so that a state can be rebuilt in place every time step.
+void release_tree(rk_state *s)
+{
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < RK_NBUF; ++i) {
+        rk::pool_free(s->buf[i]);
+        s->buf[i] = nullptr;
+        s->buf_bytes[i] = 0;
+    }
+    for (void **b : {&s->bld_codes, &s->bld_perm, &s->bld_node_code}) {
+        rk::pool_free(*b);
+        *b = nullptr;
+    }
+    if (s->graph_exec) {
+        (void)hipGraphExecDestroy(s->graph_exec);
+        s->graph_exec = nullptr;
+    }
+    s->have_last_key = false;
+}
+
 void free_state(rk_state *s)
 {
     if (!s) {
@@ -58,18 +81,9 @@ void free_state(rk_state *s)
     int prev = 0;
     (void)hipGetDevice(&prev);
     (void)hipSetDevice(s->device);
-    for (auto &b : s->buf) {
-        if (b) {
-            (void)hipFree(b);
-        }
-    }
-    if (s->d_out) {
-        (void)hipFree(s->d_out);
-    }
-    for (void *b : {s->bld_codes, s->bld_perm, s->bld_node_code, s->sup_common, s->sup_resid, s->sup_cnt}) {
-        if (b) {
-            (void)hipFree(b);
-        }
+    release_tree(s);
+    for (void *b : {s->d_out, s->sup_common, s->sup_resid, s->sup_cnt}) {
+        rk::pool_free(b);
     }
     if (s->ev0) {
         (void)hipEventDestroy(s->ev0);
@@ -79,9 +93,6 @@ void free_state(rk_state *s)
     }
     if (s->ev_fork) {
         (void)hipEventDestroy(s->ev_fork);
-    }
-    if (s->graph_exec) {
-        (void)hipGraphExecDestroy(s->graph_exec);
     }
     if (s->cap_stream) {
         (void)hipStreamDestroy(s->cap_stream);
@@ -112,7 +123,7 @@ void alloc_upload(rk_state &s, int which, const void *host, size_t bytes)
     if (!bytes) {
         return;
     }
-    RK_HIP(hipMalloc(&s.buf[which], bytes));
+    s.buf[which] = rk::pool_alloc(bytes);
     if (host) {
         RK_HIP(hipMemcpy(s.buf[which], host, bytes, hipMemcpyHostToDevice));
     }
@@ -429,7 +440,15 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
     for (int k = 0; k < rk::nres_of(q); ++k) {
         p.out[k] = static_cast<F *>(d_out[k]);
     }
-    p.out_sub = offset_output ? 0u : static_cast<uint32_t>(p_begin);
+    p.out_sub = (offset_output & 1) ? 0u : static_cast<uint32_t>(p_begin);
+    p.perm = nullptr;
+    if (offset_output & 2) {
+        if (!s.bld_perm) {
+            throw rk::error(RK_EINVAL, "original-order output needs the permutation: build the state on the device or "
+                                       "call rk_state_set_perm() first");
+        }
+        p.perm = static_cast<const uint32_t *>(s.bld_perm);
+    }
     p.dbg = nullptr;
     {
         static const int xcd_mode = [] {
@@ -474,16 +493,15 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
         if (s.super_k > 0 && s.n_crit > 0) {
             const int64_t n_super = (s.n_crit + s.super_k - 1) / s.super_k;
             if (s.sup_alloc < n_super) {
+                RK_HIP(hipDeviceSynchronize());
                 for (void **b : {&s.sup_common, &s.sup_resid, &s.sup_cnt}) {
-                    if (*b) {
-                        RK_HIP(hipFree(*b));
-                        *b = nullptr;
-                    }
+                    rk::pool_free(*b);
+                    *b = nullptr;
                 }
                 s.sup_alloc = 0;
-                RK_HIP(hipMalloc(&s.sup_common, static_cast<size_t>(n_super) * rk::SUP_CAPC * sizeof(typename rk::vt<F>::v4)));
-                RK_HIP(hipMalloc(&s.sup_resid, static_cast<size_t>(n_super) * rk::SUP_CAPR * sizeof(uint32_t)));
-                RK_HIP(hipMalloc(&s.sup_cnt, static_cast<size_t>(n_super) * sizeof(uint2)));
+                s.sup_common = rk::pool_alloc(static_cast<size_t>(n_super) * rk::SUP_CAPC * sizeof(typename rk::vt<F>::v4));
+                s.sup_resid = rk::pool_alloc(static_cast<size_t>(n_super) * rk::SUP_CAPR * sizeof(uint32_t));
+                s.sup_cnt = rk::pool_alloc(static_cast<size_t>(n_super) * sizeof(uint2));
                 s.sup_alloc = n_super;
             }
             p.super_k = static_cast<uint32_t>(s.super_k);
@@ -551,7 +569,16 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
             for (int k = 0; k < rk::nres_of(q); ++k) {
                 key.out[k] = d_out[k];
             }
-            if (!s.graph_exec || std::memcmp(&key, &s.gkey, sizeof(key)) != 0) {
+            const bool replay = s.graph_exec && std::memcmp(&key, &s.gkey, sizeof(key)) == 0;
+            const bool repeats = s.have_last_key && std::memcmp(&key, &s.last_key, sizeof(key)) == 0;
+            s.last_key = key;
+            s.have_last_key = true;
+            if (!replay && !repeats) {
+                // First call of its kind (e.g. once per rebuilt tree in a time-stepping loop): launch directly,
+                // a capture + instantiation would cost more than it saves.
+                enqueue(stream);
+            } else {
+            if (!replay) {
                 if (s.graph_exec) {
                     RK_HIP(hipGraphExecDestroy(s.graph_exec));
                     s.graph_exec = nullptr;
@@ -574,6 +601,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                 s.gkey = key;
             }
             RK_HIP(hipGraphLaunch(s.graph_exec, stream));
+            }
         } else {
             enqueue(stream);
         }
@@ -763,6 +791,9 @@ int rk_acc_pot(rk_state *s, int q, int64_t p_begin, int64_t p_end, void *const *
         if (p_begin < 0 || p_end < p_begin || p_end > s->nparts) {
             throw rk::error(RK_EINVAL, "invalid particle range");
         }
+        if (offset_output & ~RK_OUT_OFFSET) {
+            throw rk::error(RK_EINVAL, "rk_acc_pot() supports only RK_OUT_COMPACT / RK_OUT_OFFSET outputs");
+        }
         const size_t fsz = s->fp == RK_F32 ? sizeof(float) : sizeof(double);
         const auto count = static_cast<size_t>(p_end - p_begin);
         const int nres = rk::nres_of(q);
@@ -773,11 +804,12 @@ int rk_acc_pot(rk_state *s, int q, int64_t p_begin, int64_t p_end, void *const *
         const size_t need = count * fsz * static_cast<size_t>(nres);
         if (s->d_out_bytes < need) {
             if (s->d_out) {
-                RK_HIP(hipFree(s->d_out));
+                RK_HIP(hipDeviceSynchronize());
+                rk::pool_free(s->d_out);
                 s->d_out = nullptr;
                 s->d_out_bytes = 0;
             }
-            RK_HIP(hipMalloc(&s->d_out, need));
+            s->d_out = rk::pool_alloc(need);
             s->d_out_bytes = need;
         }
         void *d_ptrs[4] = {};
@@ -868,7 +900,7 @@ int rk_state_import(rk_state **out, int device, int count, void *const *ptrs, co
                 if (!ptrs[i]) {
                     throw rk::error(RK_EINVAL, "null buffer in rk_state_import");
                 }
-                RK_HIP(hipMalloc(&s->buf[i], static_cast<size_t>(bytes[i])));
+                s->buf[i] = rk::pool_alloc(static_cast<size_t>(bytes[i]));
                 RK_HIP(hipMemcpy(s->buf[i], ptrs[i], static_cast<size_t>(bytes[i]), hipMemcpyDeviceToDevice));
             }
         }
@@ -884,8 +916,66 @@ int rk_state_import(rk_state **out, int device, int count, void *const *ptrs, co
     });
 }
 
-int rk_state_build(rk_state **out, int fp, int mac, int device, const void *const parts[4], int64_t nparts,
-                   double box_size, uint64_t max_leaf_n, uint64_t ncrit)
+// Run the device build into `s` (fp, mac, device, ncrit, max_leaf_n already set; no tree buffers held).
+static void fill_from_build(rk_state &s, const void *const parts[4], bool on_device, int64_t nparts, double box_size)
+{
+    s.nparts = nparts;
+    s.tree_size = 0;
+    s.n_crit = 0;
+    s.box_size = box_size;
+    s.box_deduced = box_size == 0.;
+    std::vector<uint4> crit;
+    static const bool timing = std::getenv("RK_BUILD_TIMING") != nullptr; // diagnostic: phase times on stderr
+    const auto now = [] { return std::chrono::steady_clock::now(); };
+    const auto t0 = now();
+    auto t1 = t0, t2 = t0;
+    if (nparts > 0) {
+        std::string msg;
+        if (s.fp == RK_F32) {
+            rk::build_device<float>(s, parts, on_device, nparts, box_size, s.max_leaf_n, msg);
+        } else {
+            rk::build_device<double>(s, parts, on_device, nparts, box_size, s.max_leaf_n, msg);
+        }
+        // Host mirrors + class lists from the critical-node array.
+        crit.resize(static_cast<size_t>(s.buf_bytes[RK_BUF_CRIT]) / sizeof(uint4));
+        if (!crit.empty()) {
+            t1 = now();
+            RK_HIP(hipMemcpy(crit.data(), s.buf[RK_BUF_CRIT], crit.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+        }
+    }
+    t2 = now();
+    build_host_mirrors(s, crit);
+    const auto t3 = now();
+    if (nparts > 0) {
+        const std::vector<uint32_t> lists = concat_class_lists(s);
+        alloc_upload(s, RK_BUF_CLASS, lists.data(), lists.size() * sizeof(uint32_t));
+    }
+    if (timing) {
+        const auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        std::fprintf(stderr, "RK_BUILD_TIMING n=%lld: device build %.0f us, crit download %.0f us, host mirrors %.0f us, "
+                             "class lists + upload %.0f us\n",
+                     static_cast<long long>(nparts), us(t0, t1), us(t1, t2), us(t2, t3), us(t3, now()));
+    }
+}
+
+static void check_build_args(const void *const parts[4], int64_t nparts, double box_size)
+{
+    if (nparts < 0 || (nparts > 0 && (!parts || !parts[0] || !parts[1] || !parts[2] || !parts[3]))) {
+        throw rk::error(RK_EINVAL, "null particle array");
+    }
+    if (static_cast<uint64_t>(nparts) >= 0x7fffffffull) {
+        throw rk::error(RK_EOVERFLOW, "The number of particles (" + std::to_string(nparts)
+                                          + ") is too large for the 32-bit device indices");
+    }
+    // Parameter checks and messages of tree.hpp:1350-1362 of the reference.
+    if (!std::isfinite(box_size) || box_size < 0.) {
+        throw rk::error(RK_EINVAL, "The box size must be a finite non-negative value, but it is "
+                                       + std::to_string(box_size) + " instead");
+    }
+}
+
+static int state_build_impl(rk_state **out, int fp, int mac, int device, const void *const parts[4], bool on_device,
+                            int64_t nparts, double box_size, uint64_t max_leaf_n, uint64_t ncrit)
 {
     return guard([&] {
         if (!out) {
@@ -893,18 +983,7 @@ int rk_state_build(rk_state **out, int fp, int mac, int device, const void *cons
         }
         *out = nullptr;
         check_common(fp, mac);
-        if (nparts < 0 || (nparts > 0 && (!parts || !parts[0] || !parts[1] || !parts[2] || !parts[3]))) {
-            throw rk::error(RK_EINVAL, "null particle array");
-        }
-        if (static_cast<uint64_t>(nparts) >= 0x7fffffffull) {
-            throw rk::error(RK_EOVERFLOW, "The number of particles (" + std::to_string(nparts)
-                                              + ") is too large for the 32-bit device indices");
-        }
-        // Parameter checks and messages of tree.hpp:1350-1362 of the reference.
-        if (!std::isfinite(box_size) || box_size < 0.) {
-            throw rk::error(RK_EINVAL, "The box size must be a finite non-negative value, but it is "
-                                           + std::to_string(box_size) + " instead");
-        }
+        check_build_args(parts, nparts, box_size);
         if (!max_leaf_n) {
             throw rk::error(RK_EINVAL, "The maximum number of particles per leaf must be nonzero");
         }
@@ -918,28 +997,87 @@ int rk_state_build(rk_state **out, int fp, int mac, int device, const void *cons
         s->fp = fp;
         s->mac = mac;
         s->device = device;
-        s->nparts = nparts;
         s->ncrit = ncrit;
         s->max_leaf_n = max_leaf_n;
-        s->box_size = box_size;
-        s->box_deduced = box_size == 0.;
-        if (nparts > 0) {
-            std::string msg;
-            if (fp == RK_F32) {
-                rk::build_device<float>(*s, parts, nparts, box_size, max_leaf_n, msg);
-            } else {
-                rk::build_device<double>(*s, parts, nparts, box_size, max_leaf_n, msg);
-            }
-            // Host mirrors + class lists from the critical-node array.
-            std::vector<uint4> crit(static_cast<size_t>(s->buf_bytes[RK_BUF_CRIT]) / sizeof(uint4));
-            if (!crit.empty()) {
-                RK_HIP(hipMemcpy(crit.data(), s->buf[RK_BUF_CRIT], crit.size() * sizeof(uint4), hipMemcpyDeviceToHost));
-            }
-            build_host_mirrors(*s, crit);
-            const std::vector<uint32_t> lists = concat_class_lists(*s);
-            alloc_upload(*s, RK_BUF_CLASS, lists.data(), lists.size() * sizeof(uint32_t));
-        }
+        fill_from_build(*s, parts, on_device, nparts, box_size);
         *out = s.release();
+    });
+}
+
+int rk_state_build(rk_state **out, int fp, int mac, int device, const void *const parts[4], int64_t nparts,
+                   double box_size, uint64_t max_leaf_n, uint64_t ncrit)
+{
+    return state_build_impl(out, fp, mac, device, parts, false, nparts, box_size, max_leaf_n, ncrit);
+}
+
+int rk_state_build_device(rk_state **out, int fp, int mac, int device, const void *const d_parts[4], int64_t nparts,
+                          double box_size, uint64_t max_leaf_n, uint64_t ncrit)
+{
+    return state_build_impl(out, fp, mac, device, d_parts, true, nparts, box_size, max_leaf_n, ncrit);
+}
+
+int rk_state_rebuild_device(rk_state *s, const void *const d_parts[4], int64_t nparts, double box_size)
+{
+    return guard([&] {
+        if (!s) {
+            throw rk::error(RK_EINVAL, "null state");
+        }
+        check_build_args(d_parts, nparts, box_size);
+        device_guard dg(s->device);
+        release_tree(s);
+        try {
+            fill_from_build(*s, d_parts, true, nparts, box_size);
+        } catch (...) {
+            // Leave an empty but valid state behind.
+            release_tree(s);
+            s->nparts = 0, s->tree_size = 0;
+            build_host_mirrors(*s, {});
+            throw;
+        }
+    });
+}
+
+void rk_pool_trim(void)
+{
+    rk::pool_trim();
+}
+
+int rk_state_set_perm(rk_state *s, const uint64_t *perm)
+{
+    return guard([&] {
+        if (!s || (!perm && s->nparts)) {
+            throw rk::error(RK_EINVAL, "null argument");
+        }
+        device_guard dg(s->device);
+        std::vector<uint32_t> p32(static_cast<size_t>(s->nparts));
+        for (size_t i = 0; i < p32.size(); ++i) {
+            if (perm[i] >= static_cast<uint64_t>(s->nparts)) {
+                throw rk::error(RK_EINVAL, "invalid permutation entry");
+            }
+            p32[i] = static_cast<uint32_t>(perm[i]);
+        }
+        if (!s->bld_perm && !p32.empty()) {
+            s->bld_perm = rk::pool_alloc(p32.size() * sizeof(uint32_t));
+        }
+        if (!p32.empty()) {
+            RK_HIP(hipMemcpy(s->bld_perm, p32.data(), p32.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
+    });
+}
+
+int rk_state_device_ptr(const rk_state *s, int what, void **ptr, int64_t *bytes)
+{
+    return guard([&] {
+        if (!s || !ptr || !bytes) {
+            throw rk::error(RK_EINVAL, "null argument");
+        }
+        const size_t n = static_cast<size_t>(s->nparts);
+        switch (what) {
+            case 0: *ptr = s->buf[RK_BUF_PART4], *bytes = s->buf_bytes[RK_BUF_PART4]; break;
+            case 1: *ptr = s->bld_perm, *bytes = s->bld_perm ? static_cast<int64_t>(n * sizeof(uint32_t)) : 0; break;
+            case 2: *ptr = s->bld_codes, *bytes = s->bld_codes ? static_cast<int64_t>(n * sizeof(uint64_t)) : 0; break;
+            default: throw rk::error(RK_EINVAL, "invalid selector for rk_state_device_ptr");
+        }
     });
 }
 
@@ -987,7 +1125,7 @@ int rk_state_download(const rk_state *s, int what, void *dst)
             RK_HIP(hipMemcpy(dst, s->buf[RK_BUF_PART4], n * 4 * fsz, hipMemcpyDeviceToHost));
             return;
         }
-        if ((what == 4 || what == 5 || what == 6 || what == 7) && !s->bld_codes) {
+        if (((what == 4 || what == 6 || what == 7) && !s->bld_codes) || (what == 5 && !s->bld_perm)) {
             throw rk::error(RK_EINVAL, "this state was created from a host tree: codes, permutation and nodal codes "
                                        "live in the caller's tree");
         }

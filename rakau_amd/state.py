@@ -65,6 +65,45 @@ class State:
                                                0.0 if box_size is None else float(box_size), max_leaf_n, ncrit))
         return cls._from_handle(h, dtype, mac)
 
+    @classmethod
+    def build_device(cls, d_ptrs, nparts, dtype, box_size=None, max_leaf_n=16, ncrit=128, mac="bh", device=0):
+        """rk_state_build_device: x, y, z, m are DEVICE addresses (e.g. torch.Tensor.data_ptr()) of `nparts` values of
+        `dtype` resident on `device`, in the caller's original order. Nothing crosses PCIe."""
+        dtype = np.dtype(dtype)
+        if dtype not in _FP:
+            raise TypeError("dtype must be float32 or float64")
+        h = C.c_void_p()
+        parts = (C.c_void_p * 4)(*d_ptrs)
+        _capi.check(_capi.lib().rk_state_build_device(C.byref(h), _FP[dtype], _MAC[mac], device, parts, nparts,
+                                                      0.0 if box_size is None else float(box_size), max_leaf_n,
+                                                      ncrit))
+        return cls._from_handle(h, dtype, mac)
+
+    def rebuild_device(self, d_ptrs, nparts=None, box_size=None):
+        """rk_state_rebuild_device: new particle positions (device addresses, original order), same parameters."""
+        nparts = self.nparts if nparts is None else nparts
+        parts = (C.c_void_p * 4)(*d_ptrs)
+        try:
+            _capi.check(_capi.lib().rk_state_rebuild_device(self._h, parts, nparts,
+                                                            0.0 if box_size is None else float(box_size)))
+        finally:
+            self._read_info()
+
+    def set_perm(self, perm):
+        """Install tree::perm() (uint64, host) so that ordered=True outputs work on a state made from a host tree."""
+        perm = np.ascontiguousarray(perm, dtype=np.uint64)
+        if perm.size != self.nparts:
+            raise ValueError("perm must have one entry per particle")
+        _capi.check(_capi.lib().rk_state_set_perm(self._h, perm.ctypes.data))
+
+    def device_ptr(self, what):
+        """(address, bytes) of a resident array: 'parts' ({x,y,z,m} AoS, Morton order), 'perm' (uint32), 'codes'."""
+        ptr = C.c_void_p()
+        nbytes = C.c_int64()
+        sel = {"parts": 0, "perm": 1, "codes": 2}[what]
+        _capi.check(_capi.lib().rk_state_device_ptr(self._h, sel, C.byref(ptr), C.byref(nbytes)))
+        return ptr.value or 0, nbytes.value
+
     def tree_info(self):
         box = C.c_double()
         info = (C.c_int64 * 4)()
@@ -133,12 +172,14 @@ class State:
         return out
 
     def acc_pot_device(self, q, mac_value, d_ptrs, G=1.0, eps2=0.0, p_begin=0, p_end=None, offset_output=True,
-                       stream=None):
-        """Outputs stay in HBM: d_ptrs are device addresses (e.g. torch.Tensor.data_ptr())."""
+                       stream=None, ordered=False):
+        """Outputs stay in HBM: d_ptrs are device addresses (e.g. torch.Tensor.data_ptr()). ordered=True writes the
+        result of every particle at its ORIGINAL index (accs_o / pots_o semantics; full-size outputs)."""
         p_end = self.nparts if p_end is None else p_end
         ptrs = (C.c_void_p * 4)(*d_ptrs, *([None] * (4 - len(d_ptrs))))
-        _capi.check(_capi.lib().rk_acc_pot_device(self._h, q, p_begin, p_end, ptrs, mac_value, G, eps2,
-                                                  int(offset_output), stream))
+        flags = _capi.RK_OUT_ORDERED if ordered else int(bool(offset_output))
+        _capi.check(_capi.lib().rk_acc_pot_device(self._h, q, p_begin, p_end, ptrs, mac_value, G, eps2, flags,
+                                                  stream))
 
     def count_interactions(self, mac_value, p_begin=0, p_end=None):
         """Census of the traversal: dict(mac=..., com=..., pp=..., self=...) particle-level counts."""

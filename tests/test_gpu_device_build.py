@@ -64,7 +64,7 @@ def test_parameter_matrix(dtype):
     rng = oracle.Rng(5)
     for s in (1, 2, 17, 300, 3000):
         m, x, y, z = rng.uniform_particles(s, 1.0, dtype)
-        for max_leaf_n, ncrit in ((1, 1), (2, 16), (8, 128), (16, 256), (16, 1)):
+        for max_leaf_n, ncrit in ((1, 1), (2, 16), (8, 128), (16, 256), (16, 1), (64, 64), (65, 300), (1000, 128)):
             for box in (1.0, None):
                 ot = oracle.Tree(x, y, z, m, box_size=box or 0.0, max_leaf_n=max_leaf_n, ncrit=ncrit)
                 st = rakau_amd.State.build(x, y, z, m, box_size=box, max_leaf_n=max_leaf_n, ncrit=ncrit)

@@ -1,0 +1,192 @@
+"""Device-resident callers of the hot path: tree build from device pointers,
+in-place rebuild, original-order outputs written by the kernel epilogue, and the kick-drift-kick loop of
+benchmark/benchmark_leapfrog.cpp on top of them."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+import rakau_amd
+from helpers import rel_err_vec
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "examples"))
+
+
+def torch_dev():
+    import torch
+    return torch, torch.device("cuda", 0)
+
+
+def same_tree(a, b):
+    assert (a.nparts, a.tree_size, a.n_crit, a.max_group) == (b.nparts, b.tree_size, b.n_crit, b.max_group)
+    assert a.tree_info() == b.tree_info()
+    for what in ("x", "y", "z", "m", "codes", "perm", "crit"):
+        assert np.array_equal(a.download(what), b.download(what)), what
+    na, nb = a.download("nodes"), b.download("nodes")
+    assert na.tobytes() == nb.tobytes()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("q", [0, 1, 2])
+def test_ordered_output_is_the_perm_scatter(dtype, q):
+    """RK_OUT_ORDERED == Morton-order results scattered through perm (tree.hpp:3320-3330), bit for bit, for the full
+    range and for a sub-range (which must leave the other elements alone)."""
+    torch, dev = torch_dev()
+    m, x, y, z = oracle.plummer(30000, dtype)
+    st = rakau_amd.State.build(x, y, z, m)
+    mv = rakau_amd.mac_value_of(0.75, "bh", dtype)
+    perm = st.download("perm").astype(np.int64)
+    tt = torch.float32 if dtype == np.float32 else torch.float64
+    for variant in (0, 1):  # list kernel, depth-first kernel (+ the block kernel for big groups in both)
+        st.set_variant(variant)
+        ref = st.acc_pot(q, mv, eps2=1e-6)
+        outs = [torch.full((st.nparts,), -7.0, dtype=tt, device=dev) for _ in ref]
+        st.acc_pot_device(q, mv, [o.data_ptr() for o in outs], eps2=1e-6, ordered=True)
+        torch.cuda.synchronize()
+        for o, r in zip(outs, ref):
+            exp = np.empty_like(r)
+            exp[perm] = r
+            got = o.cpu().numpy()
+            assert np.array_equal(got, exp), (variant, int((got != exp).sum()), np.nonzero(got[perm] != r)[0][:8],
+                                              float(np.abs(got - exp).max()))
+        # Sub-range aligned to critical nodes.
+        cr = st.crit_ranges()
+        b, e = int(cr[len(cr) // 3, 0]), int(cr[2 * len(cr) // 3, 0])
+        outs = [torch.full((st.nparts,), -7.0, dtype=tt, device=dev) for _ in ref]
+        st.acc_pot_device(q, mv, [o.data_ptr() for o in outs], eps2=1e-6, p_begin=b, p_end=e, ordered=True)
+        torch.cuda.synchronize()
+        for o, r in zip(outs, ref):
+            exp = np.full_like(r, -7.0)
+            exp[perm[b:e]] = r[b:e]
+            assert np.array_equal(o.cpu().numpy(), exp)
+    st.set_variant(0)
+
+
+def test_ordered_output_needs_perm_and_set_perm_provides_it():
+    torch, dev = torch_dev()
+    rng = oracle.Rng(3)
+    m, x, y, z = rng.uniform_particles(5000, 1.0, np.float64)
+    t = rakau_amd.Octree(x, y, z, m, box_size=1.0)
+    st = t.state()
+    mv = rakau_amd.mac_value_of(0.5, "bh", np.float64)
+    outs = [torch.zeros(5000, dtype=torch.float64, device=dev) for _ in range(3)]
+    with pytest.raises(ValueError, match="needs the permutation"):
+        st.acc_pot_device(0, mv, [o.data_ptr() for o in outs], ordered=True)
+    with pytest.raises(ValueError, match="invalid permutation entry"):
+        st.set_perm(np.full(5000, 5000, dtype=np.uint64))
+    st.set_perm(t.perm())
+    st.acc_pot_device(0, mv, [o.data_ptr() for o in outs], ordered=True)
+    torch.cuda.synchronize()
+    ref = t.accs_o(0.5)
+    for o, r in zip(outs, ref):
+        assert np.array_equal(o.cpu().numpy(), r)
+    # The host entry point has no ordered mode.
+    with pytest.raises(ValueError, match="RK_OUT_COMPACT / RK_OUT_OFFSET"):
+        from rakau_amd import _capi
+        import ctypes as C
+        hout = [np.zeros(5000) for _ in range(3)]
+        ptrs = (C.c_void_p * 4)(*[o.ctypes.data for o in hout], None)
+        _capi.check(_capi.lib().rk_acc_pot(st._h, 0, 0, 5000, ptrs, mv, 1.0, 0.0, _capi.RK_OUT_ORDERED))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_build_from_device_pointers_and_rebuild(dtype):
+    """rk_state_build_device == rk_state_build on the same particles; rk_state_rebuild_device == a fresh build, through
+    growing and shrinking particle counts (recycled buffers must not leak stale data into the tree)."""
+    torch, dev = torch_dev()
+    tt = torch.float32 if dtype == np.float32 else torch.float64
+    rng = oracle.Rng(11)
+
+    def dev_parts(n, scale):
+        m, x, y, z = rng.uniform_particles(n, scale, dtype)
+        ts = [torch.as_tensor(v).to(dev) for v in (x, y, z, m)]
+        return (x, y, z, m), ts
+
+    host, ts = dev_parts(40000, 1.0)
+    torch.cuda.synchronize()
+    st = rakau_amd.State.build_device([t.data_ptr() for t in ts], 40000, dtype, mac="bh_geom")
+    same_tree(st, rakau_amd.State.build(*host, mac="bh_geom"))
+    assert st.device_ptr("parts")[1] == 40000 * 4 * np.dtype(dtype).itemsize
+    assert st.device_ptr("perm")[1] == 40000 * 4 and st.device_ptr("codes")[1] == 40000 * 8
+    mv = rakau_amd.mac_value_of(0.75, "bh_geom", dtype)
+    for n, scale, box in ((40000, 3.0, None), (90000, 1.0, 2.0), (1000, 1.0, None), (17, 1.0, None), (40000, 1.0, 4.0)):
+        host, ts = dev_parts(n, scale)
+        torch.cuda.synchronize()
+        st.rebuild_device([t.data_ptr() for t in ts], nparts=n, box_size=box)
+        fresh = rakau_amd.State.build(*host, mac="bh_geom", box_size=box)
+        same_tree(st, fresh)
+        for a, b in zip(st.acc_pot(2, mv), fresh.acc_pot(2, mv)):
+            assert np.array_equal(a, b)
+    # A failed rebuild leaves an empty, usable state.
+    bad = ts[0].clone()
+    bad[5] = float("inf")
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError, match="non-finite"):
+        st.rebuild_device([bad.data_ptr()] + [t.data_ptr() for t in ts[1:]], nparts=40000)
+    assert st.nparts == 0 and st.n_crit == 0
+    st.rebuild_device([t.data_ptr() for t in ts], nparts=40000, box_size=4.0)
+    same_tree(st, fresh)
+    rakau_amd._capi.lib().rk_pool_trim()
+    st.rebuild_device([t.data_ptr() for t in ts], nparts=40000, box_size=4.0)
+    same_tree(st, fresh)
+
+
+def cpu_leapfrog(x, y, z, vx, vy, vz, m, dt, steps, theta, eps):
+    """The same KDK loop with the oracle as force engine (float64 bookkeeping of the same operations)."""
+    pos = [x.copy(), y.copy(), z.copy()]
+    vel = [vx.copy(), vy.copy(), vz.copy()]
+    dtype = x.dtype
+    h = dtype.type(0.5 * dt)
+    dtt = dtype.type(dt)
+
+    def accs():
+        return oracle.Tree(pos[0], pos[1], pos[2], m).acc_pot(0, theta, eps=eps, ordered=True, nthreads=8)
+
+    a = accs()
+    for _ in range(steps):
+        for k in range(3):
+            vel[k] += a[k] * h
+            pos[k] += vel[k] * dtt
+        a = accs()
+        for k in range(3):
+            vel[k] += a[k] * h
+    return pos, vel
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_leapfrog_tracks_the_oracle_driven_integration(dtype):
+    import leapfrog
+    n0, dt, steps, theta = 20000, 1e-3, 5, 0.75
+    x, y, z, vx, vy, vz = leapfrog.plummer_with_velocities(n0, seed=4, dtype=dtype)
+    n = x.size
+    m = np.full(n, 1.0 / n, dtype=dtype)
+    eps = 0.45 * n ** -0.73
+    lf = leapfrog.Leapfrog(x, y, z, vx, vy, vz, m, dt, theta, eps)
+    for _ in range(steps):
+        lf.step()
+    pos, vel = cpu_leapfrog(x, y, z, vx, vy, vz, m, dt, steps, theta, eps)
+    # Displacements over the run are ~ v * steps * dt ~ 5e-3; compare them (not the positions) so that the check is
+    # sensitive: the two engines agree to the traversal tolerance of the reference's tests (ordering_acc.cpp:93-97).
+    tol = 2e-3 if dtype == np.float32 else 1e-9
+    d_gpu = [p.cpu().numpy().astype(np.float64) - p0 for p, p0 in zip(lf.pos, (x, y, z))]
+    d_cpu = [p.astype(np.float64) - p0 for p, p0 in zip(pos, (x, y, z))]
+    assert np.median(rel_err_vec(d_gpu, d_cpu)) < (1e-4 if dtype == np.float32 else 1e-12)
+    assert np.percentile(rel_err_vec(d_gpu, d_cpu), 99.9) < tol
+    v_gpu = [v.cpu().numpy() for v in lf.vel]
+    assert np.percentile(rel_err_vec(v_gpu, vel), 99.9) < tol
+
+
+def test_leapfrog_conserves_energy_and_reports():
+    import leapfrog
+    res = leapfrog.run(nparts=100000, steps=20, warmup=0, timestep=1e-3, track_integrals=True)
+    assert res["nparts"] > 97000 and res["value"] > 0
+    # Plummer model in virial equilibrium: 2K/|W| = 1 up to sampling noise; KDK at dt = 1e-3 over 20 steps conserves
+    # the total energy far better than 1e-3.
+    assert abs(res["virial_2K_over_W"] - 1.0) < 0.05
+    assert res["energy_rel_drift"] < 1e-3
+    assert all(abs(c) < 0.05 for c in res["com_end"])
+    print("\nleapfrog 100k:", {k: res[k] for k in ("value", "ms_per_step", "ms_rebuild", "ms_traversal", "energy_rel_drift")})
