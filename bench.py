@@ -7,8 +7,10 @@ A "step" is one accs_u() call (one traversal of the resident tree for all target
 tree and the particles already in HBM and the accelerations left in HBM. For N > 1 (launched through
 torch.distributed.run, one rank per GPU) rank 0 builds the tree and uploads it, the device buffers are
 replicated with RCCL broadcasts, and every rank traverses its contiguous Morton shard of the targets
-(cut at critical-node boundaries): no data-path collective. The total number of particles is fixed as N
-grows ("scaling": "strong").
+(cut at critical-node boundaries, equal interaction counts): no data-path collective. Per-GPU work is fixed as N
+grows ("scaling": "weak"): the N-GPU problem is ONE Plummer sphere of N x 4M particles in one replicated tree, each
+GPU computing the accelerations of its 4M-particle shard. RK_BENCH_SCALING=strong keeps the total at 4M instead
+(0.5M targets per GPU at N = 8: the launch is then too small to fill a 256-CU device; tools/shard_sim.py).
 
 Rank 0 prints ONE JSON line. Besides the contract's fields it carries `roofline` (FP32/FP64 vector-ALU
 bound: the path is rsqrt/FMA bound; the compulsory-HBM figures ride along) and, at
@@ -78,14 +80,22 @@ def usable_cpus():
     return n
 
 
-def shard_cuts(crit_ranges, nparts, world):
-    """Contiguous Morton shards with (nearly) equal particle counts, cut at critical-node boundaries."""
+def shard_cuts(crit_ranges, nparts, world, work=None):
+    """Contiguous Morton shards cut at critical-node boundaries: equal particle counts, or -- given the per-group
+    interaction counts of rk_group_work() -- equal traversal work (a Plummer core particle costs ~3x a halo one)."""
     begins = crit_ranges[:, 0]
     cuts = [0]
-    for r in range(1, world):
-        target = nparts * r // world
-        i = int(np.searchsorted(begins, target, side="left"))
-        cuts.append(int(begins[i]) if i < len(begins) else nparts)
+    if work is None:
+        for r in range(1, world):
+            target = nparts * r // world
+            i = int(np.searchsorted(begins, target, side="left"))
+            cuts.append(int(begins[i]) if i < len(begins) else nparts)
+    else:
+        cum = np.cumsum(work.astype(np.float64))
+        for r in range(1, world):
+            # First group whose cumulative work (exclusive) reaches r / world of the total.
+            i = int(np.searchsorted(cum, cum[-1] * r / world, side="left")) + 1 if len(cum) else 0
+            cuts.append(int(begins[i]) if i < len(begins) else nparts)
     cuts.append(nparts)
     return [max(c, cuts[i - 1]) if i else c for i, c in enumerate(cuts)]
 
@@ -113,11 +123,17 @@ def main():
     if args.nparts:
         wl["n"] = args.nparts
     n, dtype, theta, q = wl["n"], wl["dtype"], wl["theta"], wl["q"]
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    scaling = os.environ.get("RK_BENCH_SCALING", "weak")
+    if scaling not in ("weak", "strong"):
+        raise SystemExit("RK_BENCH_SCALING must be weak or strong")
+    n_per_gpu = n
+    if scaling == "weak":
+        n = n * world  # one sphere of world x n particles; every GPU owns n of them
     # Softening of the reference's leapfrog benchmark, eps = 0.45 * N^-0.73 (benchmark_leapfrog.cpp:218-223).
     eps = wl["eps"] if wl["eps"] is not None else 0.45 * n ** -0.73
     nres = rakau_amd.NRES[q]
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
@@ -200,7 +216,10 @@ def main():
         state.set_variant(args.variant)
 
     crit = state.crit_ranges()
-    cuts = shard_cuts(crit, state.nparts, world)
+    # Shards of equal WORK (integer census on the replicated tree: every rank derives the same cuts, no exchange).
+    balance = os.environ.get("RK_BENCH_BALANCE", "work")
+    work = state.group_work(mac_value) if (world > 1 and balance == "work") else None
+    cuts = shard_cuts(crit, state.nparts, world, work)
     p_begin, p_end = cuts[rank], cuts[rank + 1]
     n_local = p_end - p_begin
 
@@ -283,13 +302,14 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
-        "scaling": "strong",
+        "scaling": scaling,
         "vs_baseline": None,
         "dtype": "f32" if dtype == "float32" else "f64",
         "data": "synthetic Plummer sphere (numpy PCG64 seed 20261002), tree built on host, resident in HBM",
-        "config": {"workload": wl["desc"], "nparts": n, "theta": theta, "q": q, "eps": eps, "max_leaf_n": 16,
+        "config": {"workload": wl["desc"] + ("" if world == 1 or scaling == "strong" else " x %d GPUs (one sphere of %d particles)" % (world, n)),
+                   "nparts": n, "nparts_per_gpu": n // world if scaling == "strong" else n_per_gpu, "theta": theta, "q": q, "eps": eps, "max_leaf_n": 16,
                    "ncrit": 128, "mac": mac, "nodes": n_nodes, "critical_nodes": int(state.n_crit),
-                   "sharding": "contiguous Morton range per GPU, tree replicated by RCCL broadcast" if world > 1
+                   "sharding": ("contiguous Morton range per GPU (equal %s), tree replicated by RCCL broadcast" % ("interaction counts" if work is not None else "particle counts")) if world > 1
                    else "single GPU", "kernel_variant": args.variant},
         "kernel_ms": round(kernel_ms_max, 4),
         "interactions_per_particle": round(inter_total / n, 2),

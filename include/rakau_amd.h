@@ -210,6 +210,12 @@ RK_EXPORT int rk_device_memcpy(void *dst, const void *src, int64_t bytes, int de
 RK_EXPORT int rk_count_interactions(rk_state *s, int64_t p_begin, int64_t p_end, double mac_value,
                                     uint64_t counts[4]);
 
+/* work[g] = number of particle-level interactions (node + leaf + in-group) that critical node g performs at this MAC
+ * value, g = 0 .. n_crit-1 (host array). The traversal cost of a Morton range is proportional to the sum over its
+ * critical nodes: callers use it to cut shards / `split` fractions of equal work rather than equal particle counts
+ * (the reference leaves the split vector to the user, tree.hpp:2853-2935). */
+RK_EXPORT int rk_group_work(rk_state *s, double mac_value, uint64_t *work);
+
 /* Select the traversal kernel: 0 = automatic (default), 1 = wave-per-group scalar DFS,
  * 2 = LDS interaction-list kernel. For tests and benchmarks only. */
 RK_EXPORT int rk_set_kernel_variant(rk_state *s, int variant);

@@ -245,7 +245,7 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
                   uint64_t max_leaf_n, std::string &bad_coord_msg);
 template <typename F>
 void launch_census(const rk_state &s, const kparams<F> &p, int64_t g_begin, int64_t g_end,
-                   unsigned long long *d_counts, hipStream_t stream);
+                   unsigned long long *d_counts, unsigned long long *d_per_group, hipStream_t stream);
 } // namespace rk
 
 #endif

@@ -229,7 +229,8 @@ __global__ void __launch_bounds__(256) k_dfs_block(const kparams<F> P, const uin
 // ------------------------------------------------------------------------------------------------
 template <typename F, int MAC>
 __global__ void __launch_bounds__(256) k_census(const kparams<F> P, uint32_t g_begin, uint32_t g_end,
-                                                unsigned long long *__restrict__ counts)
+                                                unsigned long long *__restrict__ counts,
+                                                unsigned long long *__restrict__ per_group)
 {
     using v4 = typename vt<F>::v4;
     using v2 = typename vt<F>::v2;
@@ -278,12 +279,15 @@ __global__ void __launch_bounds__(256) k_census(const kparams<F> P, uint32_t g_b
         atomicAdd(&counts[1], n_com);
         atomicAdd(&counts[2], n_pp);
         atomicAdd(&counts[3], T * (T - 1));
+        if (per_group) {
+            per_group[wave] = n_com + n_pp + T * (T - 1);
+        }
     }
 }
 
 template <typename F>
 void launch_census(const rk_state &s, const kparams<F> &p, int64_t g_begin, int64_t g_end,
-                   unsigned long long *d_counts, hipStream_t stream)
+                   unsigned long long *d_counts, unsigned long long *d_per_group, hipStream_t stream)
 {
     const int64_t n = g_end - g_begin;
     if (n <= 0) {
@@ -292,17 +296,17 @@ void launch_census(const rk_state &s, const kparams<F> &p, int64_t g_begin, int6
     const auto grid = static_cast<unsigned>((n + 3) / 4);
     if (s.mac == RK_MAC_BH) {
         hipLaunchKernelGGL((k_census<F, 0>), dim3(grid), dim3(256), 0, stream, p, static_cast<uint32_t>(g_begin),
-                           static_cast<uint32_t>(g_end), d_counts);
+                           static_cast<uint32_t>(g_end), d_counts, d_per_group);
     } else {
         hipLaunchKernelGGL((k_census<F, 1>), dim3(grid), dim3(256), 0, stream, p, static_cast<uint32_t>(g_begin),
-                           static_cast<uint32_t>(g_end), d_counts);
+                           static_cast<uint32_t>(g_end), d_counts, d_per_group);
     }
     RK_HIP(hipGetLastError());
 }
 template void launch_census<float>(const rk_state &, const kparams<float> &, int64_t, int64_t, unsigned long long *,
-                                   hipStream_t);
+                                   unsigned long long *, hipStream_t);
 template void launch_census<double>(const rk_state &, const kparams<double> &, int64_t, int64_t, unsigned long long *,
-                                    hipStream_t);
+                                    unsigned long long *, hipStream_t);
 
 // ------------------------------------------------------------------------------------------------
 // Launch logic.

@@ -34,6 +34,10 @@
 #ifndef RK_UNR4
 #define RK_UNR4 1 // R = 4
 #endif
+#ifndef RK_WPB
+#define RK_WPB 1 // wavefronts (= target groups) per workgroup. Measured 4 -> 2.58 ms, 2 -> 2.45, 1 -> 2.35 at 4M: a block keeps its
+                 // LDS and wave slots until its slowest group ends, single-wave blocks free them at once (waves never sync)
+#endif
 #ifndef RK_W12
 #define RK_W12 7 // waves per SIMD the R <= 2 kernels are compiled for
 #endif
@@ -178,19 +182,19 @@ __device__ __forceinline__ void lk_eval_tile(const typename vt<F>::v4 *__restric
 }
 
 template <typename F, int Q, int MAC, int R>
-__global__ void __launch_bounds__(256, (sizeof(F) == 4 ? (R <= 2 ? RK_W12 : (R == 3 ? RK_W3 : (R == 4 ? RK_W4 : (R == 5 ? RK_W5 : RK_W6)))) : 1)) k_list(const kparams<F> P, const uint32_t *__restrict__ list, int n_list)
+__global__ void __launch_bounds__(64 * RK_WPB, (sizeof(F) == 4 ? (R <= 2 ? RK_W12 : (R == 3 ? RK_W3 : (R == 4 ? RK_W4 : (R == 5 ? RK_W5 : RK_W6)))) : 1)) k_list(const kparams<F> P, const uint32_t *__restrict__ list, int n_list)
 {
     using v4 = typename vt<F>::v4;
     using v2 = typename vt<F>::v2;
     constexpr int NR = nres_of(Q);
     constexpr int SRC_CAP = lk_cfg<F>::src_cap;
     static_assert(sizeof(lk_wave_lds<F>) >= 64 * 4 * sizeof(F), "reduction scratch does not fit");
-    __shared__ lk_wave_lds<F> s_lds[4];
+    __shared__ lk_wave_lds<F> s_lds[RK_WPB];
 
     const int wib = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     const unsigned blk = xcd_map_block(blockIdx.x, gridDim.x, P.xcd_mode);
-    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(blk * 4u) + wib);
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(blk * unsigned(RK_WPB)) + wib);
     if (wave >= n_list) {
         return;
     }
@@ -775,8 +779,8 @@ static void launch_list_qm(const rk_state &s, const kparams<F> &p, const int64_t
         if (n <= 0) {
             return;
         }
-        const auto grid = static_cast<unsigned>((n + 3) / 4);
-        hipLaunchKernelGGL((k_list<F, Q, MAC, R>), dim3(grid), dim3(256), 0, streams[c], p,
+        const auto grid = static_cast<unsigned>((n + RK_WPB - 1) / RK_WPB);
+        hipLaunchKernelGGL((k_list<F, Q, MAC, R>), dim3(grid), dim3(64 * RK_WPB), 0, streams[c], p,
                            lists + s.class2_off[c] + cb[c], static_cast<int>(n));
     };
     go(std::integral_constant<int, 5>{}, 4);

@@ -408,24 +408,30 @@ rk::kparams<F> base_params(const rk_state &s, double mac_value, double G, double
 }
 
 template <typename F>
-void census_impl(rk_state &s, int64_t p_begin, int64_t p_end, double mac_value, uint64_t counts[4])
+void census_impl(rk_state &s, int64_t p_begin, int64_t p_end, double mac_value, uint64_t counts[4],
+                 uint64_t *per_group = nullptr)
 {
     int64_t cb[rk::n_classes], ce[rk::n_classes];
     range_to_classes(s, p_begin, p_end, cb, ce); // validates the range
     const auto g0 = std::lower_bound(s.crit_begin.begin(), s.crit_begin.end(), p_begin) - s.crit_begin.begin();
     const auto g1 = std::lower_bound(s.crit_begin.begin(), s.crit_begin.end(), p_end) - s.crit_begin.begin();
     auto p = base_params<F>(s, mac_value, 1., 0.);
-    unsigned long long *d_counts = nullptr;
-    RK_HIP(hipMalloc(&d_counts, 4 * sizeof(unsigned long long)));
-    try {
-        RK_HIP(hipMemset(d_counts, 0, 4 * sizeof(unsigned long long)));
-        rk::launch_census<F>(s, p, g0, g1, d_counts, nullptr);
-        RK_HIP(hipMemcpy(counts, d_counts, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    } catch (...) {
-        (void)hipFree(d_counts);
-        throw;
+    const size_t ng = per_group ? static_cast<size_t>(g1 - g0) : 0;
+    struct pool_block {
+        void *p = nullptr;
+        ~pool_block()
+        {
+            rk::pool_free(p);
+        }
+    } blk;
+    blk.p = rk::pool_alloc((4 + ng) * sizeof(unsigned long long));
+    auto *d_counts = static_cast<unsigned long long *>(blk.p);
+    RK_HIP(hipMemset(d_counts, 0, (4 + ng) * sizeof(unsigned long long)));
+    rk::launch_census<F>(s, p, g0, g1, d_counts, ng ? d_counts + 4 : nullptr, nullptr);
+    RK_HIP(hipMemcpy(counts, d_counts, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (ng) {
+        RK_HIP(hipMemcpy(per_group, d_counts + 4, ng * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     }
-    RK_HIP(hipFree(d_counts));
 }
 
 template <typename F>
@@ -1198,6 +1204,29 @@ int rk_count_interactions(rk_state *s, int64_t p_begin, int64_t p_end, double ma
             census_impl<float>(*s, p_begin, p_end, mac_value, counts);
         } else {
             census_impl<double>(*s, p_begin, p_end, mac_value, counts);
+        }
+    });
+}
+
+int rk_group_work(rk_state *s, double mac_value, uint64_t *work)
+{
+    return guard([&] {
+        if (!s || (!work && s->n_crit)) {
+            throw rk::error(RK_EINVAL, "null argument");
+        }
+        if (!std::isfinite(mac_value) || mac_value <= 0.) {
+            throw rk::error(RK_EDOMAIN, "The transformed MAC value must be finite and positive, but it is "
+                                            + std::to_string(mac_value) + " instead");
+        }
+        if (!s->nparts) {
+            return;
+        }
+        device_guard dg(s->device);
+        uint64_t counts[4];
+        if (s->fp == RK_F32) {
+            census_impl<float>(*s, 0, s->nparts, mac_value, counts, work);
+        } else {
+            census_impl<double>(*s, 0, s->nparts, mac_value, counts, work);
         }
     });
 }

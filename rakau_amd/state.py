@@ -188,6 +188,12 @@ class State:
         _capi.check(_capi.lib().rk_count_interactions(self._h, p_begin, p_end, mac_value, c))
         return dict(mac=int(c[0]), com=int(c[1]), pp=int(c[2]), self=int(c[3]))
 
+    def group_work(self, mac_value):
+        """Particle-level interactions per critical node (uint64[n_crit]): the load-balancing weight of each group."""
+        out = np.zeros(self.n_crit, dtype=np.uint64)
+        _capi.check(_capi.lib().rk_group_work(self._h, mac_value, out.ctypes.data))
+        return out
+
     def last_kernel_ms(self):
         ms = C.c_float()
         _capi.check(_capi.lib().rk_last_kernel_ms(self._h, C.byref(ms)))

@@ -89,3 +89,27 @@ def test_shard_cuts_properties():
         assert all(a <= b for a, b in zip(cuts, cuts[1:]))
         assert all(c == n or c in set(ranges[:, 0]) for c in cuts)
         assert max(b - a for a, b in zip(cuts, cuts[1:])) <= n // world + 128
+
+
+def test_work_balanced_shard_cuts():
+    """Cuts by per-group work (rk_group_work): still on critical-node boundaries, every shard within one group's work of
+    the mean, degenerate inputs (one group, more ranks than groups, zero work) handled."""
+    sys.path.insert(0, ROOT)
+    from bench import shard_cuts
+    rng = np.random.default_rng(1)
+    sizes = rng.integers(1, 129, size=4000)
+    ends = np.cumsum(sizes)
+    ranges = np.stack([ends - sizes, ends], axis=1)
+    n = int(ends[-1])
+    work = (sizes * rng.integers(500, 4000, size=sizes.size)).astype(np.uint64)
+    for world in (1, 2, 3, 8):
+        cuts = shard_cuts(ranges, n, world, work)
+        assert len(cuts) == world + 1 and cuts[0] == 0 and cuts[-1] == n
+        assert all(a <= b for a, b in zip(cuts, cuts[1:]))
+        assert all(c == n or c in set(ranges[:, 0]) for c in cuts)
+        g = np.searchsorted(ranges[:, 0], cuts[:-1]).tolist() + [len(sizes)]
+        per = [float(work[a:b].sum()) for a, b in zip(g, g[1:])]
+        assert max(per) - min(per) <= 2 * float(work.max())
+    one = np.array([[0, 50]])
+    assert shard_cuts(one, 50, 4, np.array([7], dtype=np.uint64)) == [0, 50, 50, 50, 50]
+    assert shard_cuts(ranges[:3], int(ends[2]), 2, np.zeros(3, dtype=np.uint64))[-1] == int(ends[2])
