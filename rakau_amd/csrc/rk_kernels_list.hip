@@ -34,6 +34,9 @@
 #ifndef RK_UNR4
 #define RK_UNR4 1 // R = 4
 #endif
+#ifndef RK_CHUNKED_SPLITS
+#define RK_CHUNKED_SPLITS 1 // dense phase: contiguous (1) or interleaved (0) assignment of tile sources to splits
+#endif
 #ifndef RK_WPB
 #define RK_WPB 1 // wavefronts (= target groups) per workgroup. Measured 4 -> 2.58 ms, 2 -> 2.45, 1 -> 2.35 at 4M: a block keeps its
                  // LDS and wave slots until its slowest group ends, single-wave blocks free them at once (waves never sync)
@@ -166,6 +169,21 @@ __device__ __forceinline__ void lk_eval_tile(const typename vt<F>::v4 *__restric
     constexpr int UNR = R >= 4 ? RK_UNR4 : (R == 3 ? RK_UNR3 : (R == 2 ? RK_UNR2 : RK_UNR1));
     static_assert(R <= 6);
     const int full = n_src / ns, rem = n_src - full * ns;
+#if RK_CHUNKED_SPLITS
+    // Split sp owns the contiguous sources [sp * full, (sp + 1) * full): consecutive iterations read consecutive
+    // LDS slots (immediate offsets, no address arithmetic in the loop); the remainder sits at the end of the tile.
+    const v4 *p = src + sp * full;
+    int j = sp * full;
+#pragma unroll UNR
+    for (int it = 0; it < full; ++it) {
+        const v4 s = p[it];
+        lk_interact_src<F, Q, R, SELF>(s, j + it, tp, acc, eps2, tidx);
+    }
+    if (lane_on && sp < rem) {
+        const v4 s = src[ns * full + sp];
+        lk_interact_src<F, Q, R, SELF>(s, ns * full + sp, tp, acc, eps2, tidx);
+    }
+#else
     const v4 *p = src + sp;
     int j = sp;
 #pragma unroll UNR
@@ -179,6 +197,7 @@ __device__ __forceinline__ void lk_eval_tile(const typename vt<F>::v4 *__restric
         const v4 s = *p;
         lk_interact_src<F, Q, R, SELF>(s, j, tp, acc, eps2, tidx);
     }
+#endif
 }
 
 template <typename F, int Q, int MAC, int R>
