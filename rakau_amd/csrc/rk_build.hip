@@ -63,10 +63,27 @@ __device__ inline double d_fma(double a, double b, double c)
     return __builtin_fma(a, b, c);
 }
 
+// Control block of one build: everything the host needs to know, fetched with one copy per synchronisation point.
+struct ctrl_block {
+    unsigned long long maxbits; // bit pattern of max |coordinate| (non-negative IEEE values order like integers)
+    double box;                 // domain size actually used
+    unsigned err;               // bit 0: non-finite coordinate while deducing the box, 1: non-finite COM,
+                                // 2: non-finite node dimension, 3: non-finite deduced box
+    unsigned bad_inv;           // ~(index of the first particle that cannot be discretised), 0 = none
+    unsigned n_nonroot;         // number of nodes besides the root
+    unsigned n_crit, n_int, n_children; // critical nodes, internal nodes, sum of child counts
+    unsigned max_group;         // particles in the largest critical node
+    unsigned class2_count[8];   // critical nodes per lane-mapping class (list kernel binning)
+    unsigned pad[5];
+};
+enum { ERR_COORD = 1u, ERR_COM = 2u, ERR_DIM = 4u, ERR_BOX = 8u };
+
 // ---- box size -------------------------------------------------------------------------------------------
 template <typename F>
-__global__ void k_maxabs(const F *x, const F *y, const F *z, uint32_t n, unsigned long long *out_bits, int *err)
+__global__ void k_maxabs(const F *x, const F *y, const F *z, uint32_t n, ctrl_block *ctrl)
 {
+    unsigned long long *out_bits = &ctrl->maxbits;
+    unsigned *err = &ctrl->err;
     F mx = F(0);
     bool bad = false;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -81,30 +98,65 @@ __global__ void k_maxabs(const F *x, const F *y, const F *z, uint32_t n, unsigne
     } else {
         bits = static_cast<unsigned long long>(__double_as_longlong(static_cast<double>(mx)));
     }
-    // One atomic per wavefront.
+    // One atomic per block (same-address 64-bit atomics serialise at ~10 ns each).
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const unsigned long long other = __shfl_xor(bits, o, 64);
         bits = other > bits ? other : bits;
     }
-    const bool any_bad = __ballot(bad) != 0ull;
+    __shared__ unsigned long long s_bits[4];
+    __shared__ int s_bad[4];
+    const unsigned w = threadIdx.x >> 6;
+    const bool wave_bad = __ballot(bad) != 0ull;
     if ((threadIdx.x & 63u) == 0u) {
-        if (any_bad) {
-            atomicOr(err, 1);
+        s_bits[w] = bits;
+        s_bad[w] = wave_bad;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        for (unsigned k = 1; k < blockDim.x / 64u; ++k) {
+            bits = s_bits[k] > bits ? s_bits[k] : bits;
+            s_bad[0] |= s_bad[k];
+        }
+        if (s_bad[0]) {
+            atomicOr(err, static_cast<unsigned>(ERR_COORD));
         }
         atomicMax(out_bits, bits);
     }
 }
 
+// Domain size: given, or 2 * max|coord| + 5% (tree.hpp:1306-1312 of the reference). One thread.
+template <typename F>
+__global__ void k_box(ctrl_block *ctrl, F box_in)
+{
+    F box = box_in;
+    if (box_in == F(0)) {
+        F mx;
+        if constexpr (sizeof(F) == 4) {
+            mx = __uint_as_float(static_cast<unsigned>(ctrl->maxbits));
+        } else {
+            mx = __longlong_as_double(static_cast<long long>(ctrl->maxbits));
+        }
+        F b = mx * F(2);
+        b = d_fma(b, F(1) / F(20), b);
+        if (!isfinite(b)) {
+            atomicOr(&ctrl->err, static_cast<unsigned>(ERR_BOX));
+        }
+        box = b;
+    }
+    ctrl->box = static_cast<double>(box);
+}
+
 // ---- discretise + encode ----------------------------------------------------------------------------------
 template <typename F>
-__global__ void k_encode(const F *x, const F *y, const F *z, uint32_t n, F inv_box, uint64_t *codes, uint32_t *idx,
-                         unsigned *first_bad)
+__global__ void k_encode(const F *x, const F *y, const F *z, uint32_t n, ctrl_block *ctrl, uint64_t *codes,
+                         uint32_t *idx)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) {
         return;
     }
+    const F inv_box = F(1) / static_cast<F>(ctrl->box);
     constexpr F factor = F(1u << CBITS);
     uint64_t d[3];
     const F v[3] = {x[i], y[i], z[i]};
@@ -120,7 +172,7 @@ __global__ void k_encode(const F *x, const F *y, const F *z, uint32_t n, F inv_b
         d[k] = static_cast<uint64_t>(tmp);
     }
     if (bad) {
-        atomicMin(first_bad, i);
+        atomicMax(&ctrl->bad_inv, ~i);
     }
     codes[i] = spread3(d[0]) | (spread3(d[1]) << 1) | (spread3(d[2]) << 2);
     idx[i] = i;
@@ -229,6 +281,14 @@ __global__ void k_node_counts(const uint64_t *codes, uint32_t n, const uint8_t *
     const unsigned lvl = leaf[i];
     ldiv[i] = static_cast<uint8_t>(dv);
     cnt[i] = dv <= lvl ? lvl - dv + 1u : 0u;
+    if (i == 0u) {
+        cnt[n] = 0u; // the scan runs over n + 1 values so that off[n] is the total
+    }
+}
+
+__global__ void k_pack_nodes(ctrl_block *ctrl, const uint32_t *off_n)
+{
+    ctrl->n_nonroot = *off_n;
 }
 
 // Emit the nodes whose first particle is i. off[] = exclusive scan of cnt[] (off[n] = number of non-root nodes).
@@ -287,11 +347,15 @@ __global__ void k_emit_nodes(const uint64_t *codes, uint32_t n, const uint8_t *l
 }
 
 // parent[] of every non-root node, written by the parent (children of k: k + 1, then skipping subtrees).
-__global__ void k_parents(const uint4 *topo, uint32_t n_nodes, uint32_t *parent)
+__global__ void k_parents(const uint4 *topo, uint32_t n_nodes, uint32_t *parent, uint32_t *mask)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_nodes) {
         return;
+    }
+    mask[k] = 0u; // child-octant masks are accumulated with atomicOr by k_flags
+    if (k == 0u) {
+        mask[n_nodes] = 0u;
     }
     const uint32_t last = k + topo[k].x;
     for (uint32_t c = k + 1u; c <= last; c += topo[c].x + 1u) {
@@ -351,7 +415,7 @@ __global__ void k_up_sums(const uint4 *topo, const uint64_t *ncode, uint32_t n_n
 
 template <typename F>
 __global__ void k_finalize(const uint4 *topo, const uint64_t *ncode, uint32_t n_nodes, const typename vt<F>::v4 *sums,
-                           F box, int mac, typename vt<F>::v4 *node_com, typename vt<F>::v2 *node_mac, int *err)
+                           F box, int mac, typename vt<F>::v4 *node_com, typename vt<F>::v2 *node_mac, ctrl_block *ctrl)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_nodes) {
@@ -377,7 +441,7 @@ __global__ void k_finalize(const uint4 *topo, const uint64_t *ncode, uint32_t n_
         com[0] = s.x * inv, com[1] = s.y * inv, com[2] = s.z * inv;
     }
     if (!(isfinite(com[0]) && isfinite(com[1]) && isfinite(com[2]) && isfinite(s.w))) {
-        atomicOr(err, 2);
+        atomicOr(&ctrl->err, static_cast<unsigned>(ERR_COM));
     }
     typename vt<F>::v4 c;
     c.x = com[0], c.y = com[1], c.z = com[2], c.w = s.w;
@@ -394,14 +458,25 @@ __global__ void k_finalize(const uint4 *topo, const uint64_t *ncode, uint32_t n_
         mp.y = sqrt(d2);
     }
     if (!(isfinite(mp.x) && isfinite(mp.y))) {
-        atomicOr(err, 4);
+        atomicOr(&ctrl->err, static_cast<unsigned>(ERR_DIM));
     }
     node_mac[k] = mp;
 }
 
 // ---- critical nodes, child masks, records -----------------------------------------------------------------
+// Three counters scanned together: critical nodes, internal nodes, children.
+struct tri {
+    uint32_t a, b, c;
+};
+struct tri_sum {
+    __host__ __device__ tri operator()(const tri &x, const tri &y) const
+    {
+        return tri{x.a + y.a, x.b + y.b, x.c + y.c};
+    }
+};
+
 __global__ void k_flags(const uint4 *topo, const uint64_t *ncode, const uint32_t *parent, uint32_t n_nodes,
-                        uint32_t ncrit_clamped, uint32_t *is_crit, uint32_t *is_internal, uint32_t *mask)
+                        uint32_t ncrit_clamped, tri *flags, uint32_t *mask)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_nodes) {
@@ -409,30 +484,39 @@ __global__ void k_flags(const uint4 *topo, const uint64_t *ncode, const uint32_t
     }
     auto cand = [&](uint32_t j) { return (topo[j].z - topo[j].y) <= ncrit_clamped || topo[j].x == 0u; };
     const bool c = cand(k);
-    is_crit[k] = (c && (k == 0u || !cand(parent[k]))) ? 1u : 0u;
-    is_internal[k] = topo[k].x != 0u ? 1u : 0u;
+    flags[k].a = (c && (k == 0u || !cand(parent[k]))) ? 1u : 0u;
+    flags[k].b = topo[k].x != 0u ? 1u : 0u;
     if (k != 0u) {
         atomicOr(&mask[parent[k]], 1u << static_cast<unsigned>(ncode[k] & 7ull));
+    } else {
+        flags[n_nodes] = tri{0u, 0u, 0u};
     }
 }
 
-__global__ void k_popc(const uint32_t *mask, uint32_t n, uint32_t *out)
+__global__ void k_popc(const uint32_t *mask, uint32_t n_nodes, tri *flags)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) {
-        out[k] = static_cast<uint32_t>(__popc(mask[k]));
+    if (k < n_nodes) {
+        flags[k].c = static_cast<uint32_t>(__popc(mask[k]));
     }
+}
+
+__global__ void k_pack_counts(ctrl_block *ctrl, const tri *total)
+{
+    ctrl->n_crit = total->a;
+    ctrl->n_int = total->b;
+    ctrl->n_children = total->c;
 }
 
 template <typename F>
-__global__ void k_crit(const uint4 *topo, const uint32_t *is_crit, const uint32_t *crit_off, uint32_t n_nodes,
+__global__ void k_crit(const uint4 *topo, const tri *flags, const tri *offs, uint32_t n_nodes,
                        const typename vt<F>::v4 *part4, uint4 *crit, typename vt<F>::v4 *boxes)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_nodes || !is_crit[k]) {
+    if (k >= n_nodes || !flags[k].a) {
         return;
     }
-    const uint32_t g = crit_off[k], b = topo[k].y, e = topo[k].z;
+    const uint32_t g = offs[k].a, b = topo[k].y, e = topo[k].z;
     crit[g] = make_uint4(b, e, k, e - b);
     typename vt<F>::v4 lo = part4[b], hi = lo;
     for (uint32_t i = b + 1u; i < e; ++i) {
@@ -447,7 +531,7 @@ __global__ void k_crit(const uint4 *topo, const uint32_t *is_crit, const uint32_
 
 template <typename F>
 __global__ void k_records(uint4 *topo, const uint64_t *ncode, const uint32_t *parent, const uint32_t *mask,
-                          const uint32_t *child_off, const uint32_t *slot_off, uint32_t n_nodes,
+                          const tri *offs, uint32_t n_nodes,
                           const typename vt<F>::v4 *node_com, const typename vt<F>::v2 *node_mac, node_rec<F> *recs,
                           uint32_t *child_tab)
 {
@@ -460,8 +544,8 @@ __global__ void k_records(uint4 *topo, const uint64_t *ncode, const uint32_t *pa
         const uint32_t p = parent[k];
         const unsigned digit = static_cast<unsigned>(ncode[k] & 7ull);
         const uint32_t rank = static_cast<uint32_t>(__popc(mask[p] & ((1u << digit) - 1u)));
-        rec = 1u + child_off[p] + rank; // children of p occupy records [1 + child_off[p], ...)
-        child_tab[static_cast<size_t>(slot_off[p]) * 8u + rank] = k;
+        rec = 1u + offs[p].c + rank; // children of p occupy records [1 + offs[p].c, ...)
+        child_tab[static_cast<size_t>(offs[p].b) * 8u + rank] = k;
     }
     const uint4 t = topo[k];
     node_rec<F> r;
@@ -471,15 +555,91 @@ __global__ void k_records(uint4 *topo, const uint64_t *ncode, const uint32_t *pa
     r.nch = t.x;
     r.pad[0] = r.pad[1] = 0u;
     if (t.x != 0u) {
-        r.a = 1u + child_off[k];
+        r.a = 1u + offs[k].c;
         r.b = static_cast<uint32_t>(__popc(mask[k]));
-        topo[k].w = slot_off[k];
+        topo[k].w = offs[k].b;
     } else {
         r.a = t.y;
         r.b = t.z;
         topo[k].w = 0xffffffffu;
     }
     recs[rec] = r;
+}
+
+// ---- lane-mapping classes of the critical nodes (rk_common.hpp: class2_of), binned on the device -------------
+// Stable multi-bin partition: per-block histograms, a serial scan per bin over the blocks, then a scatter that
+// ranks every group inside its block with ballots. Group ids stay ascending inside each class (locality).
+constexpr unsigned NBIN = 8;
+static_assert(NBIN >= static_cast<unsigned>(n_classes));
+
+__global__ void k_bin_count(const uint4 *crit, uint32_t n_crit, uint32_t *block_hist, ctrl_block *ctrl)
+{
+    __shared__ uint32_t h[NBIN];
+    __shared__ uint32_t mx;
+    if (threadIdx.x < NBIN) {
+        h[threadIdx.x] = 0u;
+    }
+    if (threadIdx.x == 0u) {
+        mx = 0u;
+    }
+    __syncthreads();
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n_crit) {
+        const uint32_t size = crit[g].w;
+        atomicAdd(&h[class2_of_compute(size)], 1u);
+        atomicMax(&mx, size);
+    }
+    __syncthreads();
+    if (threadIdx.x < NBIN) {
+        block_hist[blockIdx.x * NBIN + threadIdx.x] = h[threadIdx.x];
+    }
+    if (threadIdx.x == 0u) {
+        atomicMax(&ctrl->max_group, mx);
+    }
+}
+
+__global__ void k_bin_scan(uint32_t *block_hist, uint32_t n_blocks, ctrl_block *ctrl)
+{
+    const uint32_t c = threadIdx.x; // one thread per bin
+    uint32_t run = 0u;
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+        const uint32_t t = block_hist[b * NBIN + c];
+        block_hist[b * NBIN + c] = run;
+        run += t;
+    }
+    ctrl->class2_count[c] = run;
+}
+
+__global__ void __launch_bounds__(256) k_bin_scatter(const uint4 *crit, uint32_t n_crit, const uint32_t *block_base,
+                                                     const ctrl_block *ctrl, uint32_t *lists)
+{
+    __shared__ uint32_t wave_cnt[4][NBIN];
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const unsigned c = g < n_crit ? static_cast<unsigned>(class2_of_compute(crit[g].w)) : NBIN;
+    uint32_t rank = 0u;
+#pragma unroll
+    for (unsigned b = 0; b < NBIN; ++b) {
+        const unsigned long long m = __ballot(c == b);
+        if (c == b) {
+            rank = static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
+        }
+        if (lane == 0u) {
+            wave_cnt[w][b] = static_cast<uint32_t>(__popcll(m));
+        }
+    }
+    __syncthreads();
+    if (c >= NBIN) {
+        return;
+    }
+    uint32_t pos = block_base[blockIdx.x * NBIN + c] + rank;
+    for (unsigned k = 0; k < w; ++k) {
+        pos += wave_cnt[k][c];
+    }
+    for (unsigned b = 0; b < c; ++b) {
+        pos += ctrl->class2_count[b];
+    }
+    lists[pos] = g;
 }
 
 struct dev_free {
@@ -506,13 +666,20 @@ inline unsigned nblk(size_t n, unsigned bs = 256)
 // Exclusive prefix sum of n values into out[0..n] (out[n] = total).
 void exclusive_scan(const uint32_t *in, uint32_t *out, size_t n, hipStream_t st)
 {
-    RK_HIP(hipMemsetAsync(out + n, 0, sizeof(uint32_t), st));
     size_t tb = 0;
     RK_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, in, out, static_cast<int>(n + 1), st));
     auto tmp = dalloc<unsigned char>(tb);
     // Scan n + 1 elements with a zero appended: requires in[n] readable; callers over-allocate by one and zero it.
     RK_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.get(), tb, in, out, static_cast<int>(n + 1), st));
-    RK_HIP(hipStreamSynchronize(st));
+    // No synchronisation: the scratch goes back to the block cache and is only ever reused on this stream.
+}
+
+void exclusive_scan(const tri *in, tri *out, size_t n, hipStream_t st)
+{
+    size_t tb = 0;
+    RK_HIP(hipcub::DeviceScan::ExclusiveScan(nullptr, tb, in, out, tri_sum{}, tri{0u, 0u, 0u}, static_cast<int>(n + 1), st));
+    auto tmp = dalloc<unsigned char>(tb);
+    RK_HIP(hipcub::DeviceScan::ExclusiveScan(tmp.get(), tb, in, out, tri_sum{}, tri{0u, 0u, 0u}, static_cast<int>(n + 1), st));
 }
 
 } // namespace bld
@@ -550,54 +717,71 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     };
     const view dx{in[0]}, dy{in[1]}, dz{in[2]}, dm{in[3]};
 
-    auto d_err = dalloc<int>(1);
-    auto d_bits = dalloc<unsigned long long>(1);
-    auto d_bad = dalloc<unsigned>(1);
-    RK_HIP(hipMemsetAsync(d_err.get(), 0, sizeof(int), st));
-    RK_HIP(hipMemsetAsync(d_bits.get(), 0, sizeof(unsigned long long), st));
-    RK_HIP(hipMemsetAsync(d_bad.get(), 0xff, sizeof(unsigned), st));
+    auto ctrl = dalloc<ctrl_block>(1);
+    ctrl_block hc{};
+    RK_HIP(hipMemsetAsync(ctrl.get(), 0, sizeof(ctrl_block), st));
+    const auto fetch_ctrl = [&] { RK_HIP(hipMemcpy(&hc, ctrl.get(), sizeof(hc), hipMemcpyDeviceToHost)); };
 
-    // ---- box size ----
-    F box = static_cast<F>(box_size_in);
+    // ---- box size, encode, sort, permute, leaf levels, node counts: no host round trip ----
     s.box_deduced = box_size_in == 0.;
     if (s.box_deduced) {
-        hipLaunchKernelGGL((k_maxabs<F>), dim3(std::min(nblk(n), 2048u)), dim3(256), 0, st, dx.get(), dy.get(), dz.get(), n,
-                           d_bits.get(), d_err.get());
-        unsigned long long bits = 0;
-        int err = 0;
-        RK_HIP(hipMemcpy(&bits, d_bits.get(), sizeof(bits), hipMemcpyDeviceToHost));
-        RK_HIP(hipMemcpy(&err, d_err.get(), sizeof(err), hipMemcpyDeviceToHost));
-        if (err) {
-            throw error(RK_EINVAL, "While trying to automatically determine the domain size, a non-finite coordinate "
-                                   "was encountered");
-        }
-        F mx;
-        if constexpr (sizeof(F) == 4) {
-            const auto b32 = static_cast<uint32_t>(bits);
-            std::memcpy(&mx, &b32, 4);
-        } else {
-            std::memcpy(&mx, &bits, 8);
-        }
-        F b = mx * F(2);
-        b = std::fma(b, F(1) / F(20), b); // 5% slack, tree.hpp:1310-1312
-        if (!std::isfinite(b)) {
-            throw error(RK_EINVAL, "The automatic deduction of the domain size produced the non-finite value "
-                                       + std::to_string(b));
-        }
-        box = b;
+        hipLaunchKernelGGL((k_maxabs<F>), dim3(std::min(nblk(n), 1024u)), dim3(256), 0, st, dx.get(), dy.get(), dz.get(), n,
+                           ctrl.get());
     }
-    s.box_size = static_cast<double>(box);
-    const F inv_box = F(1) / box;
-
-    // ---- encode + sort ----
+    hipLaunchKernelGGL((k_box<F>), dim3(1), dim3(1), 0, st, ctrl.get(), static_cast<F>(box_size_in));
     auto keys_in = dalloc<uint64_t>(n), keys_out = dalloc<uint64_t>(n);
     auto vals_in = dalloc<uint32_t>(n), vals_out = dalloc<uint32_t>(n);
-    hipLaunchKernelGGL((k_encode<F>), dim3(nblk(n)), dim3(256), 0, st, dx.get(), dy.get(), dz.get(), n, inv_box,
-                       keys_in.get(), vals_in.get(), d_bad.get());
-    unsigned first_bad = 0xffffffffu;
-    RK_HIP(hipMemcpy(&first_bad, d_bad.get(), sizeof(first_bad), hipMemcpyDeviceToHost));
-    if (first_bad != 0xffffffffu) {
+    hipLaunchKernelGGL((k_encode<F>), dim3(nblk(n)), dim3(256), 0, st, dx.get(), dy.get(), dz.get(), n, ctrl.get(),
+                       keys_in.get(), vals_in.get());
+    {
+        size_t tb = 0;
+        RK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys_in.get(), keys_out.get(), vals_in.get(),
+                                                  vals_out.get(), static_cast<int>(n), 0, 63, st));
+        auto tmp = dalloc<unsigned char>(tb);
+        RK_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.get(), tb, keys_in.get(), keys_out.get(), vals_in.get(),
+                                                  vals_out.get(), static_cast<int>(n), 0, 63, st));
+    }
+    keys_in.reset();
+    vals_in.reset();
+    void *p4 = pool_alloc(std::max<size_t>(n, 1) * sizeof(v4));
+    s.buf[RK_BUF_PART4] = p4;
+    s.buf_bytes[RK_BUF_PART4] = static_cast<int64_t>(n * sizeof(v4));
+    hipLaunchKernelGGL((k_permute<F>), dim3(nblk(n)), dim3(256), 0, st, dx.get(), dy.get(), dz.get(), dm.get(),
+                       vals_out.get(), n, static_cast<v4 *>(p4));
+    s.bld_codes = keys_out.release();
+    s.bld_perm = vals_out.release();
+    const auto *codes = static_cast<const uint64_t *>(s.bld_codes);
+
+    const auto mln = static_cast<uint32_t>(std::min<uint64_t>(max_leaf_n, 0xffffffffu));
+    auto leaf = dalloc<uint8_t>(n), ldiv = dalloc<uint8_t>(n);
+    auto cnt = dalloc<uint32_t>(static_cast<size_t>(n) + 1), off = dalloc<uint32_t>(static_cast<size_t>(n) + 1);
+    if (mln <= 64u) {
+        // ldiv doubles as the window scratch until k_node_counts fills it.
+        hipLaunchKernelGGL(k_windows, dim3(nblk(n)), dim3(256), 0, st, codes, n, mln, ldiv.get());
+        hipLaunchKernelGGL(k_leaf_levels_windows, dim3(nblk(n)), dim3(256), 0, st, ldiv.get(), n, mln, leaf.get());
+    } else {
+        hipLaunchKernelGGL(k_leaf_levels_search, dim3(nblk(n)), dim3(256), 0, st, codes, n, mln, leaf.get());
+    }
+    hipLaunchKernelGGL(k_node_counts, dim3(nblk(n)), dim3(256), 0, st, codes, n, leaf.get(), ldiv.get(), cnt.get());
+    exclusive_scan(cnt.get(), off.get(), n, st);
+    hipLaunchKernelGGL(k_pack_nodes, dim3(1), dim3(1), 0, st, ctrl.get(), off.get() + n);
+
+    // ---- first round trip: input errors (in the reference's order), box, node count ----
+    fetch_ctrl();
+    if (hc.err & ERR_COORD) {
+        throw error(RK_EINVAL, "While trying to automatically determine the domain size, a non-finite coordinate "
+                               "was encountered");
+    }
+    const F box = static_cast<F>(hc.box);
+    if (hc.err & ERR_BOX) {
+        throw error(RK_EINVAL, "The automatic deduction of the domain size produced the non-finite value "
+                                   + std::to_string(box));
+    }
+    s.box_size = hc.box;
+    if (hc.bad_inv != 0u) {
         // Rebuild the reference's message (tree.hpp:398-413) for the first offending coordinate.
+        const unsigned first_bad = ~hc.bad_inv;
+        const F inv_box = F(1) / box;
         for (int k = 0; k < 3; ++k) {
             F xv;
             RK_HIP(hipMemcpy(&xv, in[k] + first_bad, sizeof(F), hipMemcpyDeviceToHost));
@@ -619,49 +803,10 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
         }
         throw error(RK_EINVAL, bad_coord_msg);
     }
-    {
-        size_t tb = 0;
-        RK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys_in.get(), keys_out.get(), vals_in.get(),
-                                                  vals_out.get(), static_cast<int>(n), 0, 63, st));
-        auto tmp = dalloc<unsigned char>(tb);
-        RK_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.get(), tb, keys_in.get(), keys_out.get(), vals_in.get(),
-                                                  vals_out.get(), static_cast<int>(n), 0, 63, st));
-        RK_HIP(hipStreamSynchronize(st));
-    }
-    keys_in.reset();
-    vals_in.reset();
-
-    // ---- particles in Morton order ----
-    void *p4 = pool_alloc(std::max<size_t>(n, 1) * sizeof(v4));
-    s.buf[RK_BUF_PART4] = p4;
-    s.buf_bytes[RK_BUF_PART4] = static_cast<int64_t>(n * sizeof(v4));
-    hipLaunchKernelGGL((k_permute<F>), dim3(nblk(n)), dim3(256), 0, st, dx.get(), dy.get(), dz.get(), dm.get(),
-                       vals_out.get(), n, static_cast<v4 *>(p4));
-    RK_HIP(hipStreamSynchronize(st));
     for (auto &o : own) {
         o.reset();
     }
-    s.bld_codes = keys_out.release();
-    s.bld_perm = vals_out.release();
-    const auto *codes = static_cast<const uint64_t *>(s.bld_codes);
-
-    // ---- topology ----
-    const auto mln = static_cast<uint32_t>(std::min<uint64_t>(max_leaf_n, 0xffffffffu));
-    auto leaf = dalloc<uint8_t>(n), ldiv = dalloc<uint8_t>(n);
-    auto cnt = dalloc<uint32_t>(static_cast<size_t>(n) + 1), off = dalloc<uint32_t>(static_cast<size_t>(n) + 1);
-    RK_HIP(hipMemsetAsync(cnt.get() + n, 0, sizeof(uint32_t), st));
-    if (mln <= 64u) {
-        // ldiv doubles as the window scratch until k_node_counts fills it.
-        hipLaunchKernelGGL(k_windows, dim3(nblk(n)), dim3(256), 0, st, codes, n, mln, ldiv.get());
-        hipLaunchKernelGGL(k_leaf_levels_windows, dim3(nblk(n)), dim3(256), 0, st, ldiv.get(), n, mln, leaf.get());
-    } else {
-        hipLaunchKernelGGL(k_leaf_levels_search, dim3(nblk(n)), dim3(256), 0, st, codes, n, mln, leaf.get());
-    }
-    hipLaunchKernelGGL(k_node_counts, dim3(nblk(n)), dim3(256), 0, st, codes, n, leaf.get(), ldiv.get(), cnt.get());
-    exclusive_scan(cnt.get(), off.get(), n, st);
-    uint32_t n_nonroot = 0;
-    RK_HIP(hipMemcpy(&n_nonroot, off.get() + n, sizeof(uint32_t), hipMemcpyDeviceToHost));
-    const size_t nn = static_cast<size_t>(n_nonroot) + 1;
+    const size_t nn = static_cast<size_t>(hc.n_nonroot) + 1;
     if (nn >= max_list_nodes) {
         throw error(RK_EOVERFLOW, "The number of tree nodes (" + std::to_string(nn)
                                       + ") exceeds the 2^29 limit of the traversal kernel's node references");
@@ -679,9 +824,10 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     s.bld_node_code = pool_alloc(nn * sizeof(uint64_t));
     auto *ncode = static_cast<uint64_t *>(s.bld_node_code);
     auto parent = dalloc<uint32_t>(nn);
+    auto mask = dalloc<uint32_t>(nn + 1);
     hipLaunchKernelGGL(k_emit_nodes, dim3(nblk(n)), dim3(256), 0, st, codes, n, leaf.get(), ldiv.get(), off.get(), topo,
                        ncode, parent.get());
-    hipLaunchKernelGGL(k_parents, dim3(nblk(nn)), dim3(256), 0, st, topo, static_cast<uint32_t>(nn), parent.get());
+    hipLaunchKernelGGL(k_parents, dim3(nblk(nn)), dim3(256), 0, st, topo, static_cast<uint32_t>(nn), parent.get(), mask.get());
     leaf.reset(), ldiv.reset(), cnt.reset(), off.reset();
 
     // ---- node properties ----
@@ -692,40 +838,29 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
         hipLaunchKernelGGL((k_up_sums<F>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, static_cast<uint32_t>(nn),
                            static_cast<unsigned>(lvl), sums.get());
     }
-    RK_HIP(hipMemsetAsync(d_err.get(), 0, sizeof(int), st));
     hipLaunchKernelGGL((k_finalize<F>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, static_cast<uint32_t>(nn), sums.get(),
-                       box, s.mac, node_com, node_mac, d_err.get());
-    {
-        int err = 0;
-        RK_HIP(hipMemcpy(&err, d_err.get(), sizeof(err), hipMemcpyDeviceToHost));
-        if (err & 2) {
-            throw error(RK_EINVAL, "The computation of the centre of mass of a node produced a non-finite value");
-        }
-        if (err & 4) {
-            throw error(RK_EINVAL, "The computation of the dimension of a node produced a non-finite value");
-        }
-    }
+                       box, s.mac, node_com, node_mac, ctrl.get());
     sums.reset();
 
-    // ---- critical nodes, child masks ----
+    // ---- critical nodes, child masks: one scan of three counters ----
     const auto ncrit_c = static_cast<uint32_t>(std::min<uint64_t>(s.ncrit, 0xffffffffu));
-    auto is_crit = dalloc<uint32_t>(nn + 1), is_int = dalloc<uint32_t>(nn + 1), mask = dalloc<uint32_t>(nn + 1),
-         nchild = dalloc<uint32_t>(nn + 1);
-    auto crit_off = dalloc<uint32_t>(nn + 1), slot_off = dalloc<uint32_t>(nn + 1), child_off = dalloc<uint32_t>(nn + 1);
-    RK_HIP(hipMemsetAsync(mask.get(), 0, (nn + 1) * sizeof(uint32_t), st));
-    RK_HIP(hipMemsetAsync(is_crit.get() + nn, 0, sizeof(uint32_t), st));
-    RK_HIP(hipMemsetAsync(is_int.get() + nn, 0, sizeof(uint32_t), st));
+    auto flags = dalloc<tri>(nn + 1), offs = dalloc<tri>(nn + 1);
     hipLaunchKernelGGL(k_flags, dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, parent.get(), static_cast<uint32_t>(nn), ncrit_c,
-                       is_crit.get(), is_int.get(), mask.get());
-    hipLaunchKernelGGL(k_popc, dim3(nblk(nn + 1)), dim3(256), 0, st, mask.get(), static_cast<uint32_t>(nn + 1), nchild.get());
-    exclusive_scan(is_crit.get(), crit_off.get(), nn, st);
-    exclusive_scan(is_int.get(), slot_off.get(), nn, st);
-    exclusive_scan(nchild.get(), child_off.get(), nn, st);
-    uint32_t n_crit = 0, n_int = 0, n_children_total = 0;
-    RK_HIP(hipMemcpy(&n_crit, crit_off.get() + nn, sizeof(uint32_t), hipMemcpyDeviceToHost));
-    RK_HIP(hipMemcpy(&n_int, slot_off.get() + nn, sizeof(uint32_t), hipMemcpyDeviceToHost));
-    RK_HIP(hipMemcpy(&n_children_total, child_off.get() + nn, sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if (static_cast<size_t>(n_children_total) + 1 != nn) {
+                       flags.get(), mask.get());
+    hipLaunchKernelGGL(k_popc, dim3(nblk(nn)), dim3(256), 0, st, mask.get(), static_cast<uint32_t>(nn), flags.get());
+    exclusive_scan(flags.get(), offs.get(), nn, st);
+    hipLaunchKernelGGL(k_pack_counts, dim3(1), dim3(1), 0, st, ctrl.get(), offs.get() + nn);
+
+    // ---- second round trip: node-property errors, counts ----
+    fetch_ctrl();
+    if (hc.err & ERR_COM) {
+        throw error(RK_EINVAL, "The computation of the centre of mass of a node produced a non-finite value");
+    }
+    if (hc.err & ERR_DIM) {
+        throw error(RK_EINVAL, "The computation of the dimension of a node produced a non-finite value");
+    }
+    const uint32_t n_crit = hc.n_crit, n_int = hc.n_int;
+    if (static_cast<size_t>(hc.n_children) + 1 != nn) {
         throw error(RK_ERUNTIME, "internal error: inconsistent node count in the device tree build");
     }
     s.n_internal = n_int;
@@ -733,12 +868,37 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     auto *boxes = static_cast<v4 *>(alloc_buf(RK_BUF_CRIT_BOX, static_cast<size_t>(n_crit) * 2 * sizeof(v4)));
     auto *child_tab = static_cast<uint32_t *>(alloc_buf(RK_BUF_CHILD, static_cast<size_t>(n_int) * 8 * sizeof(uint32_t)));
     RK_HIP(hipMemsetAsync(child_tab, 0, std::max<size_t>(static_cast<size_t>(n_int) * 8 * sizeof(uint32_t), 16), st));
-    hipLaunchKernelGGL((k_crit<F>), dim3(nblk(nn)), dim3(256), 0, st, topo, is_crit.get(), crit_off.get(),
+    hipLaunchKernelGGL((k_crit<F>), dim3(nblk(nn)), dim3(256), 0, st, topo, flags.get(), offs.get(),
                        static_cast<uint32_t>(nn), static_cast<const v4 *>(p4), crit, boxes);
-    hipLaunchKernelGGL((k_records<F>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, parent.get(), mask.get(), child_off.get(),
-                       slot_off.get(), static_cast<uint32_t>(nn), node_com, node_mac, recs, child_tab);
-    RK_HIP(hipStreamSynchronize(st));
+    hipLaunchKernelGGL((k_records<F>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, parent.get(), mask.get(), offs.get(),
+                       static_cast<uint32_t>(nn), node_com, node_mac, recs, child_tab);
+
+    // ---- group lists of the list kernel (second half of RK_BUF_CLASS; the first half, the cross-check kernel's
+    // binning, is filled with the host mirrors on demand) ----
+    auto *lists = static_cast<uint32_t *>(alloc_buf(RK_BUF_CLASS, static_cast<size_t>(n_crit) * 2 * sizeof(uint32_t)));
+    const unsigned nb = nblk(n_crit);
+    auto hist = dalloc<uint32_t>(static_cast<size_t>(nb) * NBIN);
+    hipLaunchKernelGGL(k_bin_count, dim3(nb), dim3(256), 0, st, crit, n_crit, hist.get(), ctrl.get());
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(NBIN), 0, st, hist.get(), nb, ctrl.get());
+    hipLaunchKernelGGL(k_bin_scatter, dim3(nb), dim3(256), 0, st, crit, n_crit, hist.get(), ctrl.get(), lists + n_crit);
+
+    // ---- third round trip: class sizes (also the final synchronisation) ----
+    fetch_ctrl();
     RK_HIP(hipGetLastError());
+    s.n_crit = n_crit;
+    s.max_group = hc.max_group;
+    s.mirrors_valid = false;
+    s.crit_begin.clear();
+    s.crit_end.clear();
+    s.class_off[0] = 0;
+    s.class2_off[0] = n_crit;
+    for (int c = 0; c < n_classes; ++c) {
+        s.class_list[c].clear();
+        s.class2_list[c].clear();
+        s.class_off[c + 1] = 0;
+        s.class2_count[c] = hc.class2_count[c];
+        s.class2_off[c + 1] = s.class2_off[c] + s.class2_count[c];
+    }
 }
 
 template void build_device<float>(rk_state &, const void *const[4], bool, int64_t, double, uint64_t, std::string &);

@@ -65,7 +65,7 @@ inline int class_of(int64_t size)
 // Variant 2 (LDS interaction lists): each lane holds R targets, TP = ceil(T / R) target slots and
 // NS = floor(64 / TP) source splits share the wave. The dense phase costs R / NS lane-iterations per
 // source; pick the R that minimises it (ties: fewer registers).
-inline int class2_of_compute(int64_t size)
+__host__ __device__ inline int class2_of_compute(int64_t size)
 {
     if (size > 64 * RK_MAX_R) return big_class;
     int best = -1;
@@ -188,6 +188,11 @@ struct rk_state {
     void *buf[RK_NBUF] = {};
     int64_t buf_bytes[RK_NBUF] = {};
     // Host mirrors used to map a particle range onto groups.
+    // Host mirrors of the critical-node ranges and class lists. States built on the device bin their groups on the
+    // device too and only fetch the per-class counts; the mirrors are then filled on first use (sub-range calls,
+    // variant 1, export, rk_state_crit_ranges): mirrors_valid says which.
+    bool mirrors_valid = true;
+    int64_t class2_count[rk::n_classes] = {};
     std::vector<int64_t> crit_begin, crit_end;
     std::vector<uint32_t> class_list[rk::n_classes]; // ascending group ids per class (variant 1 binning)
     int64_t class_off[rk::n_classes + 1] = {};       // offsets into the concatenated device list

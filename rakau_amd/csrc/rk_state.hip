@@ -155,8 +155,10 @@ void build_host_mirrors(rk_state &s, const std::vector<uint4> &crit)
     }
     s.class2_off[0] = s.class_off[rk::n_classes];
     for (int c = 0; c < rk::n_classes; ++c) {
-        s.class2_off[c + 1] = s.class2_off[c] + static_cast<int64_t>(s.class2_list[c].size());
+        s.class2_count[c] = static_cast<int64_t>(s.class2_list[c].size());
+        s.class2_off[c + 1] = s.class2_off[c] + s.class2_count[c];
     }
+    s.mirrors_valid = true;
 }
 
 std::vector<uint32_t> concat_class_lists(const rk_state &s)
@@ -169,6 +171,29 @@ std::vector<uint32_t> concat_class_lists(const rk_state &s)
         lists.insert(lists.end(), l.begin(), l.end());
     }
     return lists;
+}
+
+// Fill the host mirrors of a device-built state (and the cross-check kernel's half of the class lists) on first use.
+void ensure_mirrors(rk_state &s)
+{
+    if (s.mirrors_valid) {
+        return;
+    }
+    std::vector<uint4> crit(static_cast<size_t>(s.n_crit));
+    if (!crit.empty()) {
+        RK_HIP(hipMemcpy(crit.data(), s.buf[RK_BUF_CRIT], crit.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+    }
+    int64_t dev_off[rk::n_classes + 1];
+    std::copy(s.class2_off, s.class2_off + rk::n_classes + 1, dev_off);
+    build_host_mirrors(s, crit);
+    if (!std::equal(dev_off, dev_off + rk::n_classes + 1, s.class2_off)) {
+        throw rk::error(RK_ERUNTIME, "internal error: device and host binning of the critical nodes disagree");
+    }
+    const std::vector<uint32_t> lists = concat_class_lists(s);
+    if (!lists.empty()) {
+        RK_HIP(hipMemcpy(s.buf[RK_BUF_CLASS], lists.data(), lists.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    s.mirrors_valid = true;
 }
 
 template <typename F>
@@ -365,13 +390,24 @@ void check_device(int device)
 }
 
 // Map [p_begin, p_end) onto per-class slices of the group lists.
-void range_to_classes(const rk_state &s, int64_t p_begin, int64_t p_end, int64_t cb[rk::n_classes],
-                      int64_t ce[rk::n_classes], bool variant2 = false)
+void range_to_classes(rk_state &s, int64_t p_begin, int64_t p_end, int64_t cb[rk::n_classes],
+                      int64_t ce[rk::n_classes], int64_t &g0_out, int64_t &g1_out, bool variant2 = false)
 {
     if (p_begin < 0 || p_end < p_begin || p_end > s.nparts) {
         throw rk::error(RK_EINVAL, "invalid particle range [" + std::to_string(p_begin) + ", " + std::to_string(p_end)
                                        + ") for a tree with " + std::to_string(s.nparts) + " particles");
     }
+    if (!s.mirrors_valid && variant2 && p_begin == 0 && p_end == s.nparts) {
+        // Whole tree on a device-built state: the per-class counts are all that is needed.
+        for (int c = 0; c < rk::n_classes; ++c) {
+            cb[c] = 0;
+            ce[c] = s.class2_count[c];
+        }
+        g0_out = 0;
+        g1_out = s.n_crit;
+        return;
+    }
+    ensure_mirrors(s);
     // First group starting at or after p_begin / p_end.
     const auto g0 = std::lower_bound(s.crit_begin.begin(), s.crit_begin.end(), p_begin) - s.crit_begin.begin();
     const auto g1 = std::lower_bound(s.crit_begin.begin(), s.crit_begin.end(), p_end) - s.crit_begin.begin();
@@ -386,6 +422,8 @@ void range_to_classes(const rk_state &s, int64_t p_begin, int64_t p_end, int64_t
         cb[c] = std::lower_bound(l.begin(), l.end(), static_cast<uint32_t>(g0)) - l.begin();
         ce[c] = std::lower_bound(l.begin(), l.end(), static_cast<uint32_t>(g1)) - l.begin();
     }
+    g0_out = g0;
+    g1_out = g1;
 }
 
 template <typename F>
@@ -411,10 +449,8 @@ template <typename F>
 void census_impl(rk_state &s, int64_t p_begin, int64_t p_end, double mac_value, uint64_t counts[4],
                  uint64_t *per_group = nullptr)
 {
-    int64_t cb[rk::n_classes], ce[rk::n_classes];
-    range_to_classes(s, p_begin, p_end, cb, ce); // validates the range
-    const auto g0 = std::lower_bound(s.crit_begin.begin(), s.crit_begin.end(), p_begin) - s.crit_begin.begin();
-    const auto g1 = std::lower_bound(s.crit_begin.begin(), s.crit_begin.end(), p_end) - s.crit_begin.begin();
+    int64_t cb[rk::n_classes], ce[rk::n_classes], g0 = 0, g1 = 0;
+    range_to_classes(s, p_begin, p_end, cb, ce, g0, g1, true); // validates the range
     auto p = base_params<F>(s, mac_value, 1., 0.);
     const size_t ng = per_group ? static_cast<size_t>(g1 - g0) : 0;
     struct pool_block {
@@ -440,8 +476,8 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
 {
     // Variant 2 (LDS interaction lists) is the default; variant 1 is kept for cross-checks.
     const bool v2 = s.variant != 1;
-    int64_t cb[rk::n_classes], ce[rk::n_classes];
-    range_to_classes(s, p_begin, p_end, cb, ce, v2);
+    int64_t cb[rk::n_classes], ce[rk::n_classes], g_lo = 0, g_hi = 0;
+    range_to_classes(s, p_begin, p_end, cb, ce, g_lo, g_hi, v2);
     auto p = base_params<F>(s, mac_value, G, eps2);
     for (int k = 0; k < rk::nres_of(q); ++k) {
         p.out[k] = static_cast<F *>(d_out[k]);
@@ -534,8 +570,6 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
             const char *e = std::getenv("RK_GRAPH"); // 0 disables the hipGraph replay of a repeated call
             return !(e && std::atoi(e) == 0);
         }();
-        const int64_t g_lo = std::lower_bound(s.crit_begin.begin(), s.crit_begin.end(), p_begin) - s.crit_begin.begin();
-        const int64_t g_hi = std::lower_bound(s.crit_begin.begin(), s.crit_begin.end(), p_end) - s.crit_begin.begin();
         // The launch sequence of one call: pre-pass, then the per-class kernels forked onto side streams (so that
         // the tail of one overlaps the others), joined back, then the big-group fallback. Stream-ordered work only,
         // so it can be recorded into a hipGraph.
@@ -767,6 +801,8 @@ int rk_state_crit_ranges(const rk_state *s, int64_t *begin_end)
         if (!s || !begin_end) {
             throw rk::error(RK_EINVAL, "null argument");
         }
+        device_guard dg(s->device);
+        ensure_mirrors(*const_cast<rk_state *>(s));
         for (int64_t i = 0; i < s->n_crit; ++i) {
             begin_end[2 * i] = s->crit_begin[static_cast<size_t>(i)];
             begin_end[2 * i + 1] = s->crit_end[static_cast<size_t>(i)];
@@ -855,6 +891,10 @@ int rk_state_export(const rk_state *s, int *count, void **ptrs, int64_t *bytes, 
         if (!s || !count || !ptrs || !bytes || !meta) {
             throw rk::error(RK_EINVAL, "null argument");
         }
+        {
+            device_guard dg(s->device);
+            ensure_mirrors(*const_cast<rk_state *>(s)); // the class-list buffer must be complete before it travels
+        }
         *count = RK_NBUF;
         for (int i = 0; i < RK_NBUF; ++i) {
             ptrs[i] = s->buf[i];
@@ -942,20 +982,12 @@ static void fill_from_build(rk_state &s, const void *const parts[4], bool on_dev
         } else {
             rk::build_device<double>(s, parts, on_device, nparts, box_size, s.max_leaf_n, msg);
         }
-        // Host mirrors + class lists from the critical-node array.
-        crit.resize(static_cast<size_t>(s.buf_bytes[RK_BUF_CRIT]) / sizeof(uint4));
-        if (!crit.empty()) {
-            t1 = now();
-            RK_HIP(hipMemcpy(crit.data(), s.buf[RK_BUF_CRIT], crit.size() * sizeof(uint4), hipMemcpyDeviceToHost));
-        }
     }
-    t2 = now();
-    build_host_mirrors(s, crit);
+    t1 = t2 = now();
+    if (nparts == 0) {
+        build_host_mirrors(s, crit); // empty tree: empty, valid mirrors
+    }
     const auto t3 = now();
-    if (nparts > 0) {
-        const std::vector<uint32_t> lists = concat_class_lists(s);
-        alloc_upload(s, RK_BUF_CLASS, lists.data(), lists.size() * sizeof(uint32_t));
-    }
     if (timing) {
         const auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
         std::fprintf(stderr, "RK_BUILD_TIMING n=%lld: device build %.0f us, crit download %.0f us, host mirrors %.0f us, "
