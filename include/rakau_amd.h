@@ -90,6 +90,17 @@ RK_EXPORT int rk_state_create(rk_state **out, int fp, int mac, int device, const
                               const uint64_t *codes, int64_t nparts, const void *tree, int64_t tree_size,
                               int64_t node_stride, uint64_t ncrit);
 
+/* The same for an ndim-dimensional tree (ndim = 2: quadtree, 3: octree; the NDim template parameter of rocm_state,
+ * rocm_fwd.hpp:26): parts = the ndim coordinate arrays followed by the masses, tree = tree_node_t<ndim, F, uint64_t, MAC>
+ * records (props[ndim + 1]). Every call that lists outputs then takes ndim accelerations, 1 potential, or ndim + 1
+ * arrays (tree_nvecs_res, tree_fwd.hpp). Quadtrees run on the same kernels in the z = 0 plane. */
+RK_EXPORT int rk_state_create_nd(rk_state **out, int ndim, int fp, int mac, int device, const void *const *parts,
+                                 const uint64_t *codes, int64_t nparts, const void *tree, int64_t tree_size,
+                                 int64_t node_stride, uint64_t ncrit);
+
+/* Number of dimensions of a state's tree (0 for a null state). */
+RK_EXPORT int rk_state_ndim(const rk_state *s);
+
 RK_EXPORT void rk_state_destroy(rk_state *s);
 
 /* info[0..7] = nparts, tree_size, n_crit, max group size, fp, mac, device, ncrit. */
@@ -165,6 +176,11 @@ RK_EXPORT int rk_state_build(rk_state **out, int fp, int mac, int device, const 
 /* Same, with x, y, z, m already resident on `device` (DEVICE pointers): no host transfer at all. */
 RK_EXPORT int rk_state_build_device(rk_state **out, int fp, int mac, int device, const void *const d_parts[4],
                                     int64_t nparts, double box_size, uint64_t max_leaf_n, uint64_t ncrit);
+
+/* ndim-dimensional variant of rk_state_build / rk_state_build_device: parts = ndim coordinate arrays + masses, host
+ * (on_device = 0) or device (on_device != 0) pointers. rk_state_rebuild_device() keeps a state's ndim. */
+RK_EXPORT int rk_state_build_nd(rk_state **out, int ndim, int fp, int mac, int device, const void *const *parts,
+                                int on_device, int64_t nparts, double box_size, uint64_t max_leaf_n, uint64_t ncrit);
 
 /* Rebuild the tree of an existing state in place from new device-resident particles (tree::update_particles_u(),
  * tree.hpp:3560-3640 of the reference: the particles moved, sort again and rebuild). fp, mac, max_leaf_n and ncrit

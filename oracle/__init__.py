@@ -19,6 +19,11 @@ MAC = {"bh": 0, "bh_geom": 1}
 NRES = {0: 3, 1: 1, 2: 4}
 
 
+def nres(q, ndim=3):
+    """Number of output arrays: ndim accelerations, 1 potential, or both (tree_fwd.hpp: tree_nvecs_res)."""
+    return {0: ndim, 1: 1, 2: ndim + 1}[q]
+
+
 class OracleError(Exception):
     pass
 
@@ -49,6 +54,10 @@ def lib():
         L.orc_rng_create.argtypes = [C.c_uint]
         L.orc_rng_destroy.argtypes = [C.c_void_p]
         L.orc_uniform.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_double, C.c_void_p]
+        L.orc_uniform_nd.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_double, C.c_void_p]
+        L.orc_tree_create_nd.restype = C.c_void_p
+        L.orc_tree_create_nd.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_uint64, C.c_double,
+                                         C.c_uint64, C.c_uint64, C.POINTER(C.c_int)]
         L.orc_tree_create.restype = C.c_void_p
         L.orc_tree_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                       C.c_double, C.c_uint64, C.c_uint64, C.POINTER(C.c_int)]
@@ -87,25 +96,29 @@ class Rng:
             lib().orc_rng_destroy(self._h)
             self._h = None
 
-    def uniform_particles(self, n, size, dtype):
-        """test/test_utils.hpp:41-59. Returns (m, x, y, z)."""
-        out = np.empty(4 * n, dtype=dtype)
-        _check(lib().orc_uniform(_FP[np.dtype(dtype)], out.ctypes.data, n, float(size), self._h))
-        return out[:n], out[n:2 * n], out[2 * n:3 * n], out[3 * n:]
+    def uniform_particles(self, n, size, dtype, ndim=3):
+        """test/test_utils.hpp:41-59 (get_uniform_particles<ndim>). Returns (m, x, y, z) or (m, x, y)."""
+        out = np.empty((ndim + 1) * n, dtype=dtype)
+        _check(lib().orc_uniform_nd(ndim, _FP[np.dtype(dtype)], out.ctypes.data, n, float(size), self._h))
+        return tuple(out[k * n:(k + 1) * n] for k in range(ndim + 1))
 
 
 class Tree:
-    """CPU restatement of rakau::octree<F, MAC> (construction + acc/pot + exact sums)."""
+    """CPU restatement of rakau::octree<F, MAC> / quadtree<F, MAC> (construction + acc/pot + exact sums).
+    ndim = 2: pass z = None; everything that lists coordinates then has two of them."""
 
-    def __init__(self, x, y, z, m, box_size=0.0, max_leaf_n=16, ncrit=128, mac="bh"):
-        x, y, z, m = (np.ascontiguousarray(v) for v in (x, y, z, m))
-        self.dtype = x.dtype
-        assert all(v.dtype == self.dtype for v in (y, z, m))
+    def __init__(self, x, y, z, m, box_size=0.0, max_leaf_n=16, ncrit=128, mac="bh", ndim=3):
+        assert ndim in (2, 3) and (z is None) == (ndim == 2)
+        arrs = [np.ascontiguousarray(v) for v in ((x, y, m) if ndim == 2 else (x, y, z, m))]
+        self.ndim = ndim
+        self.dtype = arrs[0].dtype
+        assert all(v.dtype == self.dtype and v.size == arrs[0].size for v in arrs)
         self.fp = _FP[self.dtype]
         self.mac = mac
         st = C.c_int(0)
-        self._h = lib().orc_tree_create(self.fp, MAC[mac], x.ctypes.data, y.ctypes.data, z.ctypes.data,
-                                        m.ctypes.data, x.size, float(box_size), max_leaf_n, ncrit, C.byref(st))
+        src = (C.c_void_p * 4)(*[a.ctypes.data for a in arrs])
+        self._h = lib().orc_tree_create_nd(ndim, self.fp, MAC[mac], src, arrs[0].size, float(box_size), max_leaf_n,
+                                           ncrit, C.byref(st))
         _check(st.value)
         info = (C.c_uint64 * 4)()
         box = C.c_double()
@@ -123,7 +136,7 @@ class Tree:
         n = self.nparts
         out = [np.empty(n, dtype=self.dtype) for _ in range(4)]
         lib().orc_tree_get_parts(self._h, *[o.ctypes.data for o in out], None, None, None, None)
-        return out  # x, y, z, m in Morton order
+        return out if self.ndim == 3 else [out[0], out[1], out[3]]  # x, y, (z,) m in Morton order
 
     def codes_perms(self):
         n = self.nparts
@@ -134,7 +147,7 @@ class Tree:
     def nodes(self):
         n = self.n_nodes
         topo = np.empty((n, 5), dtype=np.uint64)
-        props = np.empty((n, 4), dtype=self.dtype)
+        props = np.empty((n, self.ndim + 1), dtype=self.dtype)
         dims = np.empty((n, 2), dtype=self.dtype)
         lib().orc_tree_get_nodes(self._h, topo.ctypes.data, props.ctypes.data, dims.ctypes.data)
         return dict(begin=topo[:, 0].copy(), end=topo[:, 1].copy(), n_children=topo[:, 2].copy(),
@@ -148,7 +161,7 @@ class Tree:
     def acc_pot(self, q, theta, G=1.0, eps=0.0, ordered=False, nthreads=1, c_begin=0, c_end=2 ** 62,
                 want_stats=False):
         n = self.nparts
-        outs = [np.zeros(n, dtype=self.dtype) for _ in range(NRES[q])]
+        outs = [np.zeros(n, dtype=self.dtype) for _ in range(nres(q, self.ndim))]
         ptrs = (C.c_void_p * 4)(*[o.ctypes.data for o in outs], *([None] * (4 - len(outs))))
         stats = np.zeros(9, dtype=np.uint64)
         _check(lib().orc_acc_pot(self._h, q, ptrs, int(ordered), theta, G, eps, nthreads, c_begin, c_end,
@@ -179,4 +192,4 @@ class Tree:
     def exact(self, q, idx, G=1.0, eps=0.0, ordered=False):
         out = np.zeros(4, dtype=self.dtype)
         _check(lib().orc_exact(self._h, q, out.ctypes.data, int(ordered), idx, G, eps))
-        return out[:NRES[q]]
+        return out[:nres(q, self.ndim)]

@@ -47,10 +47,11 @@ using u64 = std::uint64_t;
 
 thread_local std::string g_last_error;
 
-// Number of bits per coordinate in the 64-bit 3D Morton code.
-// Reference: include/rakau/detail/tree_fwd.hpp:141-150 (64/3 - !(64%3) = 21).
-constexpr unsigned cbits = 21;
-constexpr unsigned NDim = 3;
+// Number of bits per coordinate in the 64-bit Morton code of an ND-dimensional tree.
+// Reference: include/rakau/detail/tree_fwd.hpp:141-150 (64/3 - !(64%3) = 21 for octrees, 64/2 - 1 = 31 for quadtrees).
+template <unsigned ND>
+constexpr unsigned cbits_of = 64u / ND - !(64u % ND);
+static_assert(cbits_of<3> == 21 && cbits_of<2> == 31);
 
 // 3D Morton encoding, x -> bit 0, y -> bit 1, z -> bit 2.
 // Reference: include/rakau/detail/libmorton/morton3D.h:38-50 (as used at tree.hpp:222-242).
@@ -74,22 +75,60 @@ inline u64 compact3(u64 v)
     v = (v ^ (v >> 32)) & 0x1fffffULL;
     return v;
 }
-inline u64 morton_encode(u64 x, u64 y, u64 z)
+// 2D Morton encoding of two 31-bit (in general, up to 32-bit) coordinates, x -> bit 0, y -> bit 1.
+// Reference: include/rakau/detail/libmorton/morton2D.h (magic-bits flavour), as used at tree.hpp:207-220.
+inline u64 spread2(u64 v)
 {
-    return spread3(x) | (spread3(y) << 1) | (spread3(z) << 2);
+    v &= 0xffffffffULL;
+    v = (v | (v << 16)) & 0x0000ffff0000ffffULL;
+    v = (v | (v << 8)) & 0x00ff00ff00ff00ffULL;
+    v = (v | (v << 4)) & 0x0f0f0f0f0f0f0f0fULL;
+    v = (v | (v << 2)) & 0x3333333333333333ULL;
+    v = (v | (v << 1)) & 0x5555555555555555ULL;
+    return v;
+}
+inline u64 compact2(u64 v)
+{
+    v &= 0x5555555555555555ULL;
+    v = (v ^ (v >> 1)) & 0x3333333333333333ULL;
+    v = (v ^ (v >> 2)) & 0x0f0f0f0f0f0f0f0fULL;
+    v = (v ^ (v >> 4)) & 0x00ff00ff00ff00ffULL;
+    v = (v ^ (v >> 8)) & 0x0000ffff0000ffffULL;
+    v = (v ^ (v >> 16)) & 0xffffffffULL;
+    return v;
+}
+template <unsigned ND>
+inline u64 morton_encode(const u64 *d)
+{
+    if constexpr (ND == 3) {
+        return spread3(d[0]) | (spread3(d[1]) << 1) | (spread3(d[2]) << 2);
+    } else {
+        return spread2(d[0]) | (spread2(d[1]) << 1);
+    }
+}
+// Coordinate j of a Morton code.
+template <unsigned ND>
+inline u64 morton_coord(u64 code, unsigned j)
+{
+    if constexpr (ND == 3) {
+        return compact3(code >> j);
+    } else {
+        return compact2(code >> j);
+    }
 }
 
 // Level of a nodal code. Reference: tree_fwd.hpp:212-228.
+template <unsigned ND>
 inline unsigned tree_level(u64 n)
 {
-    return (63u - static_cast<unsigned>(__builtin_clzll(n))) / NDim;
+    return (63u - static_cast<unsigned>(__builtin_clzll(n))) / ND;
 }
 
-template <typename F>
+template <typename F, unsigned ND>
 struct node_t {
-    // Reference: tree_fwd.hpp:77-116 (begin,end,n_children,code,level,props[4], dim2 | dim,delta).
+    // Reference: tree_fwd.hpp:77-116 (begin,end,n_children,code,level,props[NDim+1], dim2 | dim,delta).
     u64 begin, end, n_children, code, level;
-    F props[4];
+    F props[ND + 1];
     F dim; // dim2 for mac==bh, dim for mac==bh_geom
     F delta; // bh_geom only
 };
@@ -99,15 +138,17 @@ struct cnode_t {
     u64 code, begin, end;
 };
 
-template <typename F>
+template <typename F, unsigned ND>
 struct tree_t {
+    static constexpr unsigned NDim = ND, cbits = cbits_of<ND>;
+    using fp_type = F;
     int mac = 0; // 0 = bh, 1 = bh_geom
     F box_size = 0;
     bool box_deduced = false;
     u64 max_leaf_n = 16, ncrit = 128;
-    std::vector<F> parts[4]; // x, y, z, m in Morton order
+    std::vector<F> parts[ND + 1]; // x, y, (z,) m in Morton order
     std::vector<u64> codes, perm, last_perm, inv_perm;
-    std::vector<node_t<F>> nodes;
+    std::vector<node_t<F, ND>> nodes;
     std::vector<cnode_t> crit;
 
     u64 nparts() const
@@ -145,31 +186,31 @@ struct tree_t {
     {
         return box / static_cast<F>(u64(1) << level);
     }
-    void get_node_centre(F (&out)[3], u64 code) const
+    void get_node_centre(F (&out)[ND], u64 code) const
     {
-        const auto level = tree_level(code);
+        const auto level = tree_level<ND>(code);
         const u64 c_code = (code - (u64(1) << (level * NDim))) << ((cbits - level) * NDim);
         const F node_dim_2 = get_node_dim(level, box_size) * (F(1) / F(2));
         const F cell_size = box_size * (F(1) / static_cast<F>(u64(1) << cbits));
-        const u64 d[3] = {compact3(c_code), compact3(c_code >> 1), compact3(c_code >> 2)};
-        for (unsigned j = 0; j < 3; ++j) {
-            out[j] = std::fma(static_cast<F>(d[j]), cell_size, node_dim_2 - box_size * (F(1) / F(2)));
+        for (unsigned j = 0; j < ND; ++j) {
+            out[j] = std::fma(static_cast<F>(morton_coord<ND>(c_code, j)), cell_size,
+                              node_dim_2 - box_size * (F(1) / F(2)));
         }
     }
 
     // Reference: tree.hpp:1116-1237 (compute_node_properties, scalar branch 1162-1168).
-    void compute_node_properties(node_t<F> &node) const
+    void compute_node_properties(node_t<F, ND> &node) const
     {
         const auto begin = node.begin, end = node.end;
-        F tot_mass(0), com[3] = {F(0), F(0), F(0)};
+        F tot_mass(0), com[ND] = {};
         for (u64 i = begin; i < end; ++i) {
-            const F mass = parts[3][i];
+            const F mass = parts[ND][i];
             tot_mass += mass;
-            for (unsigned j = 0; j < 3; ++j) {
+            for (unsigned j = 0; j < ND; ++j) {
                 com[j] = std::fma(mass, parts[j][i], com[j]);
             }
         }
-        F geo[3] = {F(0), F(0), F(0)};
+        F geo[ND] = {};
         if (mac == 1) {
             get_node_centre(geo, node.code);
         }
@@ -177,15 +218,15 @@ struct tree_t {
             if (mac == 0) {
                 get_node_centre(com, node.code);
             } else {
-                std::copy(geo, geo + 3, com);
+                std::copy(geo, geo + ND, com);
             }
         } else {
             const F inv = F(1) / tot_mass;
-            for (unsigned j = 0; j < 3; ++j) {
+            for (unsigned j = 0; j < ND; ++j) {
                 com[j] *= inv;
             }
         }
-        for (unsigned j = 0; j < 3; ++j) {
+        for (unsigned j = 0; j < ND; ++j) {
             if (!std::isfinite(com[j])) {
                 throw std::invalid_argument(
                     "The computation of the centre of mass of a node produced a non-finite value");
@@ -196,7 +237,7 @@ struct tree_t {
             throw std::invalid_argument("The computation of the total mass in a node produced the non-finite value "
                                         + std::to_string(tot_mass));
         }
-        node.props[3] = tot_mass;
+        node.props[ND] = tot_mass;
         const F node_dim = get_node_dim(node.level, box_size);
         if (mac == 0) {
             node.dim = node_dim * node_dim;
@@ -208,7 +249,7 @@ struct tree_t {
         } else {
             node.dim = node_dim;
             F delta2 = (com[0] - geo[0]) * (com[0] - geo[0]);
-            for (unsigned j = 1; j < 3; ++j) {
+            for (unsigned j = 1; j < ND; ++j) {
                 delta2 = std::fma(com[j] - geo[j], com[j] - geo[j], delta2);
             }
             node.delta = std::sqrt(delta2);
@@ -243,7 +284,7 @@ struct tree_t {
             if (!npart) {
                 continue;
             }
-            node_t<F> nn{};
+            node_t<F, ND> nn{};
             nn.begin = it_start;
             nn.end = it_end;
             nn.n_children = 0;
@@ -278,7 +319,7 @@ struct tree_t {
         if (!np) {
             return;
         }
-        node_t<F> root{};
+        node_t<F, ND> root{};
         root.begin = 0;
         root.end = np;
         root.code = 1;
@@ -299,7 +340,7 @@ struct tree_t {
     static F determine_box_size(const F *const *c, u64 n)
     {
         F mx(0);
-        for (unsigned j = 0; j < 3; ++j) {
+        for (unsigned j = 0; j < ND; ++j) {
             for (u64 i = 0; i < n; ++i) {
                 const F tmp = std::abs(c[j][i]);
                 if (!std::isfinite(tmp)) {
@@ -320,7 +361,8 @@ struct tree_t {
     }
 
     // Reference: tree.hpp:1330-1487 (construct_impl).
-    void construct(const F *x, const F *y, const F *z, const F *m, u64 n, F box, u64 mln, u64 nc)
+    // src: the ND coordinate arrays followed by the masses.
+    void construct(const F *const *src, u64 n, F box, u64 mln, u64 nc)
     {
         box_size = box;
         box_deduced = (box == F(0));
@@ -337,8 +379,7 @@ struct tree_t {
             throw std::invalid_argument("The critical number of particles for the vectorised computation of the "
                                         "potentials/accelerations must be nonzero");
         }
-        const F *src[4] = {x, y, z, m};
-        for (unsigned j = 0; j < 4; ++j) {
+        for (unsigned j = 0; j < ND + 1; ++j) {
             parts[j].assign(src[j], src[j] + n);
         }
         codes.resize(n);
@@ -347,7 +388,10 @@ struct tree_t {
         inv_perm.resize(n);
         std::iota(perm.begin(), perm.end(), u64(0));
         if (box_deduced) {
-            const F *c[3] = {parts[0].data(), parts[1].data(), parts[2].data()};
+            const F *c[ND];
+            for (unsigned j = 0; j < ND; ++j) {
+                c[j] = parts[j].data();
+            }
             box_size = determine_box_size(c, n);
         }
         sort_and_build();
@@ -362,9 +406,11 @@ struct tree_t {
         const u64 n = nparts();
         const F inv_box_size = F(1) / box_size;
         for (u64 i = 0; i < n; ++i) {
-            codes[i] = morton_encode(disc_single_coord(parts[0][i], inv_box_size),
-                                     disc_single_coord(parts[1][i], inv_box_size),
-                                     disc_single_coord(parts[2][i], inv_box_size));
+            u64 d[ND];
+            for (unsigned j = 0; j < ND; ++j) {
+                d[j] = disc_single_coord(parts[j][i], inv_box_size);
+            }
+            codes[i] = morton_encode<ND>(d);
         }
         std::vector<u64> idx(n);
         std::iota(idx.begin(), idx.end(), u64(0));
@@ -378,7 +424,7 @@ struct tree_t {
             v = std::move(nv);
         };
         apply(codes);
-        for (unsigned j = 0; j < 4; ++j) {
+        for (unsigned j = 0; j < ND + 1; ++j) {
             apply(parts[j]);
         }
         // On construction perm == iota, so perm becomes idx; in general perm is permuted by idx
@@ -396,7 +442,7 @@ struct tree_t {
     // ---------------------------------------------------------------------------------------------
 
     struct scratch_t {
-        std::vector<F> tgt[4], res[4], tmp[5];
+        std::vector<F> tgt[ND + 1], res[ND + 1], tmp[ND + 2];
     };
 
     // Per-group statistics used for the roofline's algorithmic work count.
@@ -411,12 +457,12 @@ struct tree_t {
     template <unsigned Q>
     static void self_interactions(F eps2, u64 tgt_size, const F *const *p, F *const *res)
     {
-        constexpr unsigned nres = Q == 0 ? 3 : (Q == 1 ? 1 : 4);
-        constexpr unsigned pot_idx = Q == 1 ? 0 : 3;
-        const F *m_ptr = p[3];
-        F diffs[3], pos1[3];
+        constexpr unsigned nres = Q == 0 ? ND : (Q == 1 ? 1 : ND + 1);
+        constexpr unsigned pot_idx = Q == 1 ? 0 : ND;
+        const F *m_ptr = p[ND];
+        F diffs[ND], pos1[ND];
         for (u64 i1 = 0; i1 < tgt_size; ++i1) {
-            for (unsigned j = 0; j < 3; ++j) {
+            for (unsigned j = 0; j < ND; ++j) {
                 pos1[j] = p[j][i1];
             }
             const F m1 = m_ptr[i1];
@@ -426,14 +472,14 @@ struct tree_t {
             }
             for (u64 i2 = i1 + 1u; i2 < tgt_size; ++i2) {
                 F dist2(eps2);
-                for (unsigned j = 0; j < 3; ++j) {
+                for (unsigned j = 0; j < ND; ++j) {
                     diffs[j] = p[j][i2] - pos1[j];
                     dist2 = std::fma(diffs[j], diffs[j], dist2);
                 }
                 const F dist = std::sqrt(dist2), m2 = m_ptr[i2];
                 if constexpr (Q == 0 || Q == 2) {
                     const F dist3 = dist2 * dist, m2_dist3 = m2 / dist3, m1_dist3 = m1 / dist3;
-                    for (unsigned j = 0; j < 3; ++j) {
+                    for (unsigned j = 0; j < ND; ++j) {
                         a1[j] = std::fma(m2_dist3, diffs[j], a1[j]);
                         res[j][i2] = std::fma(m1_dist3, -diffs[j], res[j][i2]);
                     }
@@ -445,7 +491,7 @@ struct tree_t {
                 }
             }
             if constexpr (Q == 0 || Q == 2) {
-                for (unsigned j = 0; j < 3; ++j) {
+                for (unsigned j = 0; j < ND; ++j) {
                     res[j][i1] += a1[j];
                 }
             }
@@ -457,28 +503,28 @@ struct tree_t {
 
     // Reference: tree.hpp:2327-2471 (tree_acc_pot_leaf), scalar branch 2432-2470.
     template <unsigned Q>
-    void leaf_interactions(F eps2, const node_t<F> &src, u64 tgt_size, const F *const *p, F *const *res) const
+    void leaf_interactions(F eps2, const node_t<F, ND> &src, u64 tgt_size, const F *const *p, F *const *res) const
     {
-        constexpr unsigned pot_idx = Q == 1 ? 0 : 3;
-        F pos1[3], diffs[3];
+        constexpr unsigned pot_idx = Q == 1 ? 0 : ND;
+        F pos1[ND], diffs[ND];
         for (u64 i1 = 0; i1 < tgt_size; ++i1) {
-            for (unsigned j = 0; j < 3; ++j) {
+            for (unsigned j = 0; j < ND; ++j) {
                 pos1[j] = p[j][i1];
             }
             F m1 = F(0);
             if constexpr (Q == 1 || Q == 2) {
-                m1 = p[3][i1];
+                m1 = p[ND][i1];
             }
             for (u64 i2 = src.begin; i2 < src.end; ++i2) {
                 F dist2(eps2);
-                for (unsigned j = 0; j < 3; ++j) {
+                for (unsigned j = 0; j < ND; ++j) {
                     diffs[j] = parts[j][i2] - pos1[j];
                     dist2 = std::fma(diffs[j], diffs[j], dist2);
                 }
-                const F dist = std::sqrt(dist2), m2 = parts[3][i2];
+                const F dist = std::sqrt(dist2), m2 = parts[ND][i2];
                 if constexpr (Q == 0 || Q == 2) {
                     const F dist3 = dist * dist2, m_dist3 = m2 / dist3;
-                    for (unsigned j = 0; j < 3; ++j) {
+                    for (unsigned j = 0; j < ND; ++j) {
                         res[j][i1] = std::fma(diffs[j], m_dist3, res[j][i1]);
                     }
                 }
@@ -496,8 +542,8 @@ struct tree_t {
     u64 mac_check(u64 src_idx, F mac_value, F eps2, u64 tgt_size, const F *const *p, F *const *res, F *const *tmp,
                   stats_t *st) const
     {
-        constexpr unsigned pot_idx = Q == 1 ? 0 : 3;
-        constexpr unsigned dist_idx = Q == 1 ? 0 : 4;
+        constexpr unsigned pot_idx = Q == 1 ? 0 : ND;
+        constexpr unsigned dist_idx = Q == 1 ? 0 : ND + 1; // tmp: ND differences, dist^3, dist
         const auto &src = nodes[src_idx];
         const u64 n_children_src = src.n_children;
         // tree.hpp:2632-2642.
@@ -511,7 +557,7 @@ struct tree_t {
         bool mac_flag = true;
         for (u64 i = 0; i < tgt_size; ++i) {
             F dist2(0);
-            for (unsigned j = 0; j < 3; ++j) {
+            for (unsigned j = 0; j < ND; ++j) {
                 const F diff = src.props[j] - p[j][i];
                 if constexpr (Q == 0 || Q == 2) {
                     tmp[j][i] = diff;
@@ -525,7 +571,7 @@ struct tree_t {
             dist2 += eps2;
             const F dist = std::sqrt(dist2);
             if constexpr (Q == 0 || Q == 2) {
-                tmp[3][i] = dist * dist2;
+                tmp[ND][i] = dist * dist2;
             }
             if constexpr (Q == 1 || Q == 2) {
                 tmp[dist_idx][i] = dist;
@@ -537,16 +583,16 @@ struct tree_t {
         }
         if (mac_flag) {
             // tree.hpp:2564-2589.
-            const F m_src = src.props[3];
+            const F m_src = src.props[ND];
             for (u64 i = 0; i < tgt_size; ++i) {
                 if constexpr (Q == 0 || Q == 2) {
-                    const F m_src_dist3 = m_src / tmp[3][i];
-                    for (unsigned j = 0; j < 3; ++j) {
+                    const F m_src_dist3 = m_src / tmp[ND][i];
+                    for (unsigned j = 0; j < ND; ++j) {
                         res[j][i] = std::fma(tmp[j][i], m_src_dist3, res[j][i]);
                     }
                 }
                 if constexpr (Q == 1 || Q == 2) {
-                    res[pot_idx][i] = std::fma(-p[3][i], m_src / tmp[dist_idx][i], res[pot_idx][i]);
+                    res[pot_idx][i] = std::fma(-p[ND][i], m_src / tmp[dist_idx][i], res[pot_idx][i]);
                 }
             }
             if (st) {
@@ -571,7 +617,7 @@ struct tree_t {
     void tree_acc_pot(F mac_value, F eps2, u64 tgt_size, u64 tgt_code, const F *const *p, F *const *res,
                       F *const *tmp, stats_t *st) const
     {
-        const u64 tgt_level = tree_level(tgt_code);
+        const u64 tgt_level = tree_level<ND>(tgt_code);
         const u64 tree_size = nodes.size();
         for (u64 src_idx = 0; src_idx < tree_size;) {
             const auto &src = nodes[src_idx];
@@ -600,7 +646,7 @@ struct tree_t {
     void cpu_run(u64 c_begin, u64 c_end, F *const *out, bool ordered, F mac_value, F G, F eps2, unsigned nthreads,
                  stats_t *stats_out) const
     {
-        constexpr unsigned nres = Q == 0 ? 3 : (Q == 1 ? 1 : 4);
+        constexpr unsigned nres = Q == 0 ? ND : (Q == 1 ? 1 : ND + 1);
         std::atomic<u64> next(c_begin);
         std::vector<stats_t> tstats(nthreads);
         auto worker = [&](unsigned tid) {
@@ -615,10 +661,10 @@ struct tree_t {
                 for (u64 ci = b; ci < e; ++ci) {
                     const u64 tgt_code = crit[ci].code, tgt_begin = crit[ci].begin,
                               tgt_size = crit[ci].end - tgt_begin;
-                    const F *p[4];
-                    F *res[4] = {nullptr, nullptr, nullptr, nullptr};
-                    F *tmp[5];
-                    for (unsigned j = 0; j < 4; ++j) {
+                    const F *p[ND + 1];
+                    F *res[ND + 1] = {};
+                    F *tmp[ND + 2];
+                    for (unsigned j = 0; j < ND + 1; ++j) {
                         s.tgt[j].assign(parts[j].data() + tgt_begin, parts[j].data() + tgt_begin + tgt_size);
                         p[j] = s.tgt[j].data();
                     }
@@ -626,7 +672,7 @@ struct tree_t {
                         s.res[j].assign(tgt_size, F(0));
                         res[j] = s.res[j].data();
                     }
-                    for (unsigned j = 0; j < 5; ++j) {
+                    for (unsigned j = 0; j < ND + 2; ++j) {
                         s.tmp[j].resize(tgt_size);
                         tmp[j] = s.tmp[j].data();
                     }
@@ -716,8 +762,8 @@ struct tree_t {
     template <unsigned Q>
     void exact(F *retval, bool ordered, u64 orig_idx, F G, F eps) const
     {
-        constexpr unsigned nres = Q == 0 ? 3 : (Q == 1 ? 1 : 4);
-        constexpr unsigned pot_idx = Q == 1 ? 0 : 3;
+        constexpr unsigned nres = Q == 0 ? ND : (Q == 1 ? 1 : ND + 1);
+        constexpr unsigned pot_idx = Q == 1 ? 0 : ND;
         if (!std::isfinite(eps) || eps < F(0)) {
             throw std::domain_error("The softening length must be finite and non-negative");
         }
@@ -729,26 +775,26 @@ struct tree_t {
         for (unsigned j = 0; j < nres; ++j) {
             retval[j] = F(0);
         }
-        F diffs[3];
+        F diffs[ND];
         const u64 idx = ordered ? inv_perm[orig_idx] : orig_idx;
         for (u64 i = 0; i < size; ++i) {
             if (i == idx) {
                 continue;
             }
             F dist2(eps2);
-            for (unsigned j = 0; j < 3; ++j) {
+            for (unsigned j = 0; j < ND; ++j) {
                 diffs[j] = parts[j][i] - parts[j][idx];
                 dist2 = std::fma(diffs[j], diffs[j], dist2);
             }
-            const F inv_dist = F(1) / std::sqrt(dist2), Gmi_dist = G * parts[3][i] * inv_dist;
+            const F inv_dist = F(1) / std::sqrt(dist2), Gmi_dist = G * parts[ND][i] * inv_dist;
             if constexpr (Q == 0 || Q == 2) {
                 const F Gmi_dist3 = inv_dist * inv_dist * Gmi_dist;
-                for (unsigned j = 0; j < 3; ++j) {
+                for (unsigned j = 0; j < ND; ++j) {
                     retval[j] = std::fma(diffs[j], Gmi_dist3, retval[j]);
                 }
             }
             if constexpr (Q == 1 || Q == 2) {
-                retval[pot_idx] = std::fma(-Gmi_dist, parts[3][idx], retval[pot_idx]);
+                retval[pot_idx] = std::fma(-Gmi_dist, parts[ND][idx], retval[pot_idx]);
             }
         }
     }
@@ -795,23 +841,45 @@ void plummer(F *retval, u64 n, F a, F size, std::uint32_t seed)
     }
 }
 
-// Reference: test/test_utils.hpp:41-59 (get_uniform_particles<3>): masses U[0,1) then the 3n coordinates
+// Reference: test/test_utils.hpp:41-59 (get_uniform_particles<NDim>): masses U[0,1) then the NDim*n coordinates
 // U[-size/2, size/2), all drawn from one engine. The engine is passed by the caller so that a sequence of
 // calls continues one stream, as the reference tests do with their file-static rng.
 template <typename F>
-void uniform_particles(F *retval, u64 n, F size, std::mt19937 &rng)
+void uniform_particles(F *retval, u64 n, F size, std::mt19937 &rng, unsigned ndim)
 {
     std::uniform_real_distribution<F> mdist(F(0), F(1));
     std::generate(retval, retval + n, [&]() { return mdist(rng); });
     std::uniform_real_distribution<F> rdist(-size / F(2), size / F(2));
-    std::generate(retval + n, retval + 4 * n, [&]() { return rdist(rng); });
+    std::generate(retval + n, retval + (ndim + 1) * n, [&]() { return rdist(rng); });
 }
 
 struct handle_t {
-    int fp; // 0 = float, 1 = double
-    std::unique_ptr<tree_t<float>> tf;
-    std::unique_ptr<tree_t<double>> td;
+    int fp;   // 0 = float, 1 = double
+    int ndim; // 2 or 3
+    std::unique_ptr<tree_t<float, 3>> tf3;
+    std::unique_ptr<tree_t<double, 3>> td3;
+    std::unique_ptr<tree_t<float, 2>> tf2;
+    std::unique_ptr<tree_t<double, 2>> td2;
 };
+
+// Calls f(tree) on whichever tree the handle holds.
+template <typename H, typename Fn>
+void visit(H *h, Fn &&f)
+{
+    if (h->ndim == 3) {
+        if (h->fp == 0) {
+            f(*h->tf3);
+        } else {
+            f(*h->td3);
+        }
+    } else {
+        if (h->fp == 0) {
+            f(*h->tf2);
+        } else {
+            f(*h->td2);
+        }
+    }
+}
 
 template <typename Fn>
 int guard(Fn &&f)
@@ -834,10 +902,11 @@ int guard(Fn &&f)
     }
 }
 
-template <typename F, typename T>
+template <typename T>
 void acc_pot_q(const T &t, int q, void *const *out, int ordered, double theta, double G, double eps, unsigned nthreads,
                u64 c_begin, u64 c_end, u64 *stats)
 {
+    using F = typename T::fp_type;
     F *o[4] = {static_cast<F *>(out[0]), static_cast<F *>(out[1]), static_cast<F *>(out[2]),
                static_cast<F *>(out[3])};
     typename T::stats_t st;
@@ -898,37 +967,61 @@ void orc_rng_destroy(void *r)
 {
     delete static_cast<std::mt19937 *>(r);
 }
-int orc_uniform(int fp, void *out, u64 n, double size, void *rng)
+// out: (ndim + 1) * n values laid out m | x | y (| z).
+int orc_uniform_nd(int ndim, int fp, void *out, u64 n, double size, void *rng)
 {
     return guard([&] {
+        if (ndim != 2 && ndim != 3) {
+            throw std::invalid_argument("ndim must be 2 or 3");
+        }
         auto &r = *static_cast<std::mt19937 *>(rng);
         if (fp == 0) {
-            uniform_particles<float>(static_cast<float *>(out), n, float(size), r);
+            uniform_particles<float>(static_cast<float *>(out), n, float(size), r, unsigned(ndim));
         } else {
-            uniform_particles<double>(static_cast<double *>(out), n, size, r);
+            uniform_particles<double>(static_cast<double *>(out), n, size, r, unsigned(ndim));
         }
     });
 }
+int orc_uniform(int fp, void *out, u64 n, double size, void *rng)
+{
+    return orc_uniform_nd(3, fp, out, n, size, rng);
+}
 
-// mac: 0 = bh, 1 = bh_geom. box_size == 0 -> deduced. Returns nullptr on error (see orc_last_error()).
-void *orc_tree_create(int fp, int mac, const void *x, const void *y, const void *z, const void *m, u64 n,
-                      double box_size, u64 max_leaf_n, u64 ncrit, int *status)
+// mac: 0 = bh, 1 = bh_geom. box_size == 0 -> deduced. src: the ndim coordinate arrays followed by the masses.
+// Returns nullptr on error (see orc_last_error()).
+void *orc_tree_create_nd(int ndim, int fp, int mac, const void *const *src, u64 n, double box_size, u64 max_leaf_n,
+                         u64 ncrit, int *status)
 {
     auto h = std::make_unique<handle_t>();
     h->fp = fp;
+    h->ndim = ndim;
     const int rc = guard([&] {
-        if (fp == 0) {
-            h->tf = std::make_unique<tree_t<float>>();
-            h->tf->mac = mac;
-            h->tf->construct(static_cast<const float *>(x), static_cast<const float *>(y),
-                             static_cast<const float *>(z), static_cast<const float *>(m), n, float(box_size),
-                             max_leaf_n, ncrit);
+        if (ndim != 2 && ndim != 3) {
+            throw std::invalid_argument("ndim must be 2 or 3");
+        }
+        auto make = [&](auto &ptr) {
+            using T = typename std::remove_reference_t<decltype(ptr)>::element_type;
+            using F = typename T::fp_type;
+            ptr = std::make_unique<T>();
+            ptr->mac = mac;
+            const F *s[4] = {};
+            for (int j = 0; j < ndim + 1; ++j) {
+                s[j] = static_cast<const F *>(src[j]);
+            }
+            ptr->construct(s, n, F(box_size), max_leaf_n, ncrit);
+        };
+        if (ndim == 3) {
+            if (fp == 0) {
+                make(h->tf3);
+            } else {
+                make(h->td3);
+            }
         } else {
-            h->td = std::make_unique<tree_t<double>>();
-            h->td->mac = mac;
-            h->td->construct(static_cast<const double *>(x), static_cast<const double *>(y),
-                             static_cast<const double *>(z), static_cast<const double *>(m), n, box_size, max_leaf_n,
-                             ncrit);
+            if (fp == 0) {
+                make(h->tf2);
+            } else {
+                make(h->td2);
+            }
         }
     });
     if (status) {
@@ -937,41 +1030,48 @@ void *orc_tree_create(int fp, int mac, const void *x, const void *y, const void 
     return rc ? nullptr : h.release();
 }
 
+void *orc_tree_create(int fp, int mac, const void *x, const void *y, const void *z, const void *m, u64 n,
+                      double box_size, u64 max_leaf_n, u64 ncrit, int *status)
+{
+    const void *src[4] = {x, y, z, m};
+    return orc_tree_create_nd(3, fp, mac, src, n, box_size, max_leaf_n, ncrit, status);
+}
+
 void orc_tree_destroy(void *hp)
 {
     delete static_cast<handle_t *>(hp);
 }
 
-// info[0..3] = nparts, n_nodes, n_crit, (unused); box = box size.
+// info[0..3] = nparts, n_nodes, n_crit, ndim; box = box size.
 void orc_tree_info(void *hp, u64 *info, double *box)
 {
     auto *h = static_cast<handle_t *>(hp);
-    if (h->fp == 0) {
-        info[0] = h->tf->nparts();
-        info[1] = h->tf->nodes.size();
-        info[2] = h->tf->crit.size();
-        *box = h->tf->box_size;
-    } else {
-        info[0] = h->td->nparts();
-        info[1] = h->td->nodes.size();
-        info[2] = h->td->crit.size();
-        *box = h->td->box_size;
-    }
+    visit(h, [&](auto &t) {
+        info[0] = t.nparts();
+        info[1] = t.nodes.size();
+        info[2] = t.crit.size();
+        info[3] = t.NDim;
+        *box = t.box_size;
+    });
 }
 
 // Copy out the Morton-ordered particle SoA (p_its_u, tree.hpp:3638-3641), codes and permutations.
-// Any pointer may be null.
+// Any pointer may be null; z is ignored for 2D trees.
 void orc_tree_get_parts(void *hp, void *x, void *y, void *z, void *m, u64 *codes, u64 *perm, u64 *last_perm,
                         u64 *inv_perm)
 {
     auto *h = static_cast<handle_t *>(hp);
-    auto doit = [&](auto &t) {
-        using F = typename std::remove_reference_t<decltype(t.parts[0])>::value_type;
-        void *dst[4] = {x, y, z, m};
-        for (unsigned j = 0; j < 4; ++j) {
-            if (dst[j]) {
-                std::memcpy(dst[j], t.parts[j].data(), t.nparts() * sizeof(F));
+    visit(h, [&](auto &t) {
+        using T = std::remove_reference_t<decltype(t)>;
+        using F = typename T::fp_type;
+        void *coords[3] = {x, y, z};
+        for (unsigned j = 0; j < T::NDim; ++j) {
+            if (coords[j]) {
+                std::memcpy(coords[j], t.parts[j].data(), t.nparts() * sizeof(F));
             }
+        }
+        if (m) {
+            std::memcpy(m, t.parts[T::NDim].data(), t.nparts() * sizeof(F));
         }
         if (codes) {
             std::memcpy(codes, t.codes.data(), t.nparts() * 8);
@@ -985,22 +1085,19 @@ void orc_tree_get_parts(void *hp, void *x, void *y, void *z, void *m, u64 *codes
         if (inv_perm) {
             std::memcpy(inv_perm, t.inv_perm.data(), t.nparts() * 8);
         }
-    };
-    if (h->fp == 0) {
-        doit(*h->tf);
-    } else {
-        doit(*h->td);
-    }
+    });
 }
 
 // Copy out the node array (nodes(), tree.hpp:3670-3673) as SoA:
-// topo[5*i + {0..4}] = begin, end, n_children, code, level; props[4*i + {0..3}] = COM x,y,z, mass;
+// topo[5*i + {0..4}] = begin, end, n_children, code, level; props[(ndim+1)*i + {0..ndim}] = COM, mass;
 // dims[2*i + {0,1}] = {dim2, 0} (bh) or {dim, delta} (bh_geom).
 void orc_tree_get_nodes(void *hp, u64 *topo, void *props, void *dims)
 {
     auto *h = static_cast<handle_t *>(hp);
-    auto doit = [&](auto &t) {
-        using F = typename std::remove_reference_t<decltype(t.parts[0])>::value_type;
+    visit(h, [&](auto &t) {
+        using T = std::remove_reference_t<decltype(t)>;
+        using F = typename T::fp_type;
+        constexpr unsigned np = T::NDim + 1;
         auto *pr = static_cast<F *>(props);
         auto *dm = static_cast<F *>(dims);
         for (std::size_t i = 0; i < t.nodes.size(); ++i) {
@@ -1013,8 +1110,8 @@ void orc_tree_get_nodes(void *hp, u64 *topo, void *props, void *dims)
                 topo[5 * i + 4] = n.level;
             }
             if (pr) {
-                for (unsigned j = 0; j < 4; ++j) {
-                    pr[4 * i + j] = n.props[j];
+                for (unsigned j = 0; j < np; ++j) {
+                    pr[np * i + j] = n.props[j];
                 }
             }
             if (dm) {
@@ -1022,50 +1119,44 @@ void orc_tree_get_nodes(void *hp, u64 *topo, void *props, void *dims)
                 dm[2 * i + 1] = n.delta;
             }
         }
-    };
-    if (h->fp == 0) {
-        doit(*h->tf);
-    } else {
-        doit(*h->td);
-    }
+    });
 }
 
 // crit[3*i + {0,1,2}] = code, begin, end.
 void orc_tree_get_crit(void *hp, u64 *crit)
 {
     auto *h = static_cast<handle_t *>(hp);
-    const auto &c = h->fp == 0 ? h->tf->crit : h->td->crit;
-    for (std::size_t i = 0; i < c.size(); ++i) {
-        crit[3 * i] = c[i].code;
-        crit[3 * i + 1] = c[i].begin;
-        crit[3 * i + 2] = c[i].end;
-    }
+    visit(h, [&](auto &t) {
+        const auto &c = t.crit;
+        for (std::size_t i = 0; i < c.size(); ++i) {
+            crit[3 * i] = c[i].code;
+            crit[3 * i + 1] = c[i].begin;
+            crit[3 * i + 2] = c[i].end;
+        }
+    });
 }
 
-// q: 0 accs (3 outputs), 1 pots (1), 2 accs+pots (4). ordered: 0 -> *_u, 1 -> *_o.
+// q: 0 accs (ndim outputs), 1 pots (1), 2 accs+pots (ndim + 1). ordered: 0 -> *_u, 1 -> *_o.
 // Only critical nodes [c_begin, c_end) are processed (c_end is clamped); outputs of the other
 // particles are left untouched. stats (may be null, else 9 entries): visits, com, leaves, pp, self_pairs,
-// w_visits, w_com, w_pp, w_self (see stats_t).
+// w_visits, w_com, w_pp, w_self (see stats_t). out always has room for 4 pointers.
 int orc_acc_pot(void *hp, int q, void *const *out, int ordered, double theta, double G, double eps,
                 unsigned nthreads, u64 c_begin, u64 c_end, u64 *stats)
 {
     auto *h = static_cast<handle_t *>(hp);
     return guard([&] {
-        if (h->fp == 0) {
-            acc_pot_q<float>(*h->tf, q, out, ordered, theta, G, eps, nthreads, c_begin, c_end, stats);
-        } else {
-            acc_pot_q<double>(*h->td, q, out, ordered, theta, G, eps, nthreads, c_begin, c_end, stats);
-        }
+        visit(h, [&](auto &t) { acc_pot_q(t, q, out, ordered, theta, G, eps, nthreads, c_begin, c_end, stats); });
     });
 }
 
-// exact_{acc,pot,acc_pot}_{u,o} (tree.hpp:3572-3616). out has 3/1/4 entries.
+// exact_{acc,pot,acc_pot}_{u,o} (tree.hpp:3572-3616). out has ndim/1/ndim+1 entries.
 int orc_exact(void *hp, int q, void *out, int ordered, u64 idx, double G, double eps)
 {
     auto *h = static_cast<handle_t *>(hp);
     return guard([&] {
-        auto doit = [&](auto &t, auto *o) {
-            using F = std::remove_pointer_t<decltype(o)>;
+        visit(h, [&](auto &t) {
+            using F = typename std::remove_reference_t<decltype(t)>::fp_type;
+            auto *o = static_cast<F *>(out);
             switch (q) {
                 case 0:
                     t.template exact<0>(o, ordered, idx, F(G), F(eps));
@@ -1079,12 +1170,7 @@ int orc_exact(void *hp, int q, void *out, int ordered, u64 idx, double G, double
                 default:
                     throw std::invalid_argument("q must be 0, 1 or 2");
             }
-        };
-        if (h->fp == 0) {
-            doit(*h->tf, static_cast<float *>(out));
-        } else {
-            doit(*h->td, static_cast<double *>(out));
-        }
+        });
     });
 }
 

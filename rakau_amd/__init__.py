@@ -4,7 +4,7 @@ The package holds only what the hot path needs: ``csrc/`` (hand-written HIP kern
 C ABI of ``include/rakau_amd.h``), ``lib/`` (the built ``librakau_amd.so``) and thin ctypes plumbing.
 """
 from . import _capi
-from .state import State, node_dtype, mac_value_of, NRES
+from .state import State, node_dtype, mac_value_of, NRES, nres
 from .tree import Octree
 
-__all__ = ["State", "Octree", "node_dtype", "mac_value_of", "NRES"]
+__all__ = ["State", "Octree", "node_dtype", "mac_value_of", "NRES", "nres"]

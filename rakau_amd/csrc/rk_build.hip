@@ -31,7 +31,16 @@ namespace rk
 namespace bld
 {
 
-constexpr unsigned CBITS = 21;
+// Geometry of the Morton codes of an ND-dimensional tree: CB bits per coordinate (tree_fwd.hpp:141-150 of the
+// reference: 21 for octrees, 31 for quadtrees), ND bits per level.
+template <int ND>
+struct geo {
+    static_assert(ND == 2 || ND == 3);
+    static constexpr unsigned CB = ND == 3 ? 21u : 31u;
+    static constexpr unsigned DB = static_cast<unsigned>(ND);
+    static constexpr unsigned DMASK = (1u << DB) - 1u;
+    static constexpr unsigned SLACK = 64u - CB * DB; // unused high bits of a particle code
+};
 
 __host__ __device__ inline uint64_t spread3(uint64_t v)
 {
@@ -52,6 +61,36 @@ __host__ __device__ inline uint64_t compact3(uint64_t v)
     v = (v ^ (v >> 16)) & 0x1f00000000ffffULL;
     v = (v ^ (v >> 32)) & 0x1fffffULL;
     return v;
+}
+
+__host__ __device__ inline uint64_t spread2(uint64_t v)
+{
+    v &= 0xffffffffULL;
+    v = (v | (v << 16)) & 0x0000ffff0000ffffULL;
+    v = (v | (v << 8)) & 0x00ff00ff00ff00ffULL;
+    v = (v | (v << 4)) & 0x0f0f0f0f0f0f0f0fULL;
+    v = (v | (v << 2)) & 0x3333333333333333ULL;
+    v = (v | (v << 1)) & 0x5555555555555555ULL;
+    return v;
+}
+__host__ __device__ inline uint64_t compact2(uint64_t v)
+{
+    v &= 0x5555555555555555ULL;
+    v = (v ^ (v >> 1)) & 0x3333333333333333ULL;
+    v = (v ^ (v >> 2)) & 0x0f0f0f0f0f0f0f0fULL;
+    v = (v ^ (v >> 4)) & 0x00ff00ff00ff00ffULL;
+    v = (v ^ (v >> 8)) & 0x0000ffff0000ffffULL;
+    v = (v ^ (v >> 16)) & 0xffffffffULL;
+    return v;
+}
+template <int ND>
+__host__ __device__ inline uint64_t morton_coord(uint64_t code, unsigned j)
+{
+    if constexpr (ND == 3) {
+        return compact3(code >> j);
+    } else {
+        return compact2(code >> j);
+    }
 }
 
 __device__ inline float d_fma(float a, float b, float c)
@@ -87,7 +126,7 @@ __global__ void k_maxabs(const F *x, const F *y, const F *z, uint32_t n, ctrl_bl
     F mx = F(0);
     bool bad = false;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const F a = fabs(x[i]), b = fabs(y[i]), c = fabs(z[i]);
+        const F a = fabs(x[i]), b = fabs(y[i]), c = z ? fabs(z[i]) : F(0);
         bad |= !(isfinite(a) && isfinite(b) && isfinite(c));
         mx = fmax(mx, fmax(a, fmax(b, c)));
     }
@@ -148,7 +187,7 @@ __global__ void k_box(ctrl_block *ctrl, F box_in)
 }
 
 // ---- discretise + encode ----------------------------------------------------------------------------------
-template <typename F>
+template <typename F, int ND>
 __global__ void k_encode(const F *x, const F *y, const F *z, uint32_t n, ctrl_block *ctrl, uint64_t *codes,
                          uint32_t *idx)
 {
@@ -157,12 +196,12 @@ __global__ void k_encode(const F *x, const F *y, const F *z, uint32_t n, ctrl_bl
         return;
     }
     const F inv_box = F(1) / static_cast<F>(ctrl->box);
-    constexpr F factor = F(1u << CBITS);
-    uint64_t d[3];
-    const F v[3] = {x[i], y[i], z[i]};
+    constexpr F factor = F(1u << geo<ND>::CB);
+    uint64_t d[3] = {};
+    const F v[3] = {x[i], y[i], ND == 3 ? z[i] : F(0)};
     bool bad = false;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < ND; ++k) {
         F tmp = d_fma(v[k], inv_box, F(0.5));
         tmp *= factor;
         if (!isfinite(tmp) || tmp < F(0) || tmp >= factor) {
@@ -174,7 +213,11 @@ __global__ void k_encode(const F *x, const F *y, const F *z, uint32_t n, ctrl_bl
     if (bad) {
         atomicMax(&ctrl->bad_inv, ~i);
     }
-    codes[i] = spread3(d[0]) | (spread3(d[1]) << 1) | (spread3(d[2]) << 2);
+    if constexpr (ND == 3) {
+        codes[i] = spread3(d[0]) | (spread3(d[1]) << 1) | (spread3(d[2]) << 2);
+    } else {
+        codes[i] = spread2(d[0]) | (spread2(d[1]) << 1);
+    }
     idx[i] = i;
 }
 
@@ -188,15 +231,16 @@ __global__ void k_permute(const F *x, const F *y, const F *z, const F *m, const 
     }
     const uint32_t s = order[i];
     typename vt<F>::v4 p;
-    p.x = x[s], p.y = y[s], p.z = z[s], p.w = m[s];
+    p.x = x[s], p.y = y[s], p.z = z ? z[s] : F(0), p.w = m[s];
     part4[i] = p;
 }
 
 // ---- topology ---------------------------------------------------------------------------------------------
 // Range [lo, hi) of the particles sharing the level-`lvl` cell of particle i, searched inside the parent range.
+template <int ND>
 __device__ inline void narrow(const uint64_t *codes, uint32_t i, unsigned lvl, uint32_t &lo, uint32_t &hi)
 {
-    const unsigned shift = 3u * (CBITS - lvl);
+    const unsigned shift = geo<ND>::DB * (geo<ND>::CB - lvl);
     const uint64_t p = codes[i] >> shift;
     uint32_t a = lo, b = i; // first j in [lo, i] with prefix == p
     while (a < b) {
@@ -221,14 +265,16 @@ __device__ inline void narrow(const uint64_t *codes, uint32_t i, unsigned lvl, u
     hi = a;
 }
 
-// Number of leading 3-bit digits (levels) two codes share: 0..CBITS. Codes use bits 0..62.
+// Number of leading ND-bit digits (levels) two codes share: 0..CB. Octree codes use bits 0..62, quadtree codes 0..61.
+template <int ND>
 __device__ inline unsigned common_levels(uint64_t a, uint64_t b)
 {
     const uint64_t xr = a ^ b;
-    return xr ? (static_cast<unsigned>(__clzll(static_cast<long long>(xr))) - 1u) / 3u : CBITS;
+    return xr ? (static_cast<unsigned>(__clzll(static_cast<long long>(xr))) - geo<ND>::SLACK) / geo<ND>::DB : geo<ND>::CB;
 }
 
 // Depth of the leaf holding each particle, by search (any max_leaf_n): descend while the cell holds too many.
+template <int ND>
 __global__ void k_leaf_levels_search(const uint64_t *codes, uint32_t n, uint32_t max_leaf_n, uint8_t *leaf)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -237,9 +283,9 @@ __global__ void k_leaf_levels_search(const uint64_t *codes, uint32_t n, uint32_t
     }
     uint32_t lo = 0, hi = n;
     unsigned lvl = 0;
-    while (hi - lo > max_leaf_n && lvl < CBITS) {
+    while (hi - lo > max_leaf_n && lvl < geo<ND>::CB) {
         ++lvl;
-        narrow(codes, i, lvl, lo, hi);
+        narrow<ND>(codes, i, lvl, lo, hi);
     }
     leaf[i] = static_cast<uint8_t>(lvl);
 }
@@ -248,14 +294,16 @@ __global__ void k_leaf_levels_search(const uint64_t *codes, uint32_t n, uint32_t
 // particles iff some window of m + 1 consecutive (sorted) particles containing i shares its first L digits, so
 //   leaf(i) = min(CBITS, 1 + max_{j in [i-m, i], j+m < n} common_levels(c[j], c[j+m]))      (0 without windows).
 // win[j] = common_levels(c[j], c[j+m]) + 1 for a valid window, 0 otherwise.
+template <int ND>
 __global__ void k_windows(const uint64_t *codes, uint32_t n, uint32_t m, uint8_t *win)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) {
         return;
     }
-    win[j] = (m < n && j < n - m) ? static_cast<uint8_t>(common_levels(codes[j], codes[j + m]) + 1u) : uint8_t(0);
+    win[j] = (m < n && j < n - m) ? static_cast<uint8_t>(common_levels<ND>(codes[j], codes[j + m]) + 1u) : uint8_t(0);
 }
+template <int ND>
 __global__ void k_leaf_levels_windows(const uint8_t *win, uint32_t n, uint32_t m, uint8_t *leaf)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -266,10 +314,11 @@ __global__ void k_leaf_levels_windows(const uint8_t *win, uint32_t n, uint32_t m
     for (uint32_t j = i >= m ? i - m : 0u; j <= i; ++j) {
         best = max(best, static_cast<unsigned>(win[j]));
     }
-    leaf[i] = static_cast<uint8_t>(min(best, CBITS));
+    leaf[i] = static_cast<uint8_t>(min(best, geo<ND>::CB));
 }
 
 // ldiv[i] = first level at which c[i] leaves the cell of c[i-1]; cnt[i] = number of nodes whose first particle is i.
+template <int ND>
 __global__ void k_node_counts(const uint64_t *codes, uint32_t n, const uint8_t *leaf, uint8_t *ldiv, uint32_t *cnt)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -277,7 +326,7 @@ __global__ void k_node_counts(const uint64_t *codes, uint32_t n, const uint8_t *
         return;
     }
     // Identical codes never start a node.
-    const unsigned dv = i > 0 ? common_levels(codes[i - 1], codes[i]) + 1u : 1u;
+    const unsigned dv = i > 0 ? common_levels<ND>(codes[i - 1], codes[i]) + 1u : 1u;
     const unsigned lvl = leaf[i];
     ldiv[i] = static_cast<uint8_t>(dv);
     cnt[i] = dv <= lvl ? lvl - dv + 1u : 0u;
@@ -294,6 +343,7 @@ __global__ void k_pack_nodes(ctrl_block *ctrl, const uint32_t *off_n)
 // Emit the nodes whose first particle is i. off[] = exclusive scan of cnt[] (off[n] = number of non-root nodes).
 // The nodes starting at i are nested (levels ldiv(i)..leaf(i)); their ends are found deepest first by galloping
 // from the end of the child, so a leaf of a dozen particles costs a handful of probes.
+template <int ND>
 __global__ void k_emit_nodes(const uint64_t *codes, uint32_t n, const uint8_t *leaf, const uint8_t *ldiv,
                              const uint32_t *off, uint4 *topo, uint64_t *ncode, uint32_t *parent)
 {
@@ -314,7 +364,7 @@ __global__ void k_emit_nodes(const uint64_t *codes, uint32_t n, const uint8_t *l
     const uint32_t base_dfs = 1u + off[i];
     uint32_t hi = i + 1u; // every particle in [i, hi) is known to lie in the current node
     for (unsigned lvl = lf; lvl >= dv; --lvl) {
-        const unsigned shift = 3u * (CBITS - lvl);
+        const unsigned shift = geo<ND>::DB * (geo<ND>::CB - lvl);
         const uint64_t p = ci >> shift;
         // Smallest j >= hi with j == n or a different level-lvl prefix.
         uint32_t a = hi, b, step = 1u;
@@ -342,7 +392,7 @@ __global__ void k_emit_nodes(const uint64_t *codes, uint32_t n, const uint8_t *l
         const uint32_t dfs = base_dfs + (lvl - dv);
         const uint32_t next = 1u + off[hi]; // depth-first index of the first node starting at or after hi
         topo[dfs] = make_uint4(next - dfs - 1u, i, hi, 0u);
-        ncode[dfs] = (1ull << (3u * lvl)) | p;
+        ncode[dfs] = (1ull << (geo<ND>::DB * lvl)) | p;
     }
 }
 
@@ -364,9 +414,10 @@ __global__ void k_parents(const uint4 *topo, uint32_t n_nodes, uint32_t *parent,
 }
 
 // ---- node properties --------------------------------------------------------------------------------------
+template <int ND>
 __device__ inline unsigned level_of(uint64_t code)
 {
-    return (63u - static_cast<unsigned>(__clzll(static_cast<long long>(code)))) / 3u;
+    return (63u - static_cast<unsigned>(__clzll(static_cast<long long>(code)))) / geo<ND>::DB;
 }
 
 template <typename F>
@@ -391,12 +442,12 @@ __global__ void k_leaf_sums(const uint4 *topo, uint32_t n_nodes, const typename 
     sums[k] = s;
 }
 
-template <typename F>
+template <typename F, int ND>
 __global__ void k_up_sums(const uint4 *topo, const uint64_t *ncode, uint32_t n_nodes, unsigned lvl,
                           typename vt<F>::v4 *sums)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_nodes || topo[k].x == 0u || level_of(ncode[k]) != lvl) {
+    if (k >= n_nodes || topo[k].x == 0u || level_of<ND>(ncode[k]) != lvl) {
         return;
     }
     F mt = F(0), sx = F(0), sy = F(0), sz = F(0);
@@ -413,7 +464,7 @@ __global__ void k_up_sums(const uint4 *topo, const uint64_t *ncode, uint32_t n_n
     sums[k] = s;
 }
 
-template <typename F>
+template <typename F, int ND>
 __global__ void k_finalize(const uint4 *topo, const uint64_t *ncode, uint32_t n_nodes, const typename vt<F>::v4 *sums,
                            F box, int mac, typename vt<F>::v4 *node_com, typename vt<F>::v2 *node_mac, ctrl_block *ctrl)
 {
@@ -422,16 +473,18 @@ __global__ void k_finalize(const uint4 *topo, const uint64_t *ncode, uint32_t n_
         return;
     }
     const uint64_t code = ncode[k];
-    const unsigned lvl = level_of(code);
+    const unsigned lvl = level_of<ND>(code);
     const typename vt<F>::v4 s = sums[k];
     // Geometric centre (tree.hpp:452-482 of the reference).
-    const uint64_t first_cell = (code - (1ull << (3u * lvl))) << (3u * (CBITS - lvl));
+    constexpr unsigned DB = geo<ND>::DB, CB = geo<ND>::CB;
+    const uint64_t first_cell = (code - (1ull << (DB * lvl))) << (DB * (CB - lvl));
     const F node_dim = box / static_cast<F>(1ull << lvl);
-    const F half_dim = node_dim * F(0.5), cell = box * (F(1) / static_cast<F>(1ull << CBITS));
-    F ctr[3];
+    const F half_dim = node_dim * F(0.5), cell = box * (F(1) / static_cast<F>(1ull << CB));
+    F ctr[3] = {F(0), F(0), F(0)}; // a quadtree lives in the z = 0 plane
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        ctr[j] = d_fma(static_cast<F>(compact3(first_cell >> j)), cell, half_dim - box * F(0.5));
+    for (int j = 0; j < ND; ++j) {
+        ctr[j] = d_fma(static_cast<F>(morton_coord<ND>(first_cell, static_cast<unsigned>(j))), cell,
+                       half_dim - box * F(0.5));
     }
     F com[3];
     if (s.w == F(0)) {
@@ -475,6 +528,7 @@ struct tri_sum {
     }
 };
 
+template <int ND>
 __global__ void k_flags(const uint4 *topo, const uint64_t *ncode, const uint32_t *parent, uint32_t n_nodes,
                         uint32_t ncrit_clamped, tri *flags, uint32_t *mask)
 {
@@ -487,7 +541,7 @@ __global__ void k_flags(const uint4 *topo, const uint64_t *ncode, const uint32_t
     flags[k].a = (c && (k == 0u || !cand(parent[k]))) ? 1u : 0u;
     flags[k].b = topo[k].x != 0u ? 1u : 0u;
     if (k != 0u) {
-        atomicOr(&mask[parent[k]], 1u << static_cast<unsigned>(ncode[k] & 7ull));
+        atomicOr(&mask[parent[k]], 1u << (static_cast<unsigned>(ncode[k]) & geo<ND>::DMASK));
     } else {
         flags[n_nodes] = tri{0u, 0u, 0u};
     }
@@ -529,7 +583,7 @@ __global__ void k_crit(const uint4 *topo, const tri *flags, const tri *offs, uin
     boxes[2u * g + 1u] = hi;
 }
 
-template <typename F>
+template <typename F, int ND>
 __global__ void k_records(uint4 *topo, const uint64_t *ncode, const uint32_t *parent, const uint32_t *mask,
                           const tri *offs, uint32_t n_nodes,
                           const typename vt<F>::v4 *node_com, const typename vt<F>::v2 *node_mac, node_rec<F> *recs,
@@ -542,7 +596,7 @@ __global__ void k_records(uint4 *topo, const uint64_t *ncode, const uint32_t *pa
     uint32_t rec = 0;
     if (k != 0u) {
         const uint32_t p = parent[k];
-        const unsigned digit = static_cast<unsigned>(ncode[k] & 7ull);
+        const unsigned digit = static_cast<unsigned>(ncode[k]) & geo<ND>::DMASK;
         const uint32_t rank = static_cast<uint32_t>(__popc(mask[p] & ((1u << digit) - 1u)));
         rec = 1u + offs[p].c + rank; // children of p occupy records [1 + offs[p].c, ...)
         child_tab[static_cast<size_t>(offs[p].b) * 8u + rank] = k;
@@ -685,10 +739,11 @@ void exclusive_scan(const tri *in, tri *out, size_t n, hipStream_t st)
 } // namespace bld
 
 // Builds the tree and fills `s` (buffers, sizes). Host inputs in the caller's original order.
-template <typename F>
+template <typename F, int ND>
 void build_device(rk_state &s, const void *const parts[4], bool parts_on_device, int64_t nparts, double box_size_in,
                   uint64_t max_leaf_n, std::string &bad_coord_msg)
 {
+    constexpr unsigned CBITS = bld::geo<ND>::CB;
     using namespace bld;
     using v4 = typename vt<F>::v4;
     using v2 = typename vt<F>::v2;
@@ -697,14 +752,19 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     const size_t fb = static_cast<size_t>(n) * sizeof(F);
 
     // Inputs: copied from the host, or used in place when they already live on this device.
+    // parts = ND coordinate arrays, then the masses; in[] is always {x, y, z or null, m}.
     dptr<F> own[4];
-    const F *in[4];
+    const F *in[4] = {};
     for (int k = 0; k < 4; ++k) {
+        const int src = k < ND ? k : (k == 3 ? ND : -1);
+        if (src < 0) {
+            continue;
+        }
         if (parts_on_device) {
-            in[k] = static_cast<const F *>(parts[k]);
+            in[k] = static_cast<const F *>(parts[src]);
         } else {
             own[k] = dalloc<F>(n);
-            RK_HIP(hipMemcpyAsync(own[k].get(), parts[k], fb, hipMemcpyHostToDevice, st));
+            RK_HIP(hipMemcpyAsync(own[k].get(), parts[src], fb, hipMemcpyHostToDevice, st));
             in[k] = own[k].get();
         }
     }
@@ -731,7 +791,7 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     hipLaunchKernelGGL((k_box<F>), dim3(1), dim3(1), 0, st, ctrl.get(), static_cast<F>(box_size_in));
     auto keys_in = dalloc<uint64_t>(n), keys_out = dalloc<uint64_t>(n);
     auto vals_in = dalloc<uint32_t>(n), vals_out = dalloc<uint32_t>(n);
-    hipLaunchKernelGGL((k_encode<F>), dim3(nblk(n)), dim3(256), 0, st, dx.get(), dy.get(), dz.get(), n, ctrl.get(),
+    hipLaunchKernelGGL((k_encode<F, ND>), dim3(nblk(n)), dim3(256), 0, st, dx.get(), dy.get(), dz.get(), n, ctrl.get(),
                        keys_in.get(), vals_in.get());
     {
         size_t tb = 0;
@@ -757,12 +817,12 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     auto cnt = dalloc<uint32_t>(static_cast<size_t>(n) + 1), off = dalloc<uint32_t>(static_cast<size_t>(n) + 1);
     if (mln <= 64u) {
         // ldiv doubles as the window scratch until k_node_counts fills it.
-        hipLaunchKernelGGL(k_windows, dim3(nblk(n)), dim3(256), 0, st, codes, n, mln, ldiv.get());
-        hipLaunchKernelGGL(k_leaf_levels_windows, dim3(nblk(n)), dim3(256), 0, st, ldiv.get(), n, mln, leaf.get());
+        hipLaunchKernelGGL(k_windows<ND>, dim3(nblk(n)), dim3(256), 0, st, codes, n, mln, ldiv.get());
+        hipLaunchKernelGGL(k_leaf_levels_windows<ND>, dim3(nblk(n)), dim3(256), 0, st, ldiv.get(), n, mln, leaf.get());
     } else {
-        hipLaunchKernelGGL(k_leaf_levels_search, dim3(nblk(n)), dim3(256), 0, st, codes, n, mln, leaf.get());
+        hipLaunchKernelGGL(k_leaf_levels_search<ND>, dim3(nblk(n)), dim3(256), 0, st, codes, n, mln, leaf.get());
     }
-    hipLaunchKernelGGL(k_node_counts, dim3(nblk(n)), dim3(256), 0, st, codes, n, leaf.get(), ldiv.get(), cnt.get());
+    hipLaunchKernelGGL(k_node_counts<ND>, dim3(nblk(n)), dim3(256), 0, st, codes, n, leaf.get(), ldiv.get(), cnt.get());
     exclusive_scan(cnt.get(), off.get(), n, st);
     hipLaunchKernelGGL(k_pack_nodes, dim3(1), dim3(1), 0, st, ctrl.get(), off.get() + n);
 
@@ -782,7 +842,7 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
         // Rebuild the reference's message (tree.hpp:398-413) for the first offending coordinate.
         const unsigned first_bad = ~hc.bad_inv;
         const F inv_box = F(1) / box;
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < ND; ++k) {
             F xv;
             RK_HIP(hipMemcpy(&xv, in[k] + first_bad, sizeof(F), hipMemcpyDeviceToHost));
             F tmp = std::fma(xv, inv_box, F(1) / F(2));
@@ -825,7 +885,7 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     auto *ncode = static_cast<uint64_t *>(s.bld_node_code);
     auto parent = dalloc<uint32_t>(nn);
     auto mask = dalloc<uint32_t>(nn + 1);
-    hipLaunchKernelGGL(k_emit_nodes, dim3(nblk(n)), dim3(256), 0, st, codes, n, leaf.get(), ldiv.get(), off.get(), topo,
+    hipLaunchKernelGGL(k_emit_nodes<ND>, dim3(nblk(n)), dim3(256), 0, st, codes, n, leaf.get(), ldiv.get(), off.get(), topo,
                        ncode, parent.get());
     hipLaunchKernelGGL(k_parents, dim3(nblk(nn)), dim3(256), 0, st, topo, static_cast<uint32_t>(nn), parent.get(), mask.get());
     leaf.reset(), ldiv.reset(), cnt.reset(), off.reset();
@@ -835,17 +895,17 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     hipLaunchKernelGGL((k_leaf_sums<F>), dim3(nblk(nn)), dim3(256), 0, st, topo, static_cast<uint32_t>(nn),
                        static_cast<const v4 *>(p4), sums.get());
     for (int lvl = static_cast<int>(CBITS) - 1; lvl >= 0; --lvl) {
-        hipLaunchKernelGGL((k_up_sums<F>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, static_cast<uint32_t>(nn),
+        hipLaunchKernelGGL((k_up_sums<F, ND>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, static_cast<uint32_t>(nn),
                            static_cast<unsigned>(lvl), sums.get());
     }
-    hipLaunchKernelGGL((k_finalize<F>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, static_cast<uint32_t>(nn), sums.get(),
+    hipLaunchKernelGGL((k_finalize<F, ND>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, static_cast<uint32_t>(nn), sums.get(),
                        box, s.mac, node_com, node_mac, ctrl.get());
     sums.reset();
 
     // ---- critical nodes, child masks: one scan of three counters ----
     const auto ncrit_c = static_cast<uint32_t>(std::min<uint64_t>(s.ncrit, 0xffffffffu));
     auto flags = dalloc<tri>(nn + 1), offs = dalloc<tri>(nn + 1);
-    hipLaunchKernelGGL(k_flags, dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, parent.get(), static_cast<uint32_t>(nn), ncrit_c,
+    hipLaunchKernelGGL(k_flags<ND>, dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, parent.get(), static_cast<uint32_t>(nn), ncrit_c,
                        flags.get(), mask.get());
     hipLaunchKernelGGL(k_popc, dim3(nblk(nn)), dim3(256), 0, st, mask.get(), static_cast<uint32_t>(nn), flags.get());
     exclusive_scan(flags.get(), offs.get(), nn, st);
@@ -870,7 +930,7 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     RK_HIP(hipMemsetAsync(child_tab, 0, std::max<size_t>(static_cast<size_t>(n_int) * 8 * sizeof(uint32_t), 16), st));
     hipLaunchKernelGGL((k_crit<F>), dim3(nblk(nn)), dim3(256), 0, st, topo, flags.get(), offs.get(),
                        static_cast<uint32_t>(nn), static_cast<const v4 *>(p4), crit, boxes);
-    hipLaunchKernelGGL((k_records<F>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, parent.get(), mask.get(), offs.get(),
+    hipLaunchKernelGGL((k_records<F, ND>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, parent.get(), mask.get(), offs.get(),
                        static_cast<uint32_t>(nn), node_com, node_mac, recs, child_tab);
 
     // ---- group lists of the list kernel (second half of RK_BUF_CLASS; the first half, the cross-check kernel's
@@ -901,7 +961,9 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     }
 }
 
-template void build_device<float>(rk_state &, const void *const[4], bool, int64_t, double, uint64_t, std::string &);
-template void build_device<double>(rk_state &, const void *const[4], bool, int64_t, double, uint64_t, std::string &);
+template void build_device<float, 3>(rk_state &, const void *const[4], bool, int64_t, double, uint64_t, std::string &);
+template void build_device<double, 3>(rk_state &, const void *const[4], bool, int64_t, double, uint64_t, std::string &);
+template void build_device<float, 2>(rk_state &, const void *const[4], bool, int64_t, double, uint64_t, std::string &);
+template void build_device<double, 2>(rk_state &, const void *const[4], bool, int64_t, double, uint64_t, std::string &);
 
 } // namespace rk

@@ -183,6 +183,8 @@ enum { RK_BUF_PART4 = 0, RK_BUF_NODE_COM, RK_BUF_NODE_MAC, RK_BUF_NODE_TOPO, RK_
 
 struct rk_state {
     int fp = 0, mac = 0, device = 0;
+    int ndim = 3; // 3 = octree, 2 = quadtree (particles carry z = 0 and the kernels' z output goes to z_scratch)
+    void *z_scratch = nullptr;
     int64_t nparts = 0, tree_size = 0, n_crit = 0, max_group = 0, n_internal = 0;
     uint64_t ncrit = 0;
     void *buf[RK_NBUF] = {};
@@ -245,7 +247,7 @@ template <typename F>
 void launch_super(const rk_state &s, const kparams<F> &p, int64_t s_begin, int64_t s_end, hipStream_t stream);
 template <typename F>
 void launch_block(const rk_state &s, int q, const kparams<F> &p, const uint32_t *list, int64_t n, hipStream_t stream);
-template <typename F>
+template <typename F, int ND>
 void build_device(rk_state &s, const void *const parts[4], bool parts_on_device, int64_t nparts, double box_size,
                   uint64_t max_leaf_n, std::string &bad_coord_msg);
 template <typename F>

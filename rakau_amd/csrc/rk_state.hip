@@ -51,6 +51,12 @@ struct device_guard {
     int cur = 0;
 };
 
+// Number of output arrays the CALLER passes: ndim accelerations, one potential, or both (tree_nvecs_res).
+int user_nres(const rk_state &s, int q)
+{
+    return q == 0 ? s.ndim : (q == 1 ? 1 : s.ndim + 1);
+}
+
 // Give the tree-dependent device buffers back to the pool (after a device sync: traversal kernels on other
 // streams may still be reading them) and forget everything derived from them. Streams, events and the output /
 // supergroup scratch survive, so that a state can be rebuilt in place every time step.
@@ -82,7 +88,7 @@ void free_state(rk_state *s)
     (void)hipGetDevice(&prev);
     (void)hipSetDevice(s->device);
     release_tree(s);
-    for (void *b : {s->d_out, s->sup_common, s->sup_resid, s->sup_cnt}) {
+    for (void *b : {s->d_out, s->sup_common, s->sup_resid, s->sup_cnt, s->z_scratch}) {
         rk::pool_free(b);
     }
     if (s->ev0) {
@@ -202,24 +208,27 @@ void create_impl(rk_state &s, const void *const parts[4], int64_t nparts, const 
 {
     using v4 = typename rk::vt<F>::v4;
     using v2 = typename rk::vt<F>::v2;
-    // Offsets inside rakau::tree_node_t<3, F, uint64_t, MAC> (tree_fwd.hpp:77-116 of the reference).
+    // Offsets inside rakau::tree_node_t<NDim, F, uint64_t, MAC> (tree_fwd.hpp:77-116 of the reference).
+    const auto nd = static_cast<size_t>(s.ndim);
     constexpr size_t off_props = 5 * sizeof(uint64_t);
-    constexpr size_t off_dim = off_props + 4 * sizeof(F);
+    const size_t off_dim = off_props + (nd + 1) * sizeof(F);
     const size_t min_stride = off_dim + (s.mac == RK_MAC_BH ? 1 : 2) * sizeof(F);
     if (node_stride < static_cast<int64_t>(min_stride)) {
         throw rk::error(RK_EINVAL, "node_stride (" + std::to_string(node_stride)
                                        + ") is smaller than the node record of the selected F/MAC ("
                                        + std::to_string(min_stride) + ")");
     }
+    // parts = the ndim coordinate arrays, then the masses. Quadtrees live in the z = 0 plane of the 3-D kernels:
+    // dz = 0 adds exactly nothing to any distance or acceleration.
     const auto *x = static_cast<const F *>(parts[0]), *y = static_cast<const F *>(parts[1]),
-               *z = static_cast<const F *>(parts[2]), *m = static_cast<const F *>(parts[3]);
+               *z = nd == 3 ? static_cast<const F *>(parts[2]) : nullptr, *m = static_cast<const F *>(parts[nd]);
     const auto n = static_cast<size_t>(nparts), nn = static_cast<size_t>(tree_size);
 
     std::vector<v4> part4(n);
     for (size_t i = 0; i < n; ++i) {
         part4[i].x = x[i];
         part4[i].y = y[i];
-        part4[i].z = z[i];
+        part4[i].z = z ? z[i] : F(0);
         part4[i].w = m[i];
     }
 
@@ -232,8 +241,12 @@ void create_impl(rk_state &s, const void *const parts[4], int64_t nparts, const 
         const unsigned char *rec = base + i * static_cast<size_t>(node_stride);
         uint64_t hdr[5];
         std::memcpy(hdr, rec, sizeof(hdr));
-        F props[4], dim[2] = {F(0), F(0)};
-        std::memcpy(props, rec + off_props, sizeof(props));
+        F props[4] = {F(0), F(0), F(0), F(0)}, dim[2] = {F(0), F(0)};
+        std::memcpy(props, rec + off_props, (nd + 1) * sizeof(F));
+        if (nd == 2) {
+            props[3] = props[2]; // {x, y, mass} -> {x, y, 0, mass}
+            props[2] = F(0);
+        }
         std::memcpy(dim, rec + off_dim, (s.mac == RK_MAC_BH ? 1 : 2) * sizeof(F));
         const uint64_t begin = hdr[0], end = hdr[1], nch = hdr[2];
         if (begin >= end || end > static_cast<uint64_t>(nparts) || nch > nn - 1 - i) {
@@ -340,9 +353,10 @@ void create_impl(rk_state &s, const void *const parts[4], int64_t nparts, const 
     // visiting every target).
     std::vector<v4> boxes(crit.size() * 2);
     for (size_t gi = 0; gi < crit.size(); ++gi) {
-        F lo[3] = {x[crit[gi].x], y[crit[gi].x], z[crit[gi].x]}, hi[3] = {lo[0], lo[1], lo[2]};
+        const v4 &p0 = part4[crit[gi].x];
+        F lo[3] = {p0.x, p0.y, p0.z}, hi[3] = {lo[0], lo[1], lo[2]};
         for (size_t i = crit[gi].x; i < crit[gi].y; ++i) {
-            const F pv[3] = {x[i], y[i], z[i]};
+            const F pv[3] = {part4[i].x, part4[i].y, part4[i].z};
             for (int k = 0; k < 3; ++k) {
                 lo[k] = std::min(lo[k], pv[k]);
                 hi[k] = std::max(hi[k], pv[k]);
@@ -374,6 +388,13 @@ void check_common(int fp, int mac)
     }
     if (mac != RK_MAC_BH && mac != RK_MAC_BH_GEOM) {
         throw rk::error(RK_EINVAL, "mac must be RK_MAC_BH or RK_MAC_BH_GEOM");
+    }
+}
+
+void check_ndim(int ndim)
+{
+    if (ndim != 2 && ndim != 3) {
+        throw rk::error(RK_EINVAL, "ndim must be 2 (quadtree) or 3 (octree)");
     }
 }
 
@@ -479,6 +500,24 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
     int64_t cb[rk::n_classes], ce[rk::n_classes], g_lo = 0, g_hi = 0;
     range_to_classes(s, p_begin, p_end, cb, ce, g_lo, g_hi, v2);
     auto p = base_params<F>(s, mac_value, G, eps2);
+    // Kernel-side output slots are always {ax, ay, az, pot}; a quadtree's z slot is scratch.
+    void *k_out[4] = {};
+    if (s.ndim == 3) {
+        std::copy(d_out, d_out + rk::nres_of(q), k_out);
+    } else {
+        if (q != 1 && !s.z_scratch) {
+            s.z_scratch = rk::pool_alloc(static_cast<size_t>(std::max<int64_t>(s.nparts, 1)) * sizeof(F));
+        }
+        if (q == 1) {
+            k_out[0] = d_out[0];
+        } else {
+            k_out[0] = d_out[0], k_out[1] = d_out[1], k_out[2] = s.z_scratch;
+            if (q == 2) {
+                k_out[3] = d_out[2];
+            }
+        }
+    }
+    d_out = k_out;
     for (int k = 0; k < rk::nres_of(q); ++k) {
         p.out[k] = static_cast<F *>(d_out[k]);
     }
@@ -663,7 +702,7 @@ void check_call(const rk_state *s, int q, void *const *out, double mac_value, do
     if (!out) {
         throw rk::error(RK_EINVAL, "null output array");
     }
-    for (int k = 0; k < rk::nres_of(q); ++k) {
+    for (int k = 0; k < user_nres(*s, q); ++k) {
         if (!out[k]) {
             throw rk::error(RK_EINVAL, "null output pointer");
         }
@@ -728,6 +767,13 @@ int rk_has_accelerator(void)
 int rk_state_create(rk_state **out, int fp, int mac, int device, const void *const parts[4], const uint64_t *codes,
                     int64_t nparts, const void *tree, int64_t tree_size, int64_t node_stride, uint64_t ncrit)
 {
+    return rk_state_create_nd(out, 3, fp, mac, device, parts, codes, nparts, tree, tree_size, node_stride, ncrit);
+}
+
+int rk_state_create_nd(rk_state **out, int ndim, int fp, int mac, int device, const void *const *parts,
+                       const uint64_t *codes, int64_t nparts, const void *tree, int64_t tree_size, int64_t node_stride,
+                       uint64_t ncrit)
+{
     (void)codes;
     return guard([&] {
         if (!out) {
@@ -735,10 +781,12 @@ int rk_state_create(rk_state **out, int fp, int mac, int device, const void *con
         }
         *out = nullptr;
         check_common(fp, mac);
+        check_ndim(ndim);
         if (nparts < 0 || tree_size < 0) {
             throw rk::error(RK_EINVAL, "negative size");
         }
-        if (nparts > 0 && (!parts || !parts[0] || !parts[1] || !parts[2] || !parts[3] || !tree || tree_size == 0)) {
+        if (nparts > 0 && (!parts || !parts[0] || !parts[1] || !parts[2] || (ndim == 3 && !parts[3]) || !tree
+                           || tree_size == 0)) {
             throw rk::error(RK_EINVAL, "null particle or tree array");
         }
         if (static_cast<uint64_t>(nparts) >= 0xffffffffull || static_cast<uint64_t>(tree_size) >= 0xffffffffull) {
@@ -756,6 +804,7 @@ int rk_state_create(rk_state **out, int fp, int mac, int device, const void *con
         check_device(device);
         device_guard dg(device);
         state_ptr s(new rk_state);
+        s->ndim = ndim;
         s->fp = fp;
         s->mac = mac;
         s->device = device;
@@ -838,7 +887,7 @@ int rk_acc_pot(rk_state *s, int q, int64_t p_begin, int64_t p_end, void *const *
         }
         const size_t fsz = s->fp == RK_F32 ? sizeof(float) : sizeof(double);
         const auto count = static_cast<size_t>(p_end - p_begin);
-        const int nres = rk::nres_of(q);
+        const int nres = user_nres(*s, q);
         if (!count) {
             return;
         }
@@ -909,6 +958,7 @@ int rk_state_export(const rk_state *s, int *count, void **ptrs, int64_t *bytes, 
         meta[5] = s->n_crit;
         meta[6] = static_cast<int64_t>(s->ncrit);
         meta[7] = s->n_internal;
+        meta[24] = s->ndim;
         for (int i = 0; i < RK_NBUF; ++i) {
             meta[8 + i] = s->buf_bytes[i];
         }
@@ -937,6 +987,8 @@ int rk_state_import(rk_state **out, int device, int count, void *const *ptrs, co
         s->tree_size = meta[4];
         s->ncrit = static_cast<uint64_t>(meta[6]);
         s->n_internal = meta[7];
+        s->ndim = static_cast<int>(meta[24]);
+        check_ndim(s->ndim);
         for (int i = 0; i < RK_NBUF; ++i) {
             if (bytes[i] != meta[8 + i]) {
                 throw rk::error(RK_EINVAL, "buffer size mismatch in rk_state_import");
@@ -978,9 +1030,17 @@ static void fill_from_build(rk_state &s, const void *const parts[4], bool on_dev
     if (nparts > 0) {
         std::string msg;
         if (s.fp == RK_F32) {
-            rk::build_device<float>(s, parts, on_device, nparts, box_size, s.max_leaf_n, msg);
+            if (s.ndim == 3) {
+                rk::build_device<float, 3>(s, parts, on_device, nparts, box_size, s.max_leaf_n, msg);
+            } else {
+                rk::build_device<float, 2>(s, parts, on_device, nparts, box_size, s.max_leaf_n, msg);
+            }
         } else {
-            rk::build_device<double>(s, parts, on_device, nparts, box_size, s.max_leaf_n, msg);
+            if (s.ndim == 3) {
+                rk::build_device<double, 3>(s, parts, on_device, nparts, box_size, s.max_leaf_n, msg);
+            } else {
+                rk::build_device<double, 2>(s, parts, on_device, nparts, box_size, s.max_leaf_n, msg);
+            }
         }
     }
     t1 = t2 = now();
@@ -996,9 +1056,9 @@ static void fill_from_build(rk_state &s, const void *const parts[4], bool on_dev
     }
 }
 
-static void check_build_args(const void *const parts[4], int64_t nparts, double box_size)
+static void check_build_args(const void *const *parts, int ndim, int64_t nparts, double box_size)
 {
-    if (nparts < 0 || (nparts > 0 && (!parts || !parts[0] || !parts[1] || !parts[2] || !parts[3]))) {
+    if (nparts < 0 || (nparts > 0 && (!parts || !parts[0] || !parts[1] || !parts[2] || (ndim == 3 && !parts[3])))) {
         throw rk::error(RK_EINVAL, "null particle array");
     }
     if (static_cast<uint64_t>(nparts) >= 0x7fffffffull) {
@@ -1012,8 +1072,8 @@ static void check_build_args(const void *const parts[4], int64_t nparts, double 
     }
 }
 
-static int state_build_impl(rk_state **out, int fp, int mac, int device, const void *const parts[4], bool on_device,
-                            int64_t nparts, double box_size, uint64_t max_leaf_n, uint64_t ncrit)
+static int state_build_impl(rk_state **out, int ndim, int fp, int mac, int device, const void *const *parts,
+                            bool on_device, int64_t nparts, double box_size, uint64_t max_leaf_n, uint64_t ncrit)
 {
     return guard([&] {
         if (!out) {
@@ -1021,7 +1081,8 @@ static int state_build_impl(rk_state **out, int fp, int mac, int device, const v
         }
         *out = nullptr;
         check_common(fp, mac);
-        check_build_args(parts, nparts, box_size);
+        check_ndim(ndim);
+        check_build_args(parts, ndim, nparts, box_size);
         if (!max_leaf_n) {
             throw rk::error(RK_EINVAL, "The maximum number of particles per leaf must be nonzero");
         }
@@ -1032,6 +1093,7 @@ static int state_build_impl(rk_state **out, int fp, int mac, int device, const v
         check_device(device);
         device_guard dg(device);
         state_ptr s(new rk_state);
+        s->ndim = ndim;
         s->fp = fp;
         s->mac = mac;
         s->device = device;
@@ -1045,13 +1107,24 @@ static int state_build_impl(rk_state **out, int fp, int mac, int device, const v
 int rk_state_build(rk_state **out, int fp, int mac, int device, const void *const parts[4], int64_t nparts,
                    double box_size, uint64_t max_leaf_n, uint64_t ncrit)
 {
-    return state_build_impl(out, fp, mac, device, parts, false, nparts, box_size, max_leaf_n, ncrit);
+    return state_build_impl(out, 3, fp, mac, device, parts, false, nparts, box_size, max_leaf_n, ncrit);
+}
+
+int rk_state_build_nd(rk_state **out, int ndim, int fp, int mac, int device, const void *const *parts, int on_device,
+                      int64_t nparts, double box_size, uint64_t max_leaf_n, uint64_t ncrit)
+{
+    return state_build_impl(out, ndim, fp, mac, device, parts, on_device != 0, nparts, box_size, max_leaf_n, ncrit);
+}
+
+int rk_state_ndim(const rk_state *s)
+{
+    return s ? s->ndim : 0;
 }
 
 int rk_state_build_device(rk_state **out, int fp, int mac, int device, const void *const d_parts[4], int64_t nparts,
                           double box_size, uint64_t max_leaf_n, uint64_t ncrit)
 {
-    return state_build_impl(out, fp, mac, device, d_parts, true, nparts, box_size, max_leaf_n, ncrit);
+    return state_build_impl(out, 3, fp, mac, device, d_parts, true, nparts, box_size, max_leaf_n, ncrit);
 }
 
 int rk_state_rebuild_device(rk_state *s, const void *const d_parts[4], int64_t nparts, double box_size)
@@ -1060,7 +1133,7 @@ int rk_state_rebuild_device(rk_state *s, const void *const d_parts[4], int64_t n
         if (!s) {
             throw rk::error(RK_EINVAL, "null state");
         }
-        check_build_args(d_parts, nparts, box_size);
+        check_build_args(d_parts, s->ndim, nparts, box_size);
         device_guard dg(s->device);
         release_tree(s);
         try {
@@ -1151,6 +1224,9 @@ int rk_state_download(const rk_state *s, int what, void *dst)
             return h;
         };
         if (what >= 0 && what <= 3) {
+            if (what == 2 && s->ndim == 2) {
+                throw rk::error(RK_EINVAL, "a quadtree has no z coordinates");
+            }
             const auto h = fetch(s->buf[RK_BUF_PART4], n * 4 * fsz);
             for (size_t i = 0; i < n; ++i) {
                 std::memcpy(static_cast<unsigned char *>(dst) + i * fsz, h.data() + (i * 4 + static_cast<size_t>(what)) * fsz,
@@ -1184,7 +1260,8 @@ int rk_state_download(const rk_state *s, int what, void *dst)
             const auto com = fetch(s->buf[RK_BUF_NODE_COM], nn * 4 * fsz);
             const auto macp = fetch(s->buf[RK_BUF_NODE_MAC], nn * 2 * fsz);
             const auto code = fetch(s->bld_node_code, nn * sizeof(uint64_t));
-            const size_t off_props = 40, off_dim = off_props + 4 * fsz;
+            const auto nd = static_cast<size_t>(s->ndim);
+            const size_t off_props = 40, off_dim = off_props + (nd + 1) * fsz;
             const size_t stride = ((off_dim + (s->mac == RK_MAC_BH ? 1 : 2) * fsz + 7) / 8) * 8;
             auto *o = static_cast<unsigned char *>(dst);
             std::memset(o, 0, nn * stride);
@@ -1193,9 +1270,12 @@ int rk_state_download(const rk_state *s, int what, void *dst)
                 std::memcpy(&t, topo.data() + i * sizeof(uint4), sizeof(uint4));
                 uint64_t c;
                 std::memcpy(&c, code.data() + i * 8, 8);
-                const uint64_t hdr[5] = {t.y, t.z, t.x, c, (63u - static_cast<unsigned>(__builtin_clzll(c))) / 3u};
+                const uint64_t hdr[5]
+                    = {t.y, t.z, t.x, c, (63u - static_cast<unsigned>(__builtin_clzll(c))) / static_cast<unsigned>(nd)};
                 std::memcpy(o + i * stride, hdr, sizeof(hdr));
-                std::memcpy(o + i * stride + off_props, com.data() + i * 4 * fsz, 4 * fsz);
+                // Device record {x, y, z, mass}; a quadtree's props are {x, y, mass}.
+                std::memcpy(o + i * stride + off_props, com.data() + i * 4 * fsz, nd * fsz);
+                std::memcpy(o + i * stride + off_props + nd * fsz, com.data() + (i * 4 + 3) * fsz, fsz);
                 std::memcpy(o + i * stride + off_dim, macp.data() + i * 2 * fsz, (s->mac == RK_MAC_BH ? 1 : 2) * fsz);
             }
         } else if (what == 7) {

@@ -15,12 +15,17 @@ _FP = {np.dtype(np.float32): _capi.RK_F32, np.dtype(np.float64): _capi.RK_F64}
 _MAC = {"bh": _capi.RK_MAC_BH, "bh_geom": _capi.RK_MAC_BH_GEOM}
 
 
-def node_dtype(fp_dtype, mac="bh"):
-    """numpy structured dtype laid out as rakau::tree_node_t<3, F, uint64_t, MAC>
-    (include/rakau/detail/tree_fwd.hpp:77-116 of the reference): 64/80 bytes (bh), 64/88 (bh_geom)."""
+def nres(q, ndim=3):
+    """Number of output arrays: ndim accelerations, 1 potential, or both (tree_nvecs_res)."""
+    return {0: ndim, 1: 1, 2: ndim + 1}[q]
+
+
+def node_dtype(fp_dtype, mac="bh", ndim=3):
+    """numpy structured dtype laid out as rakau::tree_node_t<ndim, F, uint64_t, MAC>
+    (include/rakau/detail/tree_fwd.hpp:77-116 of the reference): 64/80 bytes (octree, bh), 64/88 (bh_geom)."""
     f = np.dtype(fp_dtype)
     fields = [("begin", "<u8"), ("end", "<u8"), ("n_children", "<u8"), ("code", "<u8"), ("level", "<u8"),
-              ("props", f, (4,))]
+              ("props", f, (ndim + 1,))]
     fields += [("dim2", f)] if mac == "bh" else [("dim", f), ("delta", f)]
     return np.dtype(fields, align=True)
 
@@ -33,50 +38,54 @@ def mac_value_of(theta, mac, dtype):
 
 
 class State:
+    """z = None selects the 2-dimensional (quadtree) variant everywhere: coordinates are then x, y."""
+
     def __init__(self, x, y, z, m, nodes, ncrit=128, mac="bh", device=0, codes=None):
         lib = _capi.lib()
-        x, y, z, m = (np.ascontiguousarray(v) for v in (x, y, z, m))
-        self.dtype = x.dtype
-        if self.dtype not in _FP or any(v.dtype != self.dtype for v in (y, z, m)):
-            raise TypeError("x, y, z, m must share a float32 or float64 dtype")
+        arrs = [np.ascontiguousarray(v) for v in ((x, y, m) if z is None else (x, y, z, m))]
+        ndim = len(arrs) - 1
+        self.dtype = arrs[0].dtype
+        if self.dtype not in _FP or any(v.dtype != self.dtype for v in arrs):
+            raise TypeError("coordinates and masses must share a float32 or float64 dtype")
         nodes = np.ascontiguousarray(nodes)
-        if nodes.dtype != node_dtype(self.dtype, mac):
-            raise TypeError("nodes must have dtype node_dtype(%s, %r)" % (self.dtype, mac))
+        if nodes.dtype != node_dtype(self.dtype, mac, ndim):
+            raise TypeError("nodes must have dtype node_dtype(%s, %r, %d)" % (self.dtype, mac, ndim))
         self.mac = mac
         self._h = C.c_void_p()
-        parts = (C.c_void_p * 4)(x.ctypes.data, y.ctypes.data, z.ctypes.data, m.ctypes.data)
-        _capi.check(lib.rk_state_create(C.byref(self._h), _FP[self.dtype], _MAC[mac], device, parts,
-                                        codes.ctypes.data if codes is not None else None, x.size,
-                                        nodes.ctypes.data, nodes.size, nodes.dtype.itemsize, ncrit))
+        parts = (C.c_void_p * 4)(*[a.ctypes.data for a in arrs])
+        _capi.check(lib.rk_state_create_nd(C.byref(self._h), ndim, _FP[self.dtype], _MAC[mac], device, parts,
+                                           codes.ctypes.data if codes is not None else None, arrs[0].size,
+                                           nodes.ctypes.data, nodes.size, nodes.dtype.itemsize, ncrit))
         self._read_info()
 
     @classmethod
     def build(cls, x, y, z, m, box_size=None, max_leaf_n=16, ncrit=128, mac="bh", device=0):
-        """Device-side tree construction (rk_state_build): particles in the caller's original order."""
-        x, y, z, m = (np.ascontiguousarray(v) for v in (x, y, z, m))
-        dtype = x.dtype
-        if dtype not in _FP or any(v.dtype != dtype for v in (y, z, m)):
-            raise TypeError("x, y, z, m must share a float32 or float64 dtype")
-        if not (x.size == y.size == z.size == m.size):
+        """Device-side tree construction (rk_state_build_nd): particles in the caller's original order."""
+        arrs = [np.ascontiguousarray(v) for v in ((x, y, m) if z is None else (x, y, z, m))]
+        dtype = arrs[0].dtype
+        if dtype not in _FP or any(v.dtype != dtype for v in arrs):
+            raise TypeError("coordinates and masses must share a float32 or float64 dtype")
+        if any(v.size != arrs[0].size for v in arrs):
             raise ValueError("The input ranges for the particle coordinates have inconsistent sizes")
         h = C.c_void_p()
-        parts = (C.c_void_p * 4)(x.ctypes.data, y.ctypes.data, z.ctypes.data, m.ctypes.data)
-        _capi.check(_capi.lib().rk_state_build(C.byref(h), _FP[dtype], _MAC[mac], device, parts, x.size,
-                                               0.0 if box_size is None else float(box_size), max_leaf_n, ncrit))
+        parts = (C.c_void_p * 4)(*[a.ctypes.data for a in arrs])
+        _capi.check(_capi.lib().rk_state_build_nd(C.byref(h), len(arrs) - 1, _FP[dtype], _MAC[mac], device, parts, 0,
+                                                  arrs[0].size, 0.0 if box_size is None else float(box_size),
+                                                  max_leaf_n, ncrit))
         return cls._from_handle(h, dtype, mac)
 
     @classmethod
     def build_device(cls, d_ptrs, nparts, dtype, box_size=None, max_leaf_n=16, ncrit=128, mac="bh", device=0):
-        """rk_state_build_device: x, y, z, m are DEVICE addresses (e.g. torch.Tensor.data_ptr()) of `nparts` values of
-        `dtype` resident on `device`, in the caller's original order. Nothing crosses PCIe."""
+        """rk_state_build_nd(on_device): d_ptrs = DEVICE addresses (e.g. torch.Tensor.data_ptr()) of x, y, (z,) m --
+        `nparts` values of `dtype` each, resident on `device`, in the caller's original order. Nothing crosses PCIe."""
         dtype = np.dtype(dtype)
         if dtype not in _FP:
             raise TypeError("dtype must be float32 or float64")
         h = C.c_void_p()
         parts = (C.c_void_p * 4)(*d_ptrs)
-        _capi.check(_capi.lib().rk_state_build_device(C.byref(h), _FP[dtype], _MAC[mac], device, parts, nparts,
-                                                      0.0 if box_size is None else float(box_size), max_leaf_n,
-                                                      ncrit))
+        _capi.check(_capi.lib().rk_state_build_nd(C.byref(h), len(d_ptrs) - 1, _FP[dtype], _MAC[mac], device, parts, 1,
+                                                  nparts, 0.0 if box_size is None else float(box_size), max_leaf_n,
+                                                  ncrit))
         return cls._from_handle(h, dtype, mac)
 
     def rebuild_device(self, d_ptrs, nparts=None, box_size=None):
@@ -119,7 +128,7 @@ class State:
         elif sel in (4, 5):
             out = np.empty(self.nparts, dtype=np.uint64)
         elif sel == 6:
-            out = np.zeros(self.tree_size, dtype=node_dtype(self.dtype, self.mac))
+            out = np.zeros(self.tree_size, dtype=node_dtype(self.dtype, self.mac, self.ndim))
         else:
             out = np.empty((self.n_crit, 3), dtype=np.uint64)
         _capi.check(_capi.lib().rk_state_download(self._h, sel, out.ctypes.data))
@@ -141,6 +150,7 @@ class State:
         self.nparts, self.tree_size, self.n_crit, self.max_group = (int(v) for v in info[:4])
         self.device = int(info[6])
         self.ncrit = int(info[7])
+        self.ndim = int(_capi.lib().rk_state_ndim(self._h))
 
     def close(self):
         if getattr(self, "_h", None) and getattr(self, "_owned", True):
@@ -166,7 +176,7 @@ class State:
         p_end = self.nparts if p_end is None else p_end
         if out is None:
             n = self.nparts if offset_output else p_end - p_begin
-            out = [np.zeros(n, dtype=self.dtype) for _ in range(NRES[q])]
+            out = [np.zeros(n, dtype=self.dtype) for _ in range(nres(q, self.ndim))]
         ptrs = (C.c_void_p * 4)(*[o.ctypes.data for o in out], *([None] * (4 - len(out))))
         _capi.check(_capi.lib().rk_acc_pot(self._h, q, p_begin, p_end, ptrs, mac_value, G, eps2, int(offset_output)))
         return out
