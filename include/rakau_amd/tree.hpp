@@ -327,6 +327,46 @@ inline std::uint64_t morton_compact3(std::uint64_t v)
     return v;
 }
 
+// 2-D flavour: x -> even bits, y -> odd bits (libmorton/morton2D.h as used at tree.hpp:207-220 of the reference).
+inline std::uint64_t morton_spread2(std::uint64_t v)
+{
+    v &= 0xffffffffULL;
+    v = (v | (v << 16)) & 0x0000ffff0000ffffULL;
+    v = (v | (v << 8)) & 0x00ff00ff00ff00ffULL;
+    v = (v | (v << 4)) & 0x0f0f0f0f0f0f0f0fULL;
+    v = (v | (v << 2)) & 0x3333333333333333ULL;
+    v = (v | (v << 1)) & 0x5555555555555555ULL;
+    return v;
+}
+inline std::uint64_t morton_compact2(std::uint64_t v)
+{
+    v &= 0x5555555555555555ULL;
+    v = (v ^ (v >> 1)) & 0x3333333333333333ULL;
+    v = (v ^ (v >> 2)) & 0x0f0f0f0f0f0f0f0fULL;
+    v = (v ^ (v >> 4)) & 0x00ff00ff00ff00ffULL;
+    v = (v ^ (v >> 8)) & 0x0000ffff0000ffffULL;
+    v = (v ^ (v >> 16)) & 0xffffffffULL;
+    return v;
+}
+template <std::size_t NDim>
+inline std::uint64_t morton_encode(const std::uint64_t *d)
+{
+    if constexpr (NDim == 3u) {
+        return morton_spread3(d[0]) | (morton_spread3(d[1]) << 1) | (morton_spread3(d[2]) << 2);
+    } else {
+        return morton_spread2(d[0]) | (morton_spread2(d[1]) << 1);
+    }
+}
+template <std::size_t NDim>
+inline std::uint64_t morton_coord(std::uint64_t code, std::size_t j)
+{
+    if constexpr (NDim == 3u) {
+        return morton_compact3(code >> j);
+    } else {
+        return morton_compact2(code >> j);
+    }
+}
+
 // Owner of one rk_state (device-resident copy of the tree on one GPU).
 struct device_state {
     rk_state *h = nullptr;
@@ -388,7 +428,8 @@ using f_vector = std::vector<F>;
 template <std::size_t NDim, typename F, typename UInt, mac MAC>
 class tree
 {
-    static_assert(NDim == 3u, "rakau_amd::tree currently provides the 3-dimensional (octree) variant only.");
+    static_assert(NDim == 2u || NDim == 3u, "rakau_amd::tree provides quadtrees (NDim = 2) and octrees (NDim = 3).");
+    static constexpr unsigned n_children_max = 1u << NDim;
     static_assert(std::is_same_v<F, float> || std::is_same_v<F, double>,
                   "The type F must be float or double (the precisions the device kernels are built for).");
     static_assert(std::is_integral_v<UInt> && std::is_unsigned_v<UInt> && std::numeric_limits<UInt>::digits == 64,
@@ -451,7 +492,7 @@ private:
         const F half_dim = node_dim_of(level, m_box_size) * (F(1) / F(2));
         const F cell = m_box_size * (F(1) / static_cast<F>(UInt(1) << cbits));
         for (std::size_t j = 0; j < NDim; ++j) {
-            out[j] = std::fma(static_cast<F>(morton_compact3(first_cell >> j)), cell,
+            out[j] = std::fma(static_cast<F>(detail::morton_coord<NDim>(first_cell, j)), cell,
                               half_dim - m_box_size * (F(1) / F(2)));
         }
     }
@@ -460,13 +501,17 @@ private:
     void fill_node_properties(node_type &node) const
     {
         F tot_mass(0), com[NDim] = {};
-        const F *xs = m_parts[0].data(), *ys = m_parts[1].data(), *zs = m_parts[2].data(), *ms = m_parts[3].data();
+        const F *cs[NDim];
+        for (std::size_t j = 0; j < NDim; ++j) {
+            cs[j] = m_parts[j].data();
+        }
+        const F *ms = m_parts[NDim].data();
         for (size_type i = node.begin; i < node.end; ++i) {
             const F mass = ms[i];
             tot_mass += mass;
-            com[0] = std::fma(mass, xs[i], com[0]);
-            com[1] = std::fma(mass, ys[i], com[1]);
-            com[2] = std::fma(mass, zs[i], com[2]);
+            for (std::size_t j = 0; j < NDim; ++j) {
+                com[j] = std::fma(mass, cs[j][i], com[j]);
+            }
         }
         [[maybe_unused]] F centre[NDim] = {};
         if constexpr (MAC == mac::bh_geom) {
@@ -537,22 +582,22 @@ private:
         return std::max<size_type>(40000, m_codes.size() / (8u * host_threads()));
     }
 
-    // Split [begin, end) of the sorted codes into the (up to 8) children of a node at `level`.
+    // Split [begin, end) of the sorted codes into the (up to 2^NDim) children of a node at `level`.
     // Returns the child boundaries: child i owns [b[i], b[i + 1]).
-    std::array<size_type, 9> child_bounds(unsigned level, size_type begin, size_type end) const
+    std::array<size_type, n_children_max + 1u> child_bounds(unsigned level, size_type begin, size_type end) const
     {
         const unsigned shift = (cbits - level - 1u) * NDim;
-        std::array<size_type, 9> b;
+        std::array<size_type, n_children_max + 1u> b;
         b[0] = begin;
         const UInt *codes = m_codes.data();
-        for (unsigned i = 1; i < 8; ++i) {
-            // First particle whose 3-bit digit at this level is >= i.
+        for (unsigned i = 1; i < n_children_max; ++i) {
+            // First particle whose NDim-bit digit at this level is >= i.
             b[i] = static_cast<size_type>(
                 std::lower_bound(codes + b[i - 1], codes + end, i,
-                                 [shift](UInt c, unsigned digit) { return ((c >> shift) & 7u) < digit; })
+                                 [shift](UInt c, unsigned digit) { return ((c >> shift) & (n_children_max - 1u)) < digit; })
                 - codes);
         }
-        b[8] = end;
+        b[n_children_max] = end;
         return b;
     }
 
@@ -567,7 +612,7 @@ private:
         }
         const auto b = child_bounds(parent_level, begin, end);
         size_type appended = 0;
-        for (unsigned i = 0; i < 8; ++i) {
+        for (unsigned i = 0; i < n_children_max; ++i) {
             const size_type npart = b[i + 1] - b[i];
             if (!npart) {
                 continue;
@@ -616,8 +661,8 @@ private:
             bool has_future = false;
         };
         std::vector<piece> pieces;
-        pieces.reserve(8);
-        for (unsigned i = 0; i < 8; ++i) {
+        pieces.reserve(n_children_max);
+        for (unsigned i = 0; i < n_children_max; ++i) {
             const size_type npart = b[i + 1] - b[i];
             if (!npart) {
                 continue;
@@ -743,10 +788,11 @@ private:
         std::vector<key> keys(np), tmp(np);
         parallel_blocks(np, 1u << 16, [&](std::size_t b, std::size_t e) {
             for (std::size_t i = b; i < e; ++i) {
-                const UInt cx = disc_single_coord(m_parts[0][i], inv_box_size),
-                           cy = disc_single_coord(m_parts[1][i], inv_box_size),
-                           cz = disc_single_coord(m_parts[2][i], inv_box_size);
-                keys[i].code = morton_spread3(cx) | (morton_spread3(cy) << 1) | (morton_spread3(cz) << 2);
+                std::uint64_t d[NDim];
+                for (std::size_t j = 0; j < NDim; ++j) {
+                    d[j] = disc_single_coord(m_parts[j][i], inv_box_size);
+                }
+                keys[i].code = static_cast<UInt>(detail::morton_encode<NDim>(d));
                 keys[i].idx = i;
             }
         });
@@ -811,27 +857,32 @@ private:
     void sort_and_build_on_device()
     {
         const size_type np = m_parts[0].size();
-        const void *parts[4] = {m_parts[0].data(), m_parts[1].data(), m_parts[2].data(), m_parts[3].data()};
+        const void *parts[4] = {};
+        for (std::size_t j = 0; j < NDim + 1u; ++j) {
+            parts[j] = m_parts[j].data();
+        }
         detail::device_state ds;
-        throw_status(rk_state_build(&ds.h, std::is_same_v<F, float> ? RK_F32 : RK_F64,
-                                    MAC == mac::bh ? RK_MAC_BH : RK_MAC_BH_GEOM, 0, parts, static_cast<std::int64_t>(np),
-                                    m_box_size_deduced ? 0. : static_cast<double>(m_box_size), m_max_leaf_n, m_ncrit));
+        throw_status(rk_state_build_nd(&ds.h, static_cast<int>(NDim), std::is_same_v<F, float> ? RK_F32 : RK_F64,
+                                       MAC == mac::bh ? RK_MAC_BH : RK_MAC_BH_GEOM, 0, parts, 0,
+                                       static_cast<std::int64_t>(np),
+                                       m_box_size_deduced ? 0. : static_cast<double>(m_box_size), m_max_leaf_n, m_ncrit));
         std::int64_t info[8], tinfo[4];
         double box = 0.;
         throw_status(rk_state_info(ds.h, info));
         throw_status(rk_state_tree_info(ds.h, &box, tinfo));
         m_box_size = static_cast<F>(box);
         {
-            // One transfer of the {x, y, z, m} records, de-interleaved by the host threads.
+            // One transfer of the {x, y, z, m} records (z = 0 for quadtrees), de-interleaved by the host threads.
             std::vector<F> aos(static_cast<std::size_t>(np) * 4u);
             if (np) {
                 throw_status(rk_state_download(ds.h, 8, aos.data()));
             }
             parallel_blocks(np, 1u << 16, [&](std::size_t b, std::size_t e) {
                 for (std::size_t i = b; i < e; ++i) {
-                    for (std::size_t j = 0; j < 4; ++j) {
+                    for (std::size_t j = 0; j < NDim; ++j) {
                         m_parts[j][i] = aos[4u * i + j];
                     }
+                    m_parts[NDim][i] = aos[4u * i + 3u];
                 }
             });
         }
@@ -959,6 +1010,55 @@ private:
     template <typename... KwArgs>
     using generic_ctor_enabler = std::enable_if_t<generic_ctor_enabler_impl<KwArgs &&...>::value, int>;
 
+    // Compile-time checks over kwargs::coords<0> .. coords<NDim - 1>.
+    template <typename P, std::size_t... I>
+    static constexpr bool kw_has_coords(std::index_sequence<I...>)
+    {
+        return (P::has(kwargs::coords<I>) && ...);
+    }
+    template <typename P, std::size_t... I>
+    static constexpr bool kw_dup_coords(std::index_sequence<I...>)
+    {
+        return (P::duplicated(kwargs::coords<I>) || ...);
+    }
+    template <typename D, typename P, std::size_t... I>
+    static constexpr bool kw_same_coords(std::index_sequence<I...>)
+    {
+        return (std::is_same_v<D, uncvref_t<decltype(std::declval<const P &>()(kwargs::coords<I>))>> && ...);
+    }
+    using dim_seq = std::make_index_sequence<NDim>;
+
+    template <typename P, typename M, std::size_t... I>
+    void construct_from_ranges(const P &p, const M &m, F box_size, bool deduced, size_type max_leaf_n, size_type ncrit,
+                               std::index_sequence<I...>)
+    {
+        const auto size_of = [](const auto &r) { return checked_cast<size_type>(std::distance(std::begin(r), std::end(r))); };
+        const size_type sizes[] = {size_of(p(kwargs::coords<I>))...};
+        const size_type n = sizes[0];
+        for (const size_type sz : sizes) {
+            if (sz != n) {
+                throw std::invalid_argument("The input ranges for the particle coordinates have inconsistent sizes");
+            }
+        }
+        const auto nm = size_of(m);
+        if (nm != n) {
+            throw std::invalid_argument("The size of the input range for the particle masses (" + std::to_string(nm)
+                                        + ") is different from the size of "
+                                          "the input ranges for the particle coordinates ("
+                                        + std::to_string(n) + ")");
+        }
+        const auto cbegin_of = [](const auto &r) { return std::begin(r); }; // const iterators whatever was bound
+        construct_impl(box_size, deduced, std::array{cbegin_of(p(kwargs::coords<I>))..., cbegin_of(m)}, n, max_leaf_n,
+                       ncrit);
+    }
+    template <typename D, typename P, std::size_t... I>
+    void construct_from_iterators(const P &p, F box_size, bool deduced, size_type n, size_type max_leaf_n,
+                                  size_type ncrit, std::index_sequence<I...>)
+    {
+        construct_impl(box_size, deduced, std::array<D, NDim + 1u>{p(kwargs::coords<I>)..., p(kwargs::masses)}, n,
+                       max_leaf_n, ncrit);
+    }
+
 public:
     // Generic constructor with keyword arguments (tree.hpp:1573-1733): coordinates and masses as ranges
     // or as iterators + kwargs::nparts; optional kwargs::box_size, max_leaf_n, ncrit.
@@ -969,11 +1069,10 @@ public:
         using P = decltype(p);
         static_assert(!P::has_unnamed_arguments(),
                       "All the arguments for the generic constructor must be keyword arguments.");
-        static_assert(P::has_all(kwargs::coords<0>, kwargs::coords<1>, kwargs::coords<2>, kwargs::masses),
+        static_assert(kw_has_coords<P>(dim_seq{}) && P::has(kwargs::masses),
                       "The generic tree constructor needs particle coordinates for every dimension, and particle "
                       "masses.");
-        static_assert(!P::duplicated(kwargs::coords<0>) && !P::duplicated(kwargs::coords<1>)
-                          && !P::duplicated(kwargs::coords<2>) && !P::duplicated(kwargs::masses)
+        static_assert(!kw_dup_coords<P>(dim_seq{}) && !P::duplicated(kwargs::masses)
                           && !P::duplicated(kwargs::box_size) && !P::duplicated(kwargs::max_leaf_n)
                           && !P::duplicated(kwargs::ncrit) && !P::duplicated(kwargs::nparts),
                       "The generic constructor cannot have duplicate keyword arguments.");
@@ -996,8 +1095,7 @@ public:
         }
 
         using data_t = uncvref_t<decltype(p(kwargs::coords<0>))>;
-        static_assert(std::is_same_v<data_t, uncvref_t<decltype(p(kwargs::coords<1>))>>
-                          && std::is_same_v<data_t, uncvref_t<decltype(p(kwargs::coords<2>))>>,
+        static_assert(kw_same_coords<data_t, P>(dim_seq{}),
                       "All particle data in the generic tree constructor must be passed in as the same type.");
         static_assert(std::is_same_v<data_t, uncvref_t<decltype(p(kwargs::masses))>>,
                       "The type of the particle masses data is not consistent with the type of the particle "
@@ -1006,31 +1104,12 @@ public:
         if constexpr (is_range<const data_t &>::value) {
             static_assert(!P::has(kwargs::nparts), "If the particle coordinates are provided as ranges, the "
                                                    "'nparts' keyword argument must not be provided.");
-            const data_t &x = p(kwargs::coords<0>), &y = p(kwargs::coords<1>), &z = p(kwargs::coords<2>),
-                         &m = p(kwargs::masses);
-            const auto n = checked_cast<size_type>(std::distance(std::begin(x), std::end(x)));
-            if (checked_cast<size_type>(std::distance(std::begin(y), std::end(y))) != n
-                || checked_cast<size_type>(std::distance(std::begin(z), std::end(z))) != n) {
-                throw std::invalid_argument("The input ranges for the particle coordinates have inconsistent sizes");
-            }
-            const auto nm = checked_cast<size_type>(std::distance(std::begin(m), std::end(m)));
-            if (nm != n) {
-                throw std::invalid_argument("The size of the input range for the particle masses ("
-                                            + std::to_string(nm)
-                                            + ") is different from the size of "
-                                              "the input ranges for the particle coordinates ("
-                                            + std::to_string(n) + ")");
-            }
-            construct_impl(box_size, deduced, std::array{std::begin(x), std::begin(y), std::begin(z), std::begin(m)},
-                           n, max_leaf_n, ncrit);
+            construct_from_ranges(p, p(kwargs::masses), box_size, deduced, max_leaf_n, ncrit, dim_seq{});
         } else {
             static_assert(P::has(kwargs::nparts), "If the particle coordinates are provided as iterators, the "
                                                   "'nparts' keyword argument must also be provided.");
             const auto n = checked_cast<size_type>(p(kwargs::nparts));
-            construct_impl(box_size, deduced,
-                           std::array<data_t, NDim + 1u>{p(kwargs::coords<0>), p(kwargs::coords<1>),
-                                                         p(kwargs::coords<2>), p(kwargs::masses)},
-                           n, max_leaf_n, ncrit);
+            construct_from_iterators<data_t>(p, box_size, deduced, n, max_leaf_n, ncrit, dim_seq{});
         }
     }
 
@@ -1127,12 +1206,15 @@ private:
         }
         auto &d = m_dev[static_cast<std::size_t>(device)];
         if (!d.h) {
-            const void *parts[4] = {m_parts[0].data(), m_parts[1].data(), m_parts[2].data(), m_parts[3].data()};
-            throw_status(rk_state_create(&d.h, std::is_same_v<F, float> ? RK_F32 : RK_F64,
-                                         MAC == mac::bh ? RK_MAC_BH : RK_MAC_BH_GEOM, device, parts, m_codes.data(),
-                                         static_cast<std::int64_t>(nparts()), m_tree.data(),
-                                         static_cast<std::int64_t>(m_tree.size()),
-                                         static_cast<std::int64_t>(sizeof(node_type)), m_ncrit));
+            const void *parts[4] = {};
+            for (std::size_t j = 0; j < NDim + 1u; ++j) {
+                parts[j] = m_parts[j].data();
+            }
+            throw_status(rk_state_create_nd(&d.h, static_cast<int>(NDim), std::is_same_v<F, float> ? RK_F32 : RK_F64,
+                                            MAC == mac::bh ? RK_MAC_BH : RK_MAC_BH_GEOM, device, parts, m_codes.data(),
+                                            static_cast<std::int64_t>(nparts()), m_tree.data(),
+                                            static_cast<std::int64_t>(m_tree.size()),
+                                            static_cast<std::int64_t>(sizeof(node_type)), m_ncrit));
         }
         return d.h;
     }
@@ -1518,14 +1600,20 @@ public:
     // ------------------------------------------------------------------------------------------
     std::array<const F *, NDim + 1u> p_its_u() const
     {
-        return {m_parts[0].data(), m_parts[1].data(), m_parts[2].data(), m_parts[3].data()};
+        std::array<const F *, NDim + 1u> r;
+        for (std::size_t j = 0; j < NDim + 1u; ++j) {
+            r[j] = m_parts[j].data();
+        }
+        return r;
     }
     auto p_its_o() const
     {
         using it_t = perm_iterator<const F *, typename std::vector<size_type>::const_iterator>;
-        return std::array<it_t, NDim + 1u>{
-            it_t(m_parts[0].data(), m_inv_perm.begin()), it_t(m_parts[1].data(), m_inv_perm.begin()),
-            it_t(m_parts[2].data(), m_inv_perm.begin()), it_t(m_parts[3].data(), m_inv_perm.begin())};
+        std::array<it_t, NDim + 1u> r;
+        for (std::size_t j = 0; j < NDim + 1u; ++j) {
+            r[j] = it_t(m_parts[j].data(), m_inv_perm.begin());
+        }
+        return r;
     }
     const UInt *c_it_u() const
     {
@@ -1590,14 +1678,20 @@ public:
 private:
     std::array<F *, NDim + 1u> mutable_its_u()
     {
-        return {m_parts[0].data(), m_parts[1].data(), m_parts[2].data(), m_parts[3].data()};
+        std::array<F *, NDim + 1u> r;
+        for (std::size_t j = 0; j < NDim + 1u; ++j) {
+            r[j] = m_parts[j].data();
+        }
+        return r;
     }
     auto mutable_its_o()
     {
         using it_t = perm_iterator<F *, typename std::vector<size_type>::const_iterator>;
-        return std::array<it_t, NDim + 1u>{
-            it_t(m_parts[0].data(), m_inv_perm.begin()), it_t(m_parts[1].data(), m_inv_perm.begin()),
-            it_t(m_parts[2].data(), m_inv_perm.begin()), it_t(m_parts[3].data(), m_inv_perm.begin())};
+        std::array<it_t, NDim + 1u> r;
+        for (std::size_t j = 0; j < NDim + 1u; ++j) {
+            r[j] = it_t(m_parts[j].data(), m_inv_perm.begin());
+        }
+        return r;
     }
     // Particle update (tree.hpp:3744-3776): the functor moves particles, then everything is re-derived.
     // The device replicas are dropped BEFORE host data is touched and re-created on the next acc/pot call
@@ -1685,6 +1779,8 @@ private:
 
 template <typename F, mac MAC = mac::bh>
 using octree = tree<3, F, std::size_t, MAC>;
+template <typename F, mac MAC = mac::bh>
+using quadtree = tree<2, F, std::size_t, MAC>;
 
 } // namespace rakau_amd
 

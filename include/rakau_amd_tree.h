@@ -21,9 +21,13 @@ typedef struct rk_tree rk_tree;
 RK_EXPORT int rk_tree_create(rk_tree **out, int fp, int mac, const void *x, const void *y, const void *z,
                              const void *m, int64_t nparts, double box_size, uint64_t max_leaf_n, uint64_t ncrit,
                              int flags);
+/* The same for ndim = 2 (quadtree<F, MAC>) or 3: src = the ndim coordinate arrays followed by the masses. Output
+ * lists of the other entries then have ndim / 1 / ndim + 1 arrays, and the z arguments are ignored for quadtrees. */
+RK_EXPORT int rk_tree_create_nd(rk_tree **out, int ndim, int fp, int mac, const void *const *src, int64_t nparts,
+                                double box_size, uint64_t max_leaf_n, uint64_t ncrit, int flags);
 RK_EXPORT void rk_tree_destroy(rk_tree *t);
-/* info[0..6] = nparts, number of nodes, number of critical nodes, max_leaf_n, ncrit, box_size_deduced,
- * sizeof(node record); *box_size = box_size(). */
+/* info[0..7] = nparts, number of nodes, number of critical nodes, max_leaf_n, ncrit, box_size_deduced,
+ * sizeof(node record), ndim; *box_size = box_size(). */
 RK_EXPORT int rk_tree_info(const rk_tree *t, int64_t info[8], double *box_size);
 /* Copy out one array. what: 0..3 = x, y, z, masses in Morton order (p_its_u); 4 = codes (c_it_u);
  * 5 = perm(); 6 = last_perm(); 7 = inv_perm(); 8 = critical nodes as {code, begin, end} uint64 triples. */

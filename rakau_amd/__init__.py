@@ -5,6 +5,6 @@ C ABI of ``include/rakau_amd.h``), ``lib/`` (the built ``librakau_amd.so``) and 
 """
 from . import _capi
 from .state import State, node_dtype, mac_value_of, NRES, nres
-from .tree import Octree
+from .tree import Octree, Quadtree
 
-__all__ = ["State", "Octree", "node_dtype", "mac_value_of", "NRES", "nres"]
+__all__ = ["State", "Octree", "Quadtree", "node_dtype", "mac_value_of", "NRES", "nres"]

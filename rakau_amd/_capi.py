@@ -28,7 +28,7 @@ SYMBOLS = [
     "rk_state_rebuild_device", "rk_pool_trim", "rk_group_work", "rk_state_create_nd", "rk_state_build_nd",
     "rk_state_ndim",
     # host-side tree builder (include/rakau_amd_tree.h)
-    "rk_tree_create", "rk_tree_destroy", "rk_tree_info", "rk_tree_get", "rk_tree_nodes", "rk_tree_state",
+    "rk_tree_create", "rk_tree_create_nd", "rk_tree_destroy", "rk_tree_info", "rk_tree_get", "rk_tree_nodes", "rk_tree_state",
     "rk_tree_acc_pot", "rk_tree_exact", "rk_tree_update_particles",
 ]
 
@@ -100,6 +100,7 @@ def lib():
     L.rk_state_device_ptr.argtypes = [vp, ci, C.POINTER(vp), C.POINTER(i64)]
     if hasattr(L, "rk_tree_create"):
         L.rk_tree_create.argtypes = [C.POINTER(vp), ci, ci, vp, vp, vp, vp, i64, dbl, u64, u64, ci]
+        L.rk_tree_create_nd.argtypes = [C.POINTER(vp), ci, ci, ci, C.POINTER(vp), i64, dbl, u64, u64, ci]
         L.rk_tree_destroy.argtypes = [vp]
         L.rk_tree_destroy.restype = None
         L.rk_tree_info.argtypes = [vp, C.POINTER(i64), C.POINTER(dbl)]

@@ -1,4 +1,4 @@
-// C ABI over rakau_amd::octree<F, MAC> (declared in include/rakau_amd_tree.h).
+// C ABI over rakau_amd::octree<F, MAC> / quadtree<F, MAC> (declared in include/rakau_amd_tree.h).
 #include "../../include/rakau_amd/tree.hpp"
 #include "../../include/rakau_amd_tree.h"
 
@@ -10,7 +10,8 @@ namespace
 using namespace rakau_amd;
 
 using any_tree = std::variant<octree<float, mac::bh>, octree<float, mac::bh_geom>, octree<double, mac::bh>,
-                              octree<double, mac::bh_geom>>;
+                              octree<double, mac::bh_geom>, quadtree<float, mac::bh>, quadtree<float, mac::bh_geom>,
+                              quadtree<double, mac::bh>, quadtree<double, mac::bh_geom>>;
 
 thread_local std::string g_tree_err;
 
@@ -52,65 +53,101 @@ int guard(Fn &&f) noexcept
 
 template <typename Tree>
 struct fp_of;
-template <typename F, mac M>
-struct fp_of<tree<3, F, std::size_t, M>> {
+template <std::size_t ND, typename F, mac M>
+struct fp_of<tree<ND, F, std::size_t, M>> {
     using type = F;
+    static constexpr std::size_t ndim = ND;
 };
 
-template <typename F, mac M>
-octree<F, M> make_tree(const void *x, const void *y, const void *z, const void *m, std::int64_t n, double box,
-                       std::uint64_t max_leaf_n, std::uint64_t ncrit, bool dev)
+// src: the ND coordinate arrays followed by the masses.
+template <std::size_t ND, typename F, mac M>
+tree<ND, F, std::size_t, M> make_tree(const void *const *src, std::int64_t n, double box, std::uint64_t max_leaf_n,
+                                      std::uint64_t ncrit, bool dev)
 {
-    const auto *xs = static_cast<const F *>(x), *ys = static_cast<const F *>(y), *zs = static_cast<const F *>(z),
-               *ms = static_cast<const F *>(m);
-    if (box == 0.) {
-        return octree<F, M>{kwargs::x_coords = xs,         kwargs::y_coords = ys,
-                            kwargs::z_coords = zs,         kwargs::masses = ms,
-                            kwargs::nparts = n,            kwargs::max_leaf_n = max_leaf_n,
-                            kwargs::ncrit = ncrit,         kwargs::device_build = dev};
+    using tree_t = tree<ND, F, std::size_t, M>;
+    const auto *xs = static_cast<const F *>(src[0]), *ys = static_cast<const F *>(src[1]),
+               *ms = static_cast<const F *>(src[ND]);
+    if constexpr (ND == 3) {
+        const auto *zs = static_cast<const F *>(src[2]);
+        if (box == 0.) {
+            return tree_t{kwargs::x_coords = xs,         kwargs::y_coords = ys,
+                          kwargs::z_coords = zs,         kwargs::masses = ms,
+                          kwargs::nparts = n,            kwargs::max_leaf_n = max_leaf_n,
+                          kwargs::ncrit = ncrit,         kwargs::device_build = dev};
+        }
+        return tree_t{kwargs::x_coords = xs,         kwargs::y_coords = ys, kwargs::z_coords = zs,
+                      kwargs::masses = ms,           kwargs::nparts = n,    kwargs::box_size = box,
+                      kwargs::max_leaf_n = max_leaf_n, kwargs::ncrit = ncrit, kwargs::device_build = dev};
+    } else {
+        if (box == 0.) {
+            return tree_t{kwargs::x_coords = xs, kwargs::y_coords = ys,           kwargs::masses = ms,
+                          kwargs::nparts = n,    kwargs::max_leaf_n = max_leaf_n, kwargs::ncrit = ncrit,
+                          kwargs::device_build = dev};
+        }
+        return tree_t{kwargs::x_coords = xs,   kwargs::y_coords = ys,           kwargs::masses = ms,
+                      kwargs::nparts = n,      kwargs::box_size = box,          kwargs::max_leaf_n = max_leaf_n,
+                      kwargs::ncrit = ncrit,   kwargs::device_build = dev};
     }
-    return octree<F, M>{kwargs::x_coords = xs,         kwargs::y_coords = ys, kwargs::z_coords = zs,
-                        kwargs::masses = ms,           kwargs::nparts = n,    kwargs::box_size = box,
-                        kwargs::max_leaf_n = max_leaf_n, kwargs::ncrit = ncrit, kwargs::device_build = dev};
 }
 
 } // namespace
 
 extern "C" {
 
-int rk_tree_create(rk_tree **out, int fp, int mac_kind, const void *x, const void *y, const void *z, const void *m,
-                   int64_t nparts, double box_size, uint64_t max_leaf_n, uint64_t ncrit, int flags)
+int rk_tree_create_nd(rk_tree **out, int ndim, int fp, int mac_kind, const void *const *src, int64_t nparts,
+                      double box_size, uint64_t max_leaf_n, uint64_t ncrit, int flags)
 {
     return guard([&] {
         if (!out) {
             throw std::invalid_argument("null output pointer");
         }
         *out = nullptr;
-        if (nparts < 0 || (nparts > 0 && (!x || !y || !z || !m))) {
+        if (ndim != 2 && ndim != 3) {
+            throw std::invalid_argument("ndim must be 2 (quadtree) or 3 (octree)");
+        }
+        if (nparts < 0 || !src) {
             throw std::invalid_argument("invalid particle arrays");
         }
-        const int key = fp * 2 + mac_kind;
+        for (int j = 0; j < ndim + 1 && nparts > 0; ++j) {
+            if (!src[j]) {
+                throw std::invalid_argument("invalid particle arrays");
+            }
+        }
         const bool dev = (flags & 1) != 0;
         std::unique_ptr<rk_tree> t;
-        switch (key) {
-            case 0:
-                t.reset(new rk_tree{make_tree<float, mac::bh>(x, y, z, m, nparts, box_size, max_leaf_n, ncrit, dev)});
-                break;
-            case 1:
-                t.reset(new rk_tree{make_tree<float, mac::bh_geom>(x, y, z, m, nparts, box_size, max_leaf_n, ncrit, dev)});
-                break;
-            case 2:
-                t.reset(new rk_tree{make_tree<double, mac::bh>(x, y, z, m, nparts, box_size, max_leaf_n, ncrit, dev)});
-                break;
-            case 3:
-                t.reset(
-                    new rk_tree{make_tree<double, mac::bh_geom>(x, y, z, m, nparts, box_size, max_leaf_n, ncrit, dev)});
-                break;
-            default:
-                throw std::invalid_argument("invalid fp / mac selector");
+        auto make = [&](auto nd) {
+            constexpr std::size_t ND = decltype(nd)::value;
+            switch (fp * 2 + mac_kind) {
+                case 0:
+                    t.reset(new rk_tree{make_tree<ND, float, mac::bh>(src, nparts, box_size, max_leaf_n, ncrit, dev)});
+                    break;
+                case 1:
+                    t.reset(new rk_tree{make_tree<ND, float, mac::bh_geom>(src, nparts, box_size, max_leaf_n, ncrit, dev)});
+                    break;
+                case 2:
+                    t.reset(new rk_tree{make_tree<ND, double, mac::bh>(src, nparts, box_size, max_leaf_n, ncrit, dev)});
+                    break;
+                case 3:
+                    t.reset(new rk_tree{make_tree<ND, double, mac::bh_geom>(src, nparts, box_size, max_leaf_n, ncrit, dev)});
+                    break;
+                default:
+                    throw std::invalid_argument("invalid fp / mac selector");
+            }
+        };
+        if (ndim == 3) {
+            make(std::integral_constant<std::size_t, 3>{});
+        } else {
+            make(std::integral_constant<std::size_t, 2>{});
         }
         *out = t.release();
     });
+}
+
+int rk_tree_create(rk_tree **out, int fp, int mac_kind, const void *x, const void *y, const void *z, const void *m,
+                   int64_t nparts, double box_size, uint64_t max_leaf_n, uint64_t ncrit, int flags)
+{
+    const void *src[4] = {x, y, z, m};
+    return rk_tree_create_nd(out, 3, fp, mac_kind, src, nparts, box_size, max_leaf_n, ncrit, flags);
 }
 
 void rk_tree_destroy(rk_tree *t)
@@ -133,7 +170,7 @@ int rk_tree_info(const rk_tree *t, int64_t info[8], double *box_size)
                 info[4] = static_cast<int64_t>(tr.ncrit());
                 info[5] = tr.box_size_deduced();
                 info[6] = static_cast<int64_t>(sizeof(tr.nodes()[0]));
-                info[7] = 0;
+                info[7] = static_cast<int64_t>(fp_of<std::decay_t<decltype(tr)>>::ndim);
                 *box_size = static_cast<double>(tr.box_size());
             },
             t->t);
@@ -149,9 +186,14 @@ int rk_tree_get(const rk_tree *t, int what, void *dst)
         std::visit(
             [&](const auto &tr) {
                 using F = typename fp_of<std::decay_t<decltype(tr)>>::type;
+                constexpr std::size_t ND = fp_of<std::decay_t<decltype(tr)>>::ndim;
                 const auto n = tr.nparts();
                 if (what >= 0 && what <= 3) {
-                    std::memcpy(dst, tr.p_its_u()[static_cast<std::size_t>(what)], n * sizeof(F));
+                    // 0, 1, 2 = x, y, z; 3 = masses.
+                    if (what == 2 && ND == 2) {
+                        throw std::invalid_argument("a quadtree has no z coordinates");
+                    }
+                    std::memcpy(dst, tr.p_its_u()[what == 3 ? ND : static_cast<std::size_t>(what)], n * sizeof(F));
                 } else if (what == 4) {
                     std::memcpy(dst, tr.c_it_u(), n * sizeof(std::uint64_t));
                 } else if (what == 5) {
@@ -212,16 +254,23 @@ int rk_tree_acc_pot(const rk_tree *t, int q, int ordered, void *const *out, doub
         std::visit(
             [&](const auto &tr) {
                 using F = typename fp_of<std::decay_t<decltype(tr)>>::type;
+                constexpr std::size_t ND = fp_of<std::decay_t<decltype(tr)>>::ndim;
                 auto o = [&](int k) { return static_cast<F *>(out[k]); };
+                std::array<F *, ND> oa;
+                std::array<F *, ND + 1u> oap;
+                for (std::size_t k = 0; k < ND + 1u; ++k) {
+                    oap[k] = o(static_cast<int>(k));
+                    if (k < ND) {
+                        oa[k] = oap[k];
+                    }
+                }
                 const F th = static_cast<F>(theta);
                 switch (q * 2 + (ordered ? 1 : 0)) {
                     case 0:
-                        tr.accs_u(std::array<F *, 3>{o(0), o(1), o(2)}, th, kwargs::G = G, kwargs::eps = eps,
-                                  kwargs::split = sp);
+                        tr.accs_u(oa, th, kwargs::G = G, kwargs::eps = eps, kwargs::split = sp);
                         break;
                     case 1:
-                        tr.accs_o(std::array<F *, 3>{o(0), o(1), o(2)}, th, kwargs::G = G, kwargs::eps = eps,
-                                  kwargs::split = sp);
+                        tr.accs_o(oa, th, kwargs::G = G, kwargs::eps = eps, kwargs::split = sp);
                         break;
                     case 2:
                         tr.pots_u(o(0), th, kwargs::G = G, kwargs::eps = eps, kwargs::split = sp);
@@ -230,12 +279,10 @@ int rk_tree_acc_pot(const rk_tree *t, int q, int ordered, void *const *out, doub
                         tr.pots_o(o(0), th, kwargs::G = G, kwargs::eps = eps, kwargs::split = sp);
                         break;
                     case 4:
-                        tr.accs_pots_u(std::array<F *, 4>{o(0), o(1), o(2), o(3)}, th, kwargs::G = G,
-                                       kwargs::eps = eps, kwargs::split = sp);
+                        tr.accs_pots_u(oap, th, kwargs::G = G, kwargs::eps = eps, kwargs::split = sp);
                         break;
                     case 5:
-                        tr.accs_pots_o(std::array<F *, 4>{o(0), o(1), o(2), o(3)}, th, kwargs::G = G,
-                                       kwargs::eps = eps, kwargs::split = sp);
+                        tr.accs_pots_o(oap, th, kwargs::G = G, kwargs::eps = eps, kwargs::split = sp);
                         break;
                     default:
                         throw std::invalid_argument("q must be 0, 1 or 2");
@@ -287,10 +334,16 @@ int rk_tree_update_particles(rk_tree *t, const void *x, const void *y, const voi
         std::visit(
             [&](auto &tr) {
                 using F = typename fp_of<std::decay_t<decltype(tr)>>::type;
+                constexpr std::size_t ND = fp_of<std::decay_t<decltype(tr)>>::ndim;
                 const auto n = tr.nparts();
-                const void *src[4] = {x, y, z, m};
+                const void *all[4] = {x, y, z, m};
+                const void *src[ND + 1u];
+                for (std::size_t j = 0; j < ND; ++j) {
+                    src[j] = all[j];
+                }
+                src[ND] = m; // a quadtree ignores z
                 tr.update_particles_u([&](const auto &its) {
-                    for (std::size_t j = 0; j < 4; ++j) {
+                    for (std::size_t j = 0; j < ND + 1u; ++j) {
                         if (src[j]) {
                             std::copy(static_cast<const F *>(src[j]), static_cast<const F *>(src[j]) + n, its[j]);
                         }

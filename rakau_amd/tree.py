@@ -10,20 +10,25 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from .state import State, node_dtype, NRES
+from .state import State, node_dtype, nres
 
 _FP = {np.dtype(np.float32): _capi.RK_F32, np.dtype(np.float64): _capi.RK_F64}
 _MAC = {"bh": _capi.RK_MAC_BH, "bh_geom": _capi.RK_MAC_BH_GEOM}
 
 
 class Octree:
+    """rakau::octree<F, MAC>; z_coords = None gives rakau::quadtree<F, MAC> (see Quadtree)."""
+
     def __init__(self, x_coords, y_coords, z_coords, masses, box_size=None, max_leaf_n=16, ncrit=128, mac="bh",
                  builder="host"):
-        x, y, z, m = (np.ascontiguousarray(v) for v in (x_coords, y_coords, z_coords, masses))
+        coords = [x_coords, y_coords] + ([] if z_coords is None else [z_coords])
+        arrs = [np.ascontiguousarray(v) for v in coords + [masses]]
+        self.ndim = len(coords)
+        x, m = arrs[0], arrs[-1]
         self.dtype = x.dtype
-        if self.dtype not in _FP or any(v.dtype != self.dtype for v in (y, z, m)):
+        if self.dtype not in _FP or any(v.dtype != self.dtype for v in arrs):
             raise TypeError("coordinates and masses must share a float32 or float64 dtype")
-        if not (x.size == y.size == z.size):
+        if any(v.size != x.size for v in arrs[:-1]):
             raise ValueError("The input ranges for the particle coordinates have inconsistent sizes")
         if m.size != x.size:
             raise ValueError("The size of the input range for the particle masses (%d) is different from the size of "
@@ -33,10 +38,10 @@ class Octree:
         if box_size is not None and box_size == 0:
             # An explicit zero box cannot hold particles; let the builder report it like the reference does.
             box_size = float(np.finfo(self.dtype).tiny)
-        _capi.check(_capi.lib().rk_tree_create(C.byref(self._h), _FP[self.dtype], _MAC[mac], x.ctypes.data,
-                                               y.ctypes.data, z.ctypes.data, m.ctypes.data, x.size,
-                                               0.0 if box_size is None else float(box_size), max_leaf_n, ncrit,
-                                               1 if builder == "device" else 0))
+        src = (C.c_void_p * 4)(*[a.ctypes.data for a in arrs])
+        _capi.check(_capi.lib().rk_tree_create_nd(C.byref(self._h), self.ndim, _FP[self.dtype], _MAC[mac], src, x.size,
+                                                  0.0 if box_size is None else float(box_size), max_leaf_n, ncrit,
+                                                  1 if builder == "device" else 0))
         self._refresh()
 
     def _refresh(self):
@@ -67,8 +72,8 @@ class Octree:
         return out
 
     def p_its_u(self):
-        """x, y, z, masses in Morton order."""
-        return [self._get(k, self.dtype) for k in range(4)]
+        """x, y, (z,) masses in Morton order."""
+        return [self._get(k, self.dtype) for k in ((0, 1, 2, 3) if self.ndim == 3 else (0, 1, 3))]
 
     def c_it_u(self):
         return self._get(4, np.uint64)
@@ -89,7 +94,7 @@ class Octree:
         """Copy of the node array with the reference's record layout (tree_fwd.hpp:77-116)."""
         ptr, cnt, stride = C.c_void_p(), C.c_int64(), C.c_int64()
         _capi.check(_capi.lib().rk_tree_nodes(self._h, C.byref(ptr), C.byref(cnt), C.byref(stride)))
-        dt = node_dtype(self.dtype, self.mac)
+        dt = node_dtype(self.dtype, self.mac, self.ndim)
         assert dt.itemsize == stride.value
         if cnt.value == 0:
             return np.zeros(0, dtype=dt)
@@ -107,7 +112,7 @@ class Octree:
 
     # ---- acc / pot -------------------------------------------------------------------------
     def _acc_pot(self, q, ordered, theta, G=1.0, eps=0.0, split=()):
-        outs = [np.zeros(self.nparts, dtype=self.dtype) for _ in range(NRES[q])]
+        outs = [np.zeros(self.nparts, dtype=self.dtype) for _ in range(nres(q, self.ndim))]
         ptrs = (C.c_void_p * 4)(*[o.ctypes.data for o in outs], *([None] * (4 - len(outs))))
         sp = (C.c_double * max(1, len(split)))(*split)
         _capi.check(_capi.lib().rk_tree_acc_pot(self._h, q, int(ordered), ptrs, theta, G, eps, sp, len(split)))
@@ -134,7 +139,7 @@ class Octree:
     def _exact(self, q, ordered, idx, G=1.0, eps=0.0):
         out = np.zeros(4, dtype=self.dtype)
         _capi.check(_capi.lib().rk_tree_exact(self._h, q, int(ordered), idx, G, eps, out.ctypes.data))
-        return out[:NRES[q]]
+        return out[:nres(q, self.ndim)]
 
     def exact_acc_u(self, idx, **kw):
         return self._exact(0, False, idx, **kw)
@@ -156,9 +161,19 @@ class Octree:
 
     # ---- updates ---------------------------------------------------------------------------
     def update_particles_u(self, func):
-        """func receives [x, y, z, m] (numpy arrays in Morton order) and modifies them in place."""
+        """func receives [x, y, (z,) m] (numpy arrays in Morton order) and modifies them in place."""
         arrs = self.p_its_u()
         func(arrs)
         arrs = [np.ascontiguousarray(a, dtype=self.dtype) for a in arrs]
-        _capi.check(_capi.lib().rk_tree_update_particles(self._h, *[a.ctypes.data for a in arrs]))
+        ptrs = [a.ctypes.data for a in arrs]
+        if self.ndim == 2:
+            ptrs = [ptrs[0], ptrs[1], None, ptrs[2]]
+        _capi.check(_capi.lib().rk_tree_update_particles(self._h, *ptrs))
         self._refresh()
+
+
+class Quadtree(Octree):
+    """rakau::quadtree<F, MAC>: the 2-dimensional variant (accelerations have two components)."""
+
+    def __init__(self, x_coords, y_coords, masses, **kw):
+        super().__init__(x_coords, y_coords, None, masses, **kw)

@@ -142,12 +142,85 @@ static void gpu_checks()
     }
 }
 
+// Quadtrees: the call shapes of test/node_centre.cpp:23-53 and the 2-D flavour of the accuracy checks.
+template <typename F, mac M>
+static void quadtree_host_checks()
+{
+    using tree_t = quadtree<F, M>;
+    tree_t t;
+    CHECK(t.nodes().size() == 0u);
+    t = tree_t{x_coords = std::vector<F>{-1, -1, 1, 1}, y_coords = std::vector<F>{-1, 1, -1, 1},
+               masses = std::vector<F>{1, 1, 1, 1}, box_size = 10, max_leaf_n = 1};
+    CHECK(t.nodes().size() == 5u);
+    CHECK(t.nodes()[0].code == 1u && t.nodes()[1].code == 4u && t.nodes()[4].code == 7u);
+    CHECK(t.nodes()[1].props[0] == F(-1) && t.nodes()[1].props[1] == F(-1) && t.nodes()[1].props[2] == F(1));
+    CHECK(t.nodes()[2].props[0] == F(1) && t.nodes()[2].props[1] == F(-1));
+    CHECK(t.nodes()[0].props[2] == F(4));
+    std::mt19937 rng(3);
+    const std::size_t s = 1500;
+    std::vector<F> m(s), x(s), y(s);
+    std::uniform_real_distribution<F> md(F(0), F(1)), rd(F(-0.5), F(0.5));
+    for (std::size_t i = 0; i < s; ++i) m[i] = md(rng), x[i] = rd(rng), y[i] = rd(rng);
+    tree_t u{x_coords = x, y_coords = y, masses = m};
+    CHECK(u.nparts() == s && u.perm().size() == s);
+    for (std::size_t i = 1; i < s; ++i) CHECK(u.c_it_u()[i - 1] <= u.c_it_u()[i]);
+    for (std::size_t i = 0; i < s; ++i) CHECK(u.p_its_o()[0][static_cast<std::ptrdiff_t>(i)] == x[i]);
+    const auto e = u.exact_acc_pot_o(7);
+    CHECK(e.size() == 3u && std::isfinite(e[0]) && std::isfinite(e[2]));
+    CHECK_THROWS((tree_t{x_coords = x, y_coords = std::vector<F>(3), masses = m}), std::invalid_argument,
+                 "inconsistent sizes");
+}
+
+template <typename F, mac M>
+static void quadtree_gpu_checks(bool on_device)
+{
+    std::mt19937 rng(5);
+    const std::size_t s = 2500;
+    std::vector<F> m(s), x(s), y(s);
+    std::uniform_real_distribution<F> md(F(0), F(1)), rd(F(-0.5), F(0.5));
+    for (std::size_t i = 0; i < s; ++i) m[i] = md(rng), x[i] = rd(rng), y[i] = rd(rng);
+    quadtree<F, M> t{x_coords = x.data(), y_coords = y.data(), masses = m.data(), nparts = s, box_size = F(2),
+                     device_build = on_device};
+    const F theta = F(0.001);
+    const double tol = std::is_same_v<F, double> ? 5e-10 : 5e-2;
+    std::array<std::vector<F>, 2> accs;
+    t.accs_o(accs, theta);
+    std::vector<F> pots;
+    t.pots_o(pots, theta, G = F(2));
+    std::array<std::vector<F>, 3> ap;
+    t.accs_pots_u(ap, theta, eps = F(0.01));
+    for (std::size_t i = 0; i < s; i += 101) {
+        const auto e = t.exact_acc_o(i);
+        for (int k = 0; k < 2; ++k) CHECK(std::abs((e[k] - accs[k][i]) / e[k]) < tol);
+        CHECK(std::abs((t.exact_pot_o(i, G = F(2)) - pots[i]) / pots[i]) < tol);
+        const auto e2 = t.exact_acc_pot_u(i, eps = F(0.01));
+        for (int k = 0; k < 3; ++k) CHECK(std::abs((e2[k] - ap[k][i]) / e2[k]) < tol);
+    }
+    std::vector<F> ax(s), ay(s);
+    t.accs_u({ax.data(), ay.data()}, F(0.75), G = 0);
+    for (std::size_t i = 0; i < s; ++i) CHECK(ax[i] == F(0) && ay[i] == F(0));
+    t.update_particles_u([s](const auto &its) {
+        for (std::size_t i = 0; i < s; ++i) its[1][i] *= F(0.5);
+    });
+    std::array<std::vector<F>, 2> acc2;
+    t.accs_o(acc2, theta);
+    for (std::size_t i = 0; i < s; i += 97) {
+        const auto e = t.exact_acc_o(i);
+        for (int k = 0; k < 2; ++k) CHECK(std::abs((e[k] - acc2[k][i]) / e[k]) < tol);
+    }
+}
+
 int main(int argc, char **argv)
 {
     const bool gpu = argc > 1 && std::strcmp(argv[1], "gpu") == 0;
     host_checks<float, mac::bh>();
     host_checks<double, mac::bh_geom>();
+    quadtree_host_checks<double, mac::bh>();
+    quadtree_host_checks<float, mac::bh_geom>();
     if (gpu) {
+        quadtree_gpu_checks<double, mac::bh>(false);
+        quadtree_gpu_checks<double, mac::bh_geom>(true);
+        quadtree_gpu_checks<float, mac::bh>(true);
         gpu_checks<float, mac::bh>();
         gpu_checks<double, mac::bh>();
         gpu_checks<double, mac::bh_geom>();

@@ -121,3 +121,43 @@ def test_device_outputs_ordered_and_rebuild_2d():
     assert st.ndim == 2 and np.array_equal(st.download("codes"), fresh.download("codes"))
     for a, b in zip(st.acc_pot(0, mv), fresh.acc_pot(0, mv)):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("builder", ["host", "device"])
+def test_quadtree_front_door(dtype, builder):
+    """rakau::quadtree's acc/pot surface through the C++ header (Quadtree): ordering_acc.cpp / accuracy_acc.cpp style
+    checks against the direct sum, _u vs _o, split invariance, G scaling, update_particles."""
+    rng = oracle.Rng(21)
+    s = 8000
+    m, x, y = rng.uniform_particles(s, 1.0, dtype, ndim=2)
+    t = rakau_amd.Quadtree(x, y, m, box_size=4.0, builder=builder)
+    tol = 2e-3 if dtype == np.float32 else 2e-11
+    au, ao = t.accs_u(0.01), t.accs_o(0.01)
+    assert len(au) == 2 and len(t.accs_pots_o(0.75)) == 3
+    perm = t.perm().astype(np.int64)
+    for u, o in zip(au, ao):
+        assert np.array_equal(o[perm], u)
+    for i in range(0, s, 499):
+        ex = t.exact_acc_o(i).astype(np.float64)
+        got = np.array([a[i] for a in ao], dtype=np.float64)
+        assert abs(np.linalg.norm(ex) - np.linalg.norm(got)) / np.linalg.norm(ex) <= tol
+        assert abs(t.exact_pot_o(i, G=2.0, eps=0.1) - t.pots_o(0.01, G=2.0, eps=0.1)[i]) <= tol * abs(t.exact_pot_o(i, G=2.0, eps=0.1))
+    a1, a2, a3 = t.accs_u(0.75), t.accs_u(0.75, G=2.0), t.accs_u(0.75, split=[0.3, 0.7])
+    for u, v, w in zip(a1, a2, a3):
+        assert np.array_equal(2 * u, v) and np.array_equal(u, w)
+    ot = oracle.Tree(x, y, None, m, box_size=4.0, ndim=2)
+    e = rel_err_vec(a1, ot.acc_pot(0, 0.75, nthreads=4), ndim=2)
+    assert np.median(e) < (1e-6 if dtype == np.float32 else 1e-14) and e.max() < tol
+
+    def rot(a):
+        c, sn = dtype(np.cos(0.3)), dtype(np.sin(0.3))
+        ax, ay = a[0].copy(), a[1].copy()
+        a[0][:], a[1][:] = c * ax - sn * ay, sn * ax + c * ay
+
+    t.update_particles_u(rot)
+    ao = t.accs_o(0.01)
+    for i in range(0, s, 997):
+        ex = t.exact_acc_o(i).astype(np.float64)
+        got = np.array([a[i] for a in ao], dtype=np.float64)
+        assert abs(np.linalg.norm(ex) - np.linalg.norm(got)) / np.linalg.norm(ex) <= tol

@@ -133,3 +133,58 @@ def test_constructor_errors():
         rakau_amd.Octree(np.ones(3), x[1], x[2], m)
     with pytest.raises(ValueError, match="particle masses"):
         rakau_amd.Octree(*x, np.ones(3))
+
+
+# ---- quadtrees (rakau::quadtree<F, MAC>) -----------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("mac", ["bh", "bh_geom"])
+def test_quadtree_matches_oracle(dtype, mac):
+    rng = oracle.Rng(13)
+    m, x, y = rng.uniform_particles(120000, 3.0, dtype, ndim=2)  # large enough for the task-parallel build path
+    pt = rakau_amd.Quadtree(x, y, m, mac=mac)
+    assert pt.ndim == 2 and len(pt.p_its_u()) == 3
+    assert_same_tree(pt, oracle.Tree(x, y, None, m, mac=mac, ndim=2))
+    for s in (1, 2, 17, 300, 4000):
+        m, x, y = rng.uniform_particles(s, 1.0, dtype, ndim=2)
+        for max_leaf_n, ncrit, box in ((1, 1, 1.0), (2, 16, None), (16, 128, 2.0), (8, 256, None)):
+            assert_same_tree(rakau_amd.Quadtree(x, y, m, box_size=box, max_leaf_n=max_leaf_n, ncrit=ncrit, mac=mac),
+                             oracle.Tree(x, y, None, m, box_size=box or 0.0, max_leaf_n=max_leaf_n, ncrit=ncrit, mac=mac,
+                                         ndim=2))
+
+
+def test_quadtree_deep_levels_exact_sums_and_updates():
+    rng = np.random.default_rng(2)
+    x = np.concatenate([rng.uniform(-0.5, 0.5, 1500), 0.25 + rng.uniform(0, 1e-8, 400)])
+    y = np.concatenate([rng.uniform(-0.5, 0.5, 1500), -0.125 + rng.uniform(0, 1e-8, 400)])
+    m = rng.uniform(0.5, 1.5, 1900)
+    pt, ot = rakau_amd.Quadtree(x, y, m, box_size=1.0), oracle.Tree(x, y, None, m, box_size=1.0, ndim=2)
+    assert pt.nodes()["level"].max() > 21  # deeper than an octree can go (31 vs 21 bits per coordinate)
+    assert_same_tree(pt, ot)
+    for i in (0, 7, 1899):
+        for q, name in ((0, "exact_acc"), (2, "exact_acc_pot")):
+            for ordered, sfx in ((False, "_u"), (True, "_o")):
+                got = getattr(pt, name + sfx)(i, G=2.0, eps=1e-3)
+                assert got.shape == (rakau_amd.nres(q, 2),)
+                assert np.array_equal(got, ot.exact(q, i, G=2.0, eps=1e-3, ordered=ordered))
+
+    def move(a):
+        assert len(a) == 3
+        a[0][:] = a[0] * 0.5 + 0.1
+        a[2][:] = a[2] * 2.0
+
+    pt.update_particles_u(move)
+    xs, ys, ms = ot.parts_u()
+    inv = ot.codes_perms()["inv_perm"].astype(np.int64)
+    ref = oracle.Tree((xs * 0.5 + 0.1)[inv], ys[inv], None, (ms * 2.0)[inv], box_size=1.0, ndim=2)
+    assert np.array_equal(pt.c_it_u(), ref.codes_perms()["codes"])
+    for k in ("begin", "end", "n_children", "code", "level"):
+        assert np.array_equal(pt.nodes()[k], ref.nodes()[k])
+    # perm still maps Morton positions to the caller's original indices (ties between equal codes may be ordered
+    # differently from a fresh build, which sorts from the original order).
+    perm = pt.perm().astype(np.int64)
+    assert np.array_equal(np.sort(perm), np.arange(1900))
+    assert np.array_equal((x * 0.5 + 0.1)[perm], pt.p_its_u()[0]) and np.array_equal((m * 2.0)[perm], pt.p_its_u()[2])
+    with pytest.raises(ValueError, match="inconsistent sizes"):
+        rakau_amd.Quadtree(x, y[:5], m)
+    with pytest.raises(ValueError, match="outside the allowed bounds"):
+        rakau_amd.Quadtree(x, y, m, box_size=0.5)
