@@ -18,7 +18,10 @@ __device__ __forceinline__ double rk_fma(double a, double b, double c)
 {
     return __builtin_fma(a, b, c);
 }
-// 1/sqrt(x): v_rsq_f32 (1 ulp) for fp32; for fp64 v_rsq_f64 refined by two Newton steps.
+#ifndef RK_RSQ64_STEPS
+#define RK_RSQ64_STEPS 1
+#endif
+// 1/sqrt(x): v_rsq_f32 (1 ulp) for fp32; for fp64 v_rsq_f64 refined by Newton steps.
 __device__ __forceinline__ float rk_rsqrt(float x)
 {
     return __builtin_amdgcn_rsqf(x);
@@ -26,11 +29,14 @@ __device__ __forceinline__ float rk_rsqrt(float x)
 __device__ __forceinline__ double rk_rsqrt(double x)
 {
     double y = __builtin_amdgcn_rsq(x);
-    // y <- y + y * (0.5 * (1 - x*y*y)), twice: v_rsq_f64 delivers ~2^-26 relative accuracy.
+    // y <- y + y * (0.5 * (1 - x*y*y)): v_rsq_f64 delivers ~2^-26 relative accuracy, one step squares it to ~2 ulp,
+    // a second one reaches rounding level (RK_RSQ64_STEPS).
     double e = rk_fma(-x * y, y, 1.0);
     y = rk_fma(y * 0.5, e, y);
+#if RK_RSQ64_STEPS >= 2
     e = rk_fma(-x * y, y, 1.0);
     y = rk_fma(y * 0.5, e, y);
+#endif
     return y;
 }
 

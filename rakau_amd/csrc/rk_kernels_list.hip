@@ -41,6 +41,9 @@
 #define RK_WPB 1 // wavefronts (= target groups) per workgroup. Measured 4 -> 2.58 ms, 2 -> 2.45, 1 -> 2.35 at 4M: a block keeps its
                  // LDS and wave slots until its slowest group ends, single-wave blocks free them at once (waves never sync)
 #endif
+#ifndef RK_W64
+#define RK_W64 4 // fp64 kernels (all R): waves per SIMD they are compiled for (3: 63.3 ms, 4: 62.8, 5: 67.3 at 16M)
+#endif
 #ifndef RK_W12
 #define RK_W12 7 // waves per SIMD the R <= 2 kernels are compiled for
 #endif
@@ -201,7 +204,7 @@ __device__ __forceinline__ void lk_eval_tile(const typename vt<F>::v4 *__restric
 }
 
 template <typename F, int Q, int MAC, int R>
-__global__ void __launch_bounds__(64 * RK_WPB, (sizeof(F) == 4 ? (R <= 2 ? RK_W12 : (R == 3 ? RK_W3 : (R == 4 ? RK_W4 : (R == 5 ? RK_W5 : RK_W6)))) : 1)) k_list(const kparams<F> P, const uint32_t *__restrict__ list, int n_list)
+__global__ void __launch_bounds__(64 * RK_WPB, (sizeof(F) == 4 ? (R <= 2 ? RK_W12 : (R == 3 ? RK_W3 : (R == 4 ? RK_W4 : (R == 5 ? RK_W5 : RK_W6)))) : RK_W64)) k_list(const kparams<F> P, const uint32_t *__restrict__ list, int n_list)
 {
     using v4 = typename vt<F>::v4;
     using v2 = typename vt<F>::v2;
