@@ -190,3 +190,20 @@ def test_leapfrog_conserves_energy_and_reports():
     assert res["energy_rel_drift"] < 1e-3
     assert all(abs(c) < 0.05 for c in res["com_end"])
     print("\nleapfrog 100k:", {k: res[k] for k in ("value", "ms_per_step", "ms_rebuild", "ms_traversal", "energy_rel_drift")})
+
+
+def test_native_leapfrog_harness():
+    """examples/leapfrog.hip (C ABI only, own HIP integrator kernels): builds, runs, conserves energy, and reports the
+    same tree statistics as the Python harness for the same particle count."""
+    import json
+    import subprocess
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    subprocess.check_call(["make", "-C", os.path.join(root, "examples")], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(root, "examples", "leapfrog"), "--nparts", "100000", "--steps", "20", "--warmup", "0",
+                          "--timestep", "1e-3", "--track-integrals"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert 97000 < res["nparts"] <= 100000 and res["value"] > 0
+    assert abs(res["virial_2K_over_W"] - 1.0) < 0.05 and res["energy_rel_drift"] < 1e-3
+    assert res["n_crit"] > 1000 and res["tree_size"] > res["n_crit"]
+    print("\nnative leapfrog 100k:", {k: res[k] for k in ("value", "ms_per_step", "ms_rebuild", "ms_traversal", "energy_rel_drift")})
