@@ -3,15 +3,16 @@
 // One wavefront serves one target group (critical node). It alternates between two lane mappings:
 //
 //  (1) list building, lane = candidate node. Up to 64 candidate nodes are popped from a per-wave LDS
-//      stack, their records are fetched with 64 independent loads (memory-level parallelism instead of
-//      the dependent scalar chain of variant 1), and every lane tests ITS node against ALL targets of
+//      stack (runs of siblings), their records are fetched with 64 independent loads (memory-level parallelism
+//      instead of the dependent scalar chain of variant 1), and every lane tests ITS node: first against the
+//      group's bounding box and two probe targets, and only if that is inconclusive against ALL targets of
 //      the group (target coordinates arrive through scalar loads, i.e. as SGPR operands). Accepted nodes
 //      are compacted (ballot + prefix popcount) into an LDS tile of sources {x, y, z, m}; rejected
 //      internal nodes push their children; rejected leaves queue their particle range, which is then
 //      gathered into the same tile.
 //  (2) dense evaluation, lane = (target slot, source split). When the tile is full it is consumed by a
-//      dense targets x sources loop: each lane keeps R targets in registers and walks the tile with
-//      stride NS (the number of source splits that fit in 64 lanes next to the target slots), reading
+//      dense targets x sources loop: each lane keeps R targets in registers and walks ITS contiguous share of
+//      the tile (NS = number of source splits that fit in 64 lanes next to the target slots), reading
 //      sources with broadcast ds_read_b128. Accumulators live in registers across tiles; the splits are
 //      summed in a fixed order at the end (deterministic).
 //
@@ -100,7 +101,7 @@ struct lk_cfg {
     static constexpr int src_cap = 128; // sources per tile (2 KiB fp32, 4 KiB fp64)
 };
 
-// Per-wave LDS: 2 + 2 + 1 + 0.5 KiB = 5.5 KiB (fp32): 7 four-wave blocks per CU.
+// Per-wave LDS: 2 + 2 + 1 + 0.5 KiB = 5.5 KiB (fp32; 7.5 KiB fp64): 28 single-wave blocks per CU = 7 waves per SIMD.
 template <typename F>
 struct lk_wave_lds {
     uint32_t stack[LK_STACK_CAP];
@@ -511,7 +512,7 @@ __global__ void __launch_bounds__(64 * RK_WPB, (sizeof(F) == 4 ? (R <= 2 ? RK_W1
         RK_STAMP(3)
     };
 
-    // ---- list building, software-pipelined: while batch A is tested, the records of batch B load ----
+    // ---- list building ----
     // Sources accepted for the whole supergroup: stream them from the pre-pass list through the tile.
     {
         const v4 *common = P.sup_common + static_cast<size_t>(sup_S) * SUP_CAPC;
