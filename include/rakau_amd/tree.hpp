@@ -432,8 +432,10 @@ class tree
     static constexpr unsigned n_children_max = 1u << NDim;
     static_assert(std::is_same_v<F, float> || std::is_same_v<F, double>,
                   "The type F must be float or double (the precisions the device kernels are built for).");
-    static_assert(std::is_integral_v<UInt> && std::is_unsigned_v<UInt> && std::numeric_limits<UInt>::digits == 64,
-                  "rakau_amd::tree currently provides the 64-bit Morton code variant only.");
+    static_assert(std::is_integral_v<UInt> && std::is_unsigned_v<UInt>
+                      && (std::numeric_limits<UInt>::digits == 64 || std::numeric_limits<UInt>::digits == 32),
+                  "rakau_amd::tree provides 64-bit and 32-bit Morton codes (the reference's UInt instantiations).");
+    static constexpr bool wide_codes = std::numeric_limits<UInt>::digits == 64;
     static constexpr unsigned cbits = cbits_v<UInt, NDim>;
 
 public:
@@ -856,6 +858,12 @@ private:
     // traversal state as the replica of device 0.
     void sort_and_build_on_device()
     {
+        if constexpr (wide_codes) {
+            sort_and_build_on_device_impl();
+        }
+    }
+    void sort_and_build_on_device_impl()
+    {
         const size_type np = m_parts[0].size();
         const void *parts[4] = {};
         for (std::size_t j = 0; j < NDim + 1u; ++j) {
@@ -926,9 +934,15 @@ private:
     // (construction: tree.hpp:1435-1486; after an update: tree.hpp:3678-3743).
     void sort_and_build()
     {
-        if (m_device_build && rk_has_accelerator()) {
-            sort_and_build_on_device();
-            return;
+        if (m_device_build) {
+            if constexpr (!wide_codes) {
+                throw std::invalid_argument("kwargs::device_build needs 64-bit Morton codes: the device builder produces "
+                                            "the 21 / 31 bits per coordinate of tree<NDim, F, std::uint64_t>");
+            }
+            if (rk_has_accelerator()) {
+                sort_and_build_on_device();
+                return;
+            }
         }
         const size_type np = m_parts[0].size();
         if (m_box_size_deduced) {
@@ -1210,11 +1224,33 @@ private:
             for (std::size_t j = 0; j < NDim + 1u; ++j) {
                 parts[j] = m_parts[j].data();
             }
+            // The seam takes node records with 64-bit code / level fields (tree_node_t<NDim, F, uint64_t, MAC>); trees
+            // with 32-bit codes hand over a widened copy (the device side only uses the topology and the properties).
+            using wide_node = tree_node_t<NDim, F, std::uint64_t, MAC>;
+            std::vector<wide_node> widened;
+            const void *nodes = m_tree.data();
+            if constexpr (!wide_codes) {
+                widened.resize(m_tree.size());
+                parallel_blocks(m_tree.size(), 1u << 15, [&](std::size_t b, std::size_t e) {
+                    for (std::size_t i = b; i < e; ++i) {
+                        const auto &n = m_tree[i];
+                        auto &w = widened[i];
+                        w.begin = n.begin, w.end = n.end, w.n_children = n.n_children, w.code = n.code, w.level = n.level;
+                        std::copy(std::begin(n.props), std::end(n.props), std::begin(w.props));
+                        if constexpr (MAC == mac::bh) {
+                            w.dim2 = n.dim2;
+                        } else {
+                            w.dim = n.dim, w.delta = n.delta;
+                        }
+                    }
+                });
+                nodes = widened.data();
+            }
             throw_status(rk_state_create_nd(&d.h, static_cast<int>(NDim), std::is_same_v<F, float> ? RK_F32 : RK_F64,
-                                            MAC == mac::bh ? RK_MAC_BH : RK_MAC_BH_GEOM, device, parts, m_codes.data(),
-                                            static_cast<std::int64_t>(nparts()), m_tree.data(),
+                                            MAC == mac::bh ? RK_MAC_BH : RK_MAC_BH_GEOM, device, parts, nullptr,
+                                            static_cast<std::int64_t>(nparts()), nodes,
                                             static_cast<std::int64_t>(m_tree.size()),
-                                            static_cast<std::int64_t>(sizeof(node_type)), m_ncrit));
+                                            static_cast<std::int64_t>(sizeof(wide_node)), m_ncrit));
         }
         return d.h;
     }

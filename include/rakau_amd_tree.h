@@ -22,7 +22,9 @@ RK_EXPORT int rk_tree_create(rk_tree **out, int fp, int mac, const void *x, cons
                              const void *m, int64_t nparts, double box_size, uint64_t max_leaf_n, uint64_t ncrit,
                              int flags);
 /* The same for ndim = 2 (quadtree<F, MAC>) or 3: src = the ndim coordinate arrays followed by the masses. Output
- * lists of the other entries then have ndim / 1 / ndim + 1 arrays, and the z arguments are ignored for quadtrees. */
+ * lists of the other entries then have ndim / 1 / ndim + 1 arrays, and the z arguments are ignored for quadtrees.
+ * flags bit 0: build on the device; bit 1: 32-bit Morton codes (tree<ndim, F, std::uint32_t, MAC>: 10 / 15 bits per
+ * coordinate; codes and the code / level fields of the node records are then 32 bits wide; host builder only). */
 RK_EXPORT int rk_tree_create_nd(rk_tree **out, int ndim, int fp, int mac, const void *const *src, int64_t nparts,
                                 double box_size, uint64_t max_leaf_n, uint64_t ncrit, int flags);
 RK_EXPORT void rk_tree_destroy(rk_tree *t);

@@ -55,6 +55,9 @@ def lib():
         L.orc_rng_destroy.argtypes = [C.c_void_p]
         L.orc_uniform.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_double, C.c_void_p]
         L.orc_uniform_nd.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_double, C.c_void_p]
+        L.orc_tree_create_ex.restype = C.c_void_p
+        L.orc_tree_create_ex.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_uint64,
+                                         C.c_double, C.c_uint64, C.c_uint64, C.POINTER(C.c_int)]
         L.orc_tree_create_nd.restype = C.c_void_p
         L.orc_tree_create_nd.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_uint64, C.c_double,
                                          C.c_uint64, C.c_uint64, C.POINTER(C.c_int)]
@@ -107,8 +110,10 @@ class Tree:
     """CPU restatement of rakau::octree<F, MAC> / quadtree<F, MAC> (construction + acc/pot + exact sums).
     ndim = 2: pass z = None; everything that lists coordinates then has two of them."""
 
-    def __init__(self, x, y, z, m, box_size=0.0, max_leaf_n=16, ncrit=128, mac="bh", ndim=3):
-        assert ndim in (2, 3) and (z is None) == (ndim == 2)
+    def __init__(self, x, y, z, m, box_size=0.0, max_leaf_n=16, ncrit=128, mac="bh", ndim=3, code_bits=64):
+        """code_bits = 32 restates tree<NDim, F, std::uint32_t, MAC>: 10 (3-D) / 15 (2-D) bits per coordinate."""
+        assert ndim in (2, 3) and (z is None) == (ndim == 2) and code_bits in (32, 64)
+        self.code_bits = code_bits
         arrs = [np.ascontiguousarray(v) for v in ((x, y, m) if ndim == 2 else (x, y, z, m))]
         self.ndim = ndim
         self.dtype = arrs[0].dtype
@@ -117,8 +122,8 @@ class Tree:
         self.mac = mac
         st = C.c_int(0)
         src = (C.c_void_p * 4)(*[a.ctypes.data for a in arrs])
-        self._h = lib().orc_tree_create_nd(ndim, self.fp, MAC[mac], src, arrs[0].size, float(box_size), max_leaf_n,
-                                           ncrit, C.byref(st))
+        self._h = lib().orc_tree_create_ex(ndim, code_bits, self.fp, MAC[mac], src, arrs[0].size, float(box_size),
+                                           max_leaf_n, ncrit, C.byref(st))
         _check(st.value)
         info = (C.c_uint64 * 4)()
         box = C.c_double()

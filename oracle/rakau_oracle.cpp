@@ -49,9 +49,12 @@ thread_local std::string g_last_error;
 
 // Number of bits per coordinate in the 64-bit Morton code of an ND-dimensional tree.
 // Reference: include/rakau/detail/tree_fwd.hpp:141-150 (64/3 - !(64%3) = 21 for octrees, 64/2 - 1 = 31 for quadtrees).
-template <unsigned ND>
-constexpr unsigned cbits_of = 64u / ND - !(64u % ND);
-static_assert(cbits_of<3> == 21 && cbits_of<2> == 31);
+// With 32-bit codes (UInt = std::uint32_t, one of the reference's instantiations): 10 and 15.
+constexpr unsigned cbits_for(unsigned code_bits, unsigned nd)
+{
+    return code_bits / nd - !(code_bits % nd);
+}
+static_assert(cbits_for(64, 3) == 21 && cbits_for(64, 2) == 31 && cbits_for(32, 3) == 10 && cbits_for(32, 2) == 15);
 
 // 3D Morton encoding, x -> bit 0, y -> bit 1, z -> bit 2.
 // Reference: include/rakau/detail/libmorton/morton3D.h:38-50 (as used at tree.hpp:222-242).
@@ -140,7 +143,8 @@ struct cnode_t {
 
 template <typename F, unsigned ND>
 struct tree_t {
-    static constexpr unsigned NDim = ND, cbits = cbits_of<ND>;
+    static constexpr unsigned NDim = ND;
+    unsigned cbits = cbits_for(64, ND); // bits per coordinate; set before construct() for 32-bit codes
     using fp_type = F;
     int mac = 0; // 0 = bh, 1 = bh_geom
     F box_size = 0;
@@ -159,7 +163,7 @@ struct tree_t {
     // Reference: tree.hpp:381-429 (disc_single_coord, Clamp == false).
     u64 disc_single_coord(F x, F inv_box_size) const
     {
-        constexpr u64 factor = u64(1) << cbits;
+        const u64 factor = u64(1) << cbits;
         F tmp = std::fma(x, inv_box_size, F(1) / F(2));
         tmp *= F(factor);
         if (!std::isfinite(tmp)) {
@@ -989,8 +993,18 @@ int orc_uniform(int fp, void *out, u64 n, double size, void *rng)
 
 // mac: 0 = bh, 1 = bh_geom. box_size == 0 -> deduced. src: the ndim coordinate arrays followed by the masses.
 // Returns nullptr on error (see orc_last_error()).
+void *orc_tree_create_ex(int ndim, int code_bits, int fp, int mac, const void *const *src, u64 n, double box_size,
+                         u64 max_leaf_n, u64 ncrit, int *status);
+
 void *orc_tree_create_nd(int ndim, int fp, int mac, const void *const *src, u64 n, double box_size, u64 max_leaf_n,
                          u64 ncrit, int *status)
+{
+    return orc_tree_create_ex(ndim, 64, fp, mac, src, n, box_size, max_leaf_n, ncrit, status);
+}
+
+// code_bits: 64 or 32 = width of the Morton codes (the UInt template parameter of the reference's tree).
+void *orc_tree_create_ex(int ndim, int code_bits, int fp, int mac, const void *const *src, u64 n, double box_size,
+                         u64 max_leaf_n, u64 ncrit, int *status)
 {
     auto h = std::make_unique<handle_t>();
     h->fp = fp;
@@ -999,11 +1013,15 @@ void *orc_tree_create_nd(int ndim, int fp, int mac, const void *const *src, u64 
         if (ndim != 2 && ndim != 3) {
             throw std::invalid_argument("ndim must be 2 or 3");
         }
+        if (code_bits != 32 && code_bits != 64) {
+            throw std::invalid_argument("code_bits must be 32 or 64");
+        }
         auto make = [&](auto &ptr) {
             using T = typename std::remove_reference_t<decltype(ptr)>::element_type;
             using F = typename T::fp_type;
             ptr = std::make_unique<T>();
             ptr->mac = mac;
+            ptr->cbits = cbits_for(unsigned(code_bits), unsigned(ndim));
             const F *s[4] = {};
             for (int j = 0; j < ndim + 1; ++j) {
                 s[j] = static_cast<const F *>(src[j]);

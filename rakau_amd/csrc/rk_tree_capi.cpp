@@ -9,9 +9,17 @@ namespace
 
 using namespace rakau_amd;
 
-using any_tree = std::variant<octree<float, mac::bh>, octree<float, mac::bh_geom>, octree<double, mac::bh>,
-                              octree<double, mac::bh_geom>, quadtree<float, mac::bh>, quadtree<float, mac::bh_geom>,
-                              quadtree<double, mac::bh>, quadtree<double, mac::bh_geom>>;
+template <std::size_t ND, typename F, mac M>
+using narrow_tree = tree<ND, F, std::uint32_t, M>; // 32-bit Morton codes
+
+using any_tree
+    = std::variant<octree<float, mac::bh>, octree<float, mac::bh_geom>, octree<double, mac::bh>,
+                   octree<double, mac::bh_geom>, quadtree<float, mac::bh>, quadtree<float, mac::bh_geom>,
+                   quadtree<double, mac::bh>, quadtree<double, mac::bh_geom>, narrow_tree<3, float, mac::bh>,
+                   narrow_tree<3, float, mac::bh_geom>, narrow_tree<3, double, mac::bh>,
+                   narrow_tree<3, double, mac::bh_geom>, narrow_tree<2, float, mac::bh>,
+                   narrow_tree<2, float, mac::bh_geom>, narrow_tree<2, double, mac::bh>,
+                   narrow_tree<2, double, mac::bh_geom>>;
 
 thread_local std::string g_tree_err;
 
@@ -53,18 +61,19 @@ int guard(Fn &&f) noexcept
 
 template <typename Tree>
 struct fp_of;
-template <std::size_t ND, typename F, mac M>
-struct fp_of<tree<ND, F, std::size_t, M>> {
+template <std::size_t ND, typename F, typename UInt, mac M>
+struct fp_of<tree<ND, F, UInt, M>> {
     using type = F;
+    using code_type = UInt;
     static constexpr std::size_t ndim = ND;
 };
 
 // src: the ND coordinate arrays followed by the masses.
-template <std::size_t ND, typename F, mac M>
-tree<ND, F, std::size_t, M> make_tree(const void *const *src, std::int64_t n, double box, std::uint64_t max_leaf_n,
-                                      std::uint64_t ncrit, bool dev)
+template <std::size_t ND, typename F, mac M, typename UInt>
+tree<ND, F, UInt, M> make_tree(const void *const *src, std::int64_t n, double box, std::uint64_t max_leaf_n,
+                               std::uint64_t ncrit, bool dev)
 {
-    using tree_t = tree<ND, F, std::size_t, M>;
+    using tree_t = tree<ND, F, UInt, M>;
     const auto *xs = static_cast<const F *>(src[0]), *ys = static_cast<const F *>(src[1]),
                *ms = static_cast<const F *>(src[ND]);
     if constexpr (ND == 3) {
@@ -113,31 +122,42 @@ int rk_tree_create_nd(rk_tree **out, int ndim, int fp, int mac_kind, const void 
                 throw std::invalid_argument("invalid particle arrays");
             }
         }
-        const bool dev = (flags & 1) != 0;
+        const bool dev = (flags & 1) != 0, narrow = (flags & 2) != 0;
         std::unique_ptr<rk_tree> t;
-        auto make = [&](auto nd) {
+        auto make = [&](auto nd, auto code_tag) {
             constexpr std::size_t ND = decltype(nd)::value;
+            using UInt = typename decltype(code_tag)::type;
             switch (fp * 2 + mac_kind) {
                 case 0:
-                    t.reset(new rk_tree{make_tree<ND, float, mac::bh>(src, nparts, box_size, max_leaf_n, ncrit, dev)});
+                    t.reset(new rk_tree{make_tree<ND, float, mac::bh, UInt>(src, nparts, box_size, max_leaf_n, ncrit, dev)});
                     break;
                 case 1:
-                    t.reset(new rk_tree{make_tree<ND, float, mac::bh_geom>(src, nparts, box_size, max_leaf_n, ncrit, dev)});
+                    t.reset(new rk_tree{
+                        make_tree<ND, float, mac::bh_geom, UInt>(src, nparts, box_size, max_leaf_n, ncrit, dev)});
                     break;
                 case 2:
-                    t.reset(new rk_tree{make_tree<ND, double, mac::bh>(src, nparts, box_size, max_leaf_n, ncrit, dev)});
+                    t.reset(new rk_tree{make_tree<ND, double, mac::bh, UInt>(src, nparts, box_size, max_leaf_n, ncrit, dev)});
                     break;
                 case 3:
-                    t.reset(new rk_tree{make_tree<ND, double, mac::bh_geom>(src, nparts, box_size, max_leaf_n, ncrit, dev)});
+                    t.reset(new rk_tree{
+                        make_tree<ND, double, mac::bh_geom, UInt>(src, nparts, box_size, max_leaf_n, ncrit, dev)});
                     break;
                 default:
                     throw std::invalid_argument("invalid fp / mac selector");
             }
         };
+        struct wide {
+            using type = std::size_t;
+        };
+        struct narrow_t {
+            using type = std::uint32_t;
+        };
         if (ndim == 3) {
-            make(std::integral_constant<std::size_t, 3>{});
+            narrow ? make(std::integral_constant<std::size_t, 3>{}, narrow_t{})
+                   : make(std::integral_constant<std::size_t, 3>{}, wide{});
         } else {
-            make(std::integral_constant<std::size_t, 2>{});
+            narrow ? make(std::integral_constant<std::size_t, 2>{}, narrow_t{})
+                   : make(std::integral_constant<std::size_t, 2>{}, wide{});
         }
         *out = t.release();
     });
@@ -195,7 +215,8 @@ int rk_tree_get(const rk_tree *t, int what, void *dst)
                     }
                     std::memcpy(dst, tr.p_its_u()[what == 3 ? ND : static_cast<std::size_t>(what)], n * sizeof(F));
                 } else if (what == 4) {
-                    std::memcpy(dst, tr.c_it_u(), n * sizeof(std::uint64_t));
+                    // Codes in the tree's own width (uint64 or uint32).
+                    std::memcpy(dst, tr.c_it_u(), n * sizeof(typename fp_of<std::decay_t<decltype(tr)>>::code_type));
                 } else if (what == 5) {
                     std::memcpy(dst, tr.perm().data(), n * sizeof(std::uint64_t));
                 } else if (what == 6) {

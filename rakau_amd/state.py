@@ -20,11 +20,13 @@ def nres(q, ndim=3):
     return {0: ndim, 1: 1, 2: ndim + 1}[q]
 
 
-def node_dtype(fp_dtype, mac="bh", ndim=3):
-    """numpy structured dtype laid out as rakau::tree_node_t<ndim, F, uint64_t, MAC>
-    (include/rakau/detail/tree_fwd.hpp:77-116 of the reference): 64/80 bytes (octree, bh), 64/88 (bh_geom)."""
+def node_dtype(fp_dtype, mac="bh", ndim=3, code_bits=64):
+    """numpy structured dtype laid out as rakau::tree_node_t<ndim, F, UInt, MAC>
+    (include/rakau/detail/tree_fwd.hpp:77-116 of the reference): 64/80 bytes (octree, bh), 64/88 (bh_geom) with 64-bit
+    codes; code and level are UInt, the three sizes stay size_t."""
     f = np.dtype(fp_dtype)
-    fields = [("begin", "<u8"), ("end", "<u8"), ("n_children", "<u8"), ("code", "<u8"), ("level", "<u8"),
+    u = "<u8" if code_bits == 64 else "<u4"
+    fields = [("begin", "<u8"), ("end", "<u8"), ("n_children", "<u8"), ("code", u), ("level", u),
               ("props", f, (ndim + 1,))]
     fields += [("dim2", f)] if mac == "bh" else [("dim", f), ("delta", f)]
     return np.dtype(fields, align=True)

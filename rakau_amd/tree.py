@@ -20,7 +20,11 @@ class Octree:
     """rakau::octree<F, MAC>; z_coords = None gives rakau::quadtree<F, MAC> (see Quadtree)."""
 
     def __init__(self, x_coords, y_coords, z_coords, masses, box_size=None, max_leaf_n=16, ncrit=128, mac="bh",
-                 builder="host"):
+                 builder="host", code_bits=64):
+        """code_bits = 32: tree<NDim, F, std::uint32_t, MAC> (10 / 15 bits per coordinate)."""
+        if code_bits not in (32, 64):
+            raise ValueError("code_bits must be 32 or 64")
+        self.code_bits = code_bits
         coords = [x_coords, y_coords] + ([] if z_coords is None else [z_coords])
         arrs = [np.ascontiguousarray(v) for v in coords + [masses]]
         self.ndim = len(coords)
@@ -41,7 +45,7 @@ class Octree:
         src = (C.c_void_p * 4)(*[a.ctypes.data for a in arrs])
         _capi.check(_capi.lib().rk_tree_create_nd(C.byref(self._h), self.ndim, _FP[self.dtype], _MAC[mac], src, x.size,
                                                   0.0 if box_size is None else float(box_size), max_leaf_n, ncrit,
-                                                  1 if builder == "device" else 0))
+                                                  (1 if builder == "device" else 0) | (2 if code_bits == 32 else 0)))
         self._refresh()
 
     def _refresh(self):
@@ -76,7 +80,7 @@ class Octree:
         return [self._get(k, self.dtype) for k in ((0, 1, 2, 3) if self.ndim == 3 else (0, 1, 3))]
 
     def c_it_u(self):
-        return self._get(4, np.uint64)
+        return self._get(4, np.uint64 if self.code_bits == 64 else np.uint32)
 
     def perm(self):
         return self._get(5, np.uint64)
@@ -94,7 +98,7 @@ class Octree:
         """Copy of the node array with the reference's record layout (tree_fwd.hpp:77-116)."""
         ptr, cnt, stride = C.c_void_p(), C.c_int64(), C.c_int64()
         _capi.check(_capi.lib().rk_tree_nodes(self._h, C.byref(ptr), C.byref(cnt), C.byref(stride)))
-        dt = node_dtype(self.dtype, self.mac, self.ndim)
+        dt = node_dtype(self.dtype, self.mac, self.ndim, self.code_bits)
         assert dt.itemsize == stride.value
         if cnt.value == 0:
             return np.zeros(0, dtype=dt)

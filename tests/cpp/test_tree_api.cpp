@@ -210,6 +210,49 @@ static void quadtree_gpu_checks(bool on_device)
     }
 }
 
+// 32-bit Morton codes (tree<NDim, F, std::uint32_t, MAC>, one of the reference's instantiations): 10 / 15 bits per
+// coordinate, so the tree is at most 10 / 15 levels deep.
+template <std::size_t ND, typename F>
+static void narrow_code_checks(bool gpu)
+{
+    using tree_t = tree<ND, F, std::uint32_t, mac::bh>;
+    std::mt19937 rng(9);
+    const std::size_t s = 4000;
+    std::vector<F> m(s), c[3];
+    std::uniform_real_distribution<F> md(F(0), F(1)), rd(F(-0.5), F(0.5));
+    for (std::size_t i = 0; i < s; ++i) m[i] = md(rng);
+    for (auto &v : c) {
+        v.resize(s);
+        for (auto &x : v) x = rd(rng);
+    }
+    auto make = [&](bool dev) {
+        if constexpr (ND == 3) {
+            return tree_t{x_coords = c[0], y_coords = c[1], z_coords = c[2], masses = m, box_size = F(1), max_leaf_n = 2,
+                          device_build = dev};
+        } else {
+            return tree_t{x_coords = c[0], y_coords = c[1], masses = m, box_size = F(1), max_leaf_n = 2,
+                          device_build = dev};
+        }
+    };
+    tree_t t = make(false);
+    const unsigned cb = ND == 3 ? 10u : 15u;
+    unsigned max_level = 0;
+    for (const auto &n : t.nodes()) max_level = std::max<unsigned>(max_level, n.level);
+    CHECK(max_level <= cb && max_level >= 5u);
+    for (std::size_t i = 0; i < s; ++i) CHECK(t.c_it_u()[i] < (std::uint32_t(1) << (cb * ND)));
+    for (std::size_t i = 1; i < s; ++i) CHECK(t.c_it_u()[i - 1] <= t.c_it_u()[i]);
+    if (gpu) {
+        CHECK_THROWS(make(true), std::invalid_argument, "64-bit Morton codes");
+        std::array<std::vector<F>, ND> accs;
+        t.accs_o(accs, F(0.001));
+        const double tol = std::is_same_v<F, double> ? 5e-10 : 5e-2;
+        for (std::size_t i = 0; i < s; i += 211) {
+            const auto e = t.exact_acc_o(i);
+            for (std::size_t k = 0; k < ND; ++k) CHECK(std::abs((e[k] - accs[k][i]) / e[k]) < tol);
+        }
+    }
+}
+
 int main(int argc, char **argv)
 {
     const bool gpu = argc > 1 && std::strcmp(argv[1], "gpu") == 0;
@@ -217,6 +260,8 @@ int main(int argc, char **argv)
     host_checks<double, mac::bh_geom>();
     quadtree_host_checks<double, mac::bh>();
     quadtree_host_checks<float, mac::bh_geom>();
+    narrow_code_checks<3, double>(gpu);
+    narrow_code_checks<2, float>(gpu);
     if (gpu) {
         quadtree_gpu_checks<double, mac::bh>(false);
         quadtree_gpu_checks<double, mac::bh_geom>(true);

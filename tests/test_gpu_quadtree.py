@@ -161,3 +161,27 @@ def test_quadtree_front_door(dtype, builder):
         ex = t.exact_acc_o(i).astype(np.float64)
         got = np.array([a[i] for a in ao], dtype=np.float64)
         assert abs(np.linalg.norm(ex) - np.linalg.norm(got)) / np.linalg.norm(ex) <= tol
+
+
+@pytest.mark.parametrize("ndim", [2, 3])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_narrow_code_trees_on_gpu(ndim, dtype):
+    """tree<NDim, F, std::uint32_t, MAC> (32-bit Morton codes, the other UInt instantiation of the seam,
+    rakau_rocm.cpp:333-370): shallow trees whose deepest-level leaves hold many particles. The header widens the node
+    records at the seam; results against the 32-bit-code oracle on the identical tree."""
+    rng = oracle.Rng(23)
+    p = rng.uniform_particles(60000, 1.0, dtype, ndim=ndim)
+    m, c = p[0], list(p[1:])
+    z = c[2] if ndim == 3 else None
+    for max_leaf_n, ncrit, theta in ((16, 128, 0.75), (2, 300, 0.5)):
+        t = rakau_amd.Octree(c[0], c[1], z, m, max_leaf_n=max_leaf_n, ncrit=ncrit, code_bits=32)
+        ot = oracle.Tree(c[0], c[1], z, m, max_leaf_n=max_leaf_n, ncrit=ncrit, ndim=ndim, code_bits=32)
+        assert (t.n_nodes, t.n_crit) == (ot.n_nodes, ot.n_crit)
+        got, ref = t.accs_pots_u(theta, eps=1e-3), ot.acc_pot(2, theta, eps=1e-3, nthreads=4)
+        e = rel_err_vec(got, ref, ndim=ndim)
+        tol, med = (5e-4, 1e-6) if dtype == np.float32 else (1e-11, 1e-14)
+        assert e.max() <= tol and np.median(e) <= med
+        assert rel_err(got[-1], ref[-1]).max() <= tol
+        perm = t.perm().astype(np.int64)
+        for u, o in zip(got, t.accs_pots_o(theta, eps=1e-3)):
+            assert np.array_equal(o[perm], u)

@@ -188,3 +188,24 @@ def test_quadtree_deep_levels_exact_sums_and_updates():
         rakau_amd.Quadtree(x, y[:5], m)
     with pytest.raises(ValueError, match="outside the allowed bounds"):
         rakau_amd.Quadtree(x, y, m, box_size=0.5)
+
+
+# ---- 32-bit Morton codes (tree<NDim, F, std::uint32_t, MAC>) ------------------------------------------------------
+@pytest.mark.parametrize("ndim", [2, 3])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_narrow_codes_match_oracle(ndim, dtype):
+    """10 (3-D) / 15 (2-D) bits per coordinate: shallower trees, many particles per deepest-level leaf."""
+    rng = oracle.Rng(17)
+    for s, max_leaf_n, ncrit, box, mac in ((1, 16, 128, None, "bh"), (300, 1, 1, 1.0, "bh"), (50000, 16, 128, None, "bh_geom"),
+                                           (50000, 2, 16, 2.0, "bh")):
+        p = rng.uniform_particles(s, 1.0, dtype, ndim=ndim)
+        m, coords = p[0], list(p[1:])
+        z = coords[2] if ndim == 3 else None
+        pt = rakau_amd.Octree(coords[0], coords[1], z, m, box_size=box, max_leaf_n=max_leaf_n, ncrit=ncrit, mac=mac,
+                              code_bits=32)
+        ot = oracle.Tree(coords[0], coords[1], z, m, box_size=box or 0.0, max_leaf_n=max_leaf_n, ncrit=ncrit, mac=mac,
+                         ndim=ndim, code_bits=32)
+        assert pt.c_it_u().dtype == np.uint32 and pt.nodes()["level"].max(initial=0) <= (10 if ndim == 3 else 15)
+        assert_same_tree(pt, ot)
+    with pytest.raises(ValueError, match="64-bit Morton codes"):
+        rakau_amd.Octree(coords[0], coords[1], z, m, code_bits=32, builder="device")
