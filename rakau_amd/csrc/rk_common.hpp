@@ -49,6 +49,12 @@ __host__ __device__ constexpr int class_R(int c)
 #ifndef RK_MAX_R
 #define RK_MAX_R 4
 #endif
+#ifndef RK_MIN_R
+#define RK_MIN_R 1
+#endif
+#ifndef RK_TIE_HIGH
+#define RK_TIE_HIGH 0
+#endif
 // Targets per lane of the variant-2 (list kernel) classes.
 __host__ __device__ constexpr int class2_R(int c)
 {
@@ -70,11 +76,15 @@ __host__ __device__ inline int class2_of_compute(int64_t size)
     if (size > 64 * RK_MAX_R) return big_class;
     int best = -1;
     double best_cost = 0.;
-    for (int c = 0; c < RK_MAX_R; ++c) { // R = 1 .. RK_MAX_R
+    for (int c = RK_MIN_R - 1; c < RK_MAX_R; ++c) { // R = RK_MIN_R .. RK_MAX_R
         const int64_t R = class2_R(c), TP = (size + R - 1) / R;
         if (TP > 64) continue;
         const double cost = static_cast<double>(R) / static_cast<double>(64 / TP);
+#if RK_TIE_HIGH
+        if (best < 0 || cost < best_cost + 1e-12) { // ties go to the larger R
+#else
         if (best < 0 || cost < best_cost - 1e-12) {
+#endif
             best = c;
             best_cost = cost;
         }
