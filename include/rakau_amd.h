@@ -16,10 +16,19 @@
  *                               (called from tree::acc_pot_impl(), include/rakau/tree.hpp:3078-3094)
  *                               cuda_acc_pot_impl<Q,..>     include/rakau/detail/cuda_fwd.hpp:25-27
  *
- * The remaining entry points (rk_acc_pot_device, rk_state_export/rk_state_import, rk_state_info)
- * have no counterpart in the reference: they keep inputs/outputs resident in HBM and let a tree that
- * was uploaded on one GPU be replicated to the other GPUs of a node (RCCL broadcast of the exported
- * buffers) -- the replacement of the reference's multi-GPU split (src/rakau_cuda.cu:410-527).
+ *   rk_state_create_nd()     <- the same seam for NDim = 2 (quadtrees), src/rakau_rocm.cpp:333-345
+ *
+ * The remaining entry points have no counterpart in the reference's seam; they serve the callers either side of it
+ *  and the measurements:
+ *   device-resident outputs      rk_acc_pot_device (+ RK_OUT_ORDERED = the accs_o/pots_o scatter, tree.hpp:3320-3330)
+ *   multi-GPU replication        rk_state_export / rk_state_import / rk_device_memcpy (RCCL broadcast of the exported
+ *                                buffers: the replacement of the reference's multi-GPU split, src/rakau_cuda.cu:410-527),
+ *                                rk_state_crit_ranges, rk_group_work (where to cut)
+ *   tree construction on the GPU rk_state_build / _build_device / _build_nd / rk_state_rebuild_device (the constructor
+ *                                and update_particles_u of tree.hpp:1330-1487, 3678-3765), rk_state_download,
+ *                                rk_state_tree_info, rk_state_device_ptr, rk_state_set_perm, rk_pool_trim
+ *   diagnostics                  rk_state_info, rk_state_ndim, rk_last_kernel_ms, rk_count_interactions,
+ *                                rk_set_kernel_variant
  *
  * Plain C: pointers and sizes only. All functions are blocking and may be called from any thread;
  * at most one call may be in flight per state (same contract as the reference, tree.hpp:3071-3113).
@@ -208,7 +217,8 @@ RK_EXPORT int rk_state_tree_info(const rk_state *s, double *box_size, int64_t in
  * 4 = sorted Morton codes (uint64); 5 = perm() as uint64 (original index of the particle at Morton position i);
  * 6 = nodes() in the reference's record layout (stride 64/80 B for bh fp32/fp64, 64/88 for bh_geom);
  * 7 = critical nodes as {code, begin, end} uint64 triples; 8 = the particles as {x, y, z, m} records
- * (4 * nparts values, Morton order). 4..7 need a state made by rk_state_build().
+ * (4 * nparts values, Morton order; z = 0 for quadtrees, whose selector 2 is invalid and whose node records have
+ * props[3]). 4, 6, 7 need a state built on the device; 5 also works after rk_state_set_perm().
  */
 RK_EXPORT int rk_state_download(const rk_state *s, int what, void *dst);
 
