@@ -207,3 +207,47 @@ def test_native_leapfrog_harness():
     assert abs(res["virial_2K_over_W"] - 1.0) < 0.05 and res["energy_rel_drift"] < 1e-3
     assert res["n_crit"] > 1000 and res["tree_size"] > res["n_crit"]
     print("\nnative leapfrog 100k:", {k: res[k] for k in ("value", "ms_per_step", "ms_rebuild", "ms_traversal", "energy_rel_drift")})
+
+
+def test_new_entry_points_argument_checks():
+    """Error behaviour of the device-resident entry points: status codes and messages, no crashes."""
+    import ctypes as C
+    from rakau_amd import _capi
+    lib = _capi.lib()
+    m, x, y, z = oracle.plummer(5000, np.float32)
+    st = rakau_amd.State.build(x, y, z, m)
+    h = C.c_void_p()
+    parts = (C.c_void_p * 4)(x.ctypes.data, y.ctypes.data, z.ctypes.data, m.ctypes.data)
+    for ndim in (1, 4):
+        with pytest.raises(ValueError, match="ndim must be 2"):
+            _capi.check(lib.rk_state_build_nd(C.byref(h), ndim, 0, 0, 0, parts, 0, 5000, 0.0, 16, 128))
+    with pytest.raises(ValueError, match="null particle array"):
+        _capi.check(lib.rk_state_build_nd(C.byref(h), 3, 0, 0, 0, (C.c_void_p * 4)(x.ctypes.data, None, None, None), 0, 5000,
+                                          0.0, 16, 128))
+    with pytest.raises(ValueError, match="critical number of particles"):
+        _capi.check(lib.rk_state_build_nd(C.byref(h), 3, 0, 0, 0, parts, 0, 5000, 0.0, 16, 0))
+    with pytest.raises(ValueError, match="box size must be a finite non-negative"):
+        _capi.check(lib.rk_state_build_nd(C.byref(h), 3, 0, 0, 0, parts, 0, 5000, -1.0, 16, 128))
+    ptr, nb = C.c_void_p(), C.c_int64()
+    with pytest.raises(ValueError, match="invalid selector"):
+        _capi.check(lib.rk_state_device_ptr(st._h, 9, C.byref(ptr), C.byref(nb)))
+    with pytest.raises(ArithmeticError, match="finite and positive"):
+        st.group_work(-1.0)
+    w = st.group_work(rakau_amd.mac_value_of(0.75, "bh", np.float32))
+    cen = st.count_interactions(rakau_amd.mac_value_of(0.75, "bh", np.float32))
+    assert w.shape == (st.n_crit,) and int(w.sum()) == cen["com"] + cen["pp"] + cen["self"]
+    # A sub-range call on a device-built state (lazy host mirrors) and the full call agree bit for bit.
+    cr = st.crit_ranges()
+    cut = int(cr[len(cr) // 2, 0])
+    mv = rakau_amd.mac_value_of(0.75, "bh", np.float32)
+    full = st.acc_pot(0, mv)
+    lo, hi = st.acc_pot(0, mv, p_begin=0, p_end=cut, offset_output=False), st.acc_pot(0, mv, p_begin=cut, offset_output=False)
+    for f, a, b in zip(full, lo, hi):
+        assert np.array_equal(f, np.concatenate([a, b]))
+    big = cr[np.argmax(cr[:, 1] - cr[:, 0] > 1)]
+    with pytest.raises(ValueError, match="critical node boundaries"):
+        st.acc_pot(0, mv, p_begin=int(big[0]) + 1, p_end=st.nparts)
+    # Empty input: an empty, usable state.
+    e = np.zeros(0, dtype=np.float32)
+    empty = rakau_amd.State.build(e, e, e, e)
+    assert (empty.nparts, empty.tree_size, empty.n_crit) == (0, 0, 0) and empty.crit_ranges().shape == (0, 2)
