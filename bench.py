@@ -329,14 +329,19 @@ def main():
                                 "note": "README.md:42-49 of the reference, single cold calls on other hardware"},
     }
 
-    # PCIe-inclusive rate (never `value`): the C ABI call with host output buffers.
+    # PCIe-inclusive rate (never `value`): the seam's own call, rk_acc_pot() with host output arrays (what a tree.hpp
+    # user pays per accs_u() on a resident tree). Second call into the same, already touched, arrays.
     try:
-        t0 = time.perf_counter()
-        host_out = tree.accs_u(theta) if q == 0 else None
-        if host_out is not None:
-            line["host"]["accs_u_host_outputs_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+        if world == 1:
+            host_out = [np.zeros(n, dtype=dtype) for _ in range(nres)]
+            ts = []
+            for _ in range(5):  # the first call touches the arrays, the second captures the launch graph
+                t0 = time.perf_counter()
+                state.acc_pot(q, mac_value, eps2=eps2, out=host_out)
+                ts.append(time.perf_counter() - t0)
+            line["host"]["acc_pot_host_outputs_ms"] = round(min(ts[2:]) * 1e3, 3)
     except Exception as e:  # pragma: no cover
-        line["host"]["accs_u_host_outputs_error"] = str(e)
+        line["host"]["acc_pot_host_outputs_error"] = str(e)
 
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(m, x, y, z, mac, theta, eps, q, n, args.cpu_threads, outs, p_begin)

@@ -213,6 +213,12 @@ struct rk_state {
     // Output scratch for rk_acc_pot (host outputs).
     void *d_out = nullptr;
     size_t d_out_bytes = 0;
+    // Host-output path of rk_acc_pot(): pinned staging buffer, copy stream and per-chunk events (device-to-host
+    // chunks overlap the copies into the caller's pageable arrays).
+    void *h_stage = nullptr;
+    size_t h_stage_bytes = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copy_ev[16] = {};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // Side streams (and fork/join events) that let the per-class kernels of one call overlap.
     hipStream_t aux_stream[rk::n_list_R] = {};
