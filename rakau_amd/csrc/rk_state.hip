@@ -8,6 +8,7 @@
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <atomic>
 
@@ -146,6 +147,68 @@ void alloc_upload(rk_state &s, int which, const void *host, size_t bytes)
     }
 }
 
+// Host array without value-initialisation: the first touch of the pages happens in the (parallel) loop that fills it.
+template <typename T>
+struct raw_array {
+    explicit raw_array(size_t n) : m_p(new T[n]), m_n(n) {}
+    T *data()
+    {
+        return m_p.get();
+    }
+    const T *data() const
+    {
+        return m_p.get();
+    }
+    size_t size() const
+    {
+        return m_n;
+    }
+    T &operator[](size_t i)
+    {
+        return m_p[i];
+    }
+    const T &operator[](size_t i) const
+    {
+        return m_p[i];
+    }
+
+private:
+    std::unique_ptr<T[]> m_p;
+    size_t m_n;
+};
+
+// Run f(begin, end) over [0, n) on a few host threads (the conversions of rk_state_create are memory-bound loops).
+template <typename Fn>
+void host_parallel_for(size_t n, Fn &&f)
+{
+    const size_t grain = size_t(1) << 16;
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const auto n_thr = static_cast<unsigned>(std::min<size_t>(std::min(hw, 8u), (n + grain - 1) / grain));
+    if (n_thr <= 1) {
+        f(size_t(0), n);
+        return;
+    }
+    std::vector<std::thread> thr;
+    std::exception_ptr ep;
+    std::mutex m;
+    for (unsigned t = 0; t < n_thr; ++t) {
+        thr.emplace_back([&, t] {
+            try {
+                f(n * t / n_thr, n * (t + 1) / n_thr);
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(m);
+                ep = std::current_exception();
+            }
+        });
+    }
+    for (auto &t : thr) {
+        t.join();
+    }
+    if (ep) {
+        std::rethrow_exception(ep);
+    }
+}
+
 // Build the host mirrors (group ranges, class lists) from the crit array.
 void build_host_mirrors(rk_state &s, const std::vector<uint4> &crit)
 {
@@ -219,6 +282,17 @@ void create_impl(rk_state &s, const void *const parts[4], int64_t nparts, const 
 {
     using v4 = typename rk::vt<F>::v4;
     using v2 = typename rk::vt<F>::v2;
+    static const bool timing = std::getenv("RK_BUILD_TIMING") != nullptr; // diagnostic: phase times on stderr
+    const auto t_start = std::chrono::steady_clock::now();
+    auto t_prev = t_start;
+    const auto lap = [&](const char *what) {
+        if (timing) {
+            const auto t = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "RK_BUILD_TIMING create: %-22s %8.1f us\n", what,
+                         std::chrono::duration<double, std::micro>(t - t_prev).count());
+            t_prev = t;
+        }
+    };
     // Offsets inside rakau::tree_node_t<NDim, F, uint64_t, MAC> (tree_fwd.hpp:77-116 of the reference).
     const auto nd = static_cast<size_t>(s.ndim);
     constexpr size_t off_props = 5 * sizeof(uint64_t);
@@ -235,46 +309,54 @@ void create_impl(rk_state &s, const void *const parts[4], int64_t nparts, const 
                *z = nd == 3 ? static_cast<const F *>(parts[2]) : nullptr, *m = static_cast<const F *>(parts[nd]);
     const auto n = static_cast<size_t>(nparts), nn = static_cast<size_t>(tree_size);
 
-    std::vector<v4> part4(n);
-    for (size_t i = 0; i < n; ++i) {
-        part4[i].x = x[i];
-        part4[i].y = y[i];
-        part4[i].z = z ? z[i] : F(0);
-        part4[i].w = m[i];
-    }
+    raw_array<v4> part4(n);
+    host_parallel_for(n, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            part4[i].x = x[i];
+            part4[i].y = y[i];
+            part4[i].z = z ? z[i] : F(0);
+            part4[i].w = m[i];
+        }
+    });
 
-    std::vector<v4> com(nn);
-    std::vector<v2> macp(nn);
-    std::vector<uint4> topo(nn);
+    lap("particles -> AoS");
+    raw_array<v4> com(nn);
+    raw_array<v2> macp(nn);
+    raw_array<uint4> topo(nn);
     const auto *base = static_cast<const unsigned char *>(tree);
+    host_parallel_for(nn, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            const unsigned char *rec = base + i * static_cast<size_t>(node_stride);
+            uint64_t hdr[5];
+            std::memcpy(hdr, rec, sizeof(hdr));
+            F props[4] = {F(0), F(0), F(0), F(0)}, dim[2] = {F(0), F(0)};
+            std::memcpy(props, rec + off_props, (nd + 1) * sizeof(F));
+            if (nd == 2) {
+                props[3] = props[2]; // {x, y, mass} -> {x, y, 0, mass}
+                props[2] = F(0);
+            }
+            std::memcpy(dim, rec + off_dim, (s.mac == RK_MAC_BH ? 1 : 2) * sizeof(F));
+            const uint64_t begin = hdr[0], end = hdr[1], nch = hdr[2];
+            if (begin >= end || end > static_cast<uint64_t>(nparts) || nch > nn - 1 - i) {
+                throw rk::error(RK_EINVAL, "inconsistent tree node at index " + std::to_string(i));
+            }
+            com[i].x = props[0];
+            com[i].y = props[1];
+            com[i].z = props[2];
+            com[i].w = props[3];
+            macp[i].x = dim[0];
+            macp[i].y = dim[1];
+            topo[i].x = static_cast<uint32_t>(nch);
+            topo[i].y = static_cast<uint32_t>(begin);
+            topo[i].z = static_cast<uint32_t>(end);
+        }
+    });
+    // Slot of every internal node in the child table (serial: a running count).
     size_t n_internal = 0;
     for (size_t i = 0; i < nn; ++i) {
-        const unsigned char *rec = base + i * static_cast<size_t>(node_stride);
-        uint64_t hdr[5];
-        std::memcpy(hdr, rec, sizeof(hdr));
-        F props[4] = {F(0), F(0), F(0), F(0)}, dim[2] = {F(0), F(0)};
-        std::memcpy(props, rec + off_props, (nd + 1) * sizeof(F));
-        if (nd == 2) {
-            props[3] = props[2]; // {x, y, mass} -> {x, y, 0, mass}
-            props[2] = F(0);
-        }
-        std::memcpy(dim, rec + off_dim, (s.mac == RK_MAC_BH ? 1 : 2) * sizeof(F));
-        const uint64_t begin = hdr[0], end = hdr[1], nch = hdr[2];
-        if (begin >= end || end > static_cast<uint64_t>(nparts) || nch > nn - 1 - i) {
-            throw rk::error(RK_EINVAL, "inconsistent tree node at index " + std::to_string(i));
-        }
-        com[i].x = props[0];
-        com[i].y = props[1];
-        com[i].z = props[2];
-        com[i].w = props[3];
-        macp[i].x = dim[0];
-        macp[i].y = dim[1];
-        topo[i].x = static_cast<uint32_t>(nch);
-        topo[i].y = static_cast<uint32_t>(begin);
-        topo[i].z = static_cast<uint32_t>(end);
-        topo[i].w = nch ? static_cast<uint32_t>(n_internal++) : 0xffffffffu;
+        topo[i].w = topo[i].x ? static_cast<uint32_t>(n_internal++) : 0xffffffffu;
     }
-
+    lap("node records -> SoA");
     // Child table: the indices of the (up to 8) children of every internal node. In the depth-first
     // layout the first child of node i is i + 1 and the next sibling of c is c + n_children(c) + 1
     // (tree.hpp:2783 of the reference).
@@ -297,19 +379,15 @@ void create_impl(rk_state &s, const void *const parts[4], int64_t nparts, const 
         }
     }
 
+    lap("child table");
     // Records for the list kernel in sibling order: record 0 is the root; walking the depth-first array,
     // every internal node gets the next free run of records for its children.
-    std::vector<rk::node_rec<F>> recs(nn);
+    raw_array<rk::node_rec<F>> recs(nn);
     {
-        std::vector<uint32_t> rec_of(nn, 0u); // depth-first index -> record index
+        // Serial part: depth-first index -> record index (a running count over the internal nodes).
+        std::vector<uint32_t> rec_of(nn, 0u);
         uint32_t next = nn ? 1u : 0u;
         for (size_t i = 0; i < nn; ++i) {
-            auto &r = recs[rec_of[i]];
-            r.com = com[i];
-            r.mac = macp[i];
-            r.dfs = static_cast<uint32_t>(i);
-            r.nch = topo[i].x;
-            r.pad[0] = r.pad[1] = 0;
             if (topo[i].x) {
                 const uint32_t *ch = &child[static_cast<size_t>(topo[i].w) * 8];
                 uint32_t cnt = 0;
@@ -317,19 +395,38 @@ void create_impl(rk_state &s, const void *const parts[4], int64_t nparts, const 
                     rec_of[ch[cnt]] = next + cnt;
                     ++cnt;
                 }
-                r.a = next;
-                r.b = cnt;
                 next += cnt;
-            } else {
-                r.a = topo[i].y;
-                r.b = topo[i].z;
             }
         }
+        // Parallel part: fill the records.
+        host_parallel_for(nn, [&](size_t b, size_t e) {
+            for (size_t i = b; i < e; ++i) {
+                auto &r = recs[rec_of[i]];
+                r.com = com[i];
+                r.mac = macp[i];
+                r.dfs = static_cast<uint32_t>(i);
+                r.nch = topo[i].x;
+                r.pad[0] = r.pad[1] = 0;
+                if (topo[i].x) {
+                    const uint32_t *ch = &child[static_cast<size_t>(topo[i].w) * 8];
+                    uint32_t cnt = 0;
+                    while (cnt < 8 && ch[cnt]) {
+                        ++cnt;
+                    }
+                    r.a = rec_of[ch[0]];
+                    r.b = cnt;
+                } else {
+                    r.a = topo[i].y;
+                    r.b = topo[i].z;
+                }
+            }
+        });
         if (nn && next != nn) {
             throw rk::error(RK_EINVAL, "inconsistent tree: not every node is reachable from the root");
         }
     }
 
+    lap("sibling-order records");
     // Critical nodes: the first node on each root->leaf path with at most ncrit particles or without
     // children (equivalent to the rule at tree.hpp:801-803 of the reference: a node has no children
     // iff it holds at most max_leaf_n particles or sits at the deepest level).
@@ -360,26 +457,31 @@ void create_impl(rk_state &s, const void *const parts[4], int64_t nparts, const 
         throw rk::error(RK_EINVAL, "the critical nodes derived from the tree do not cover all particles");
     }
 
+    lap("critical nodes");
     // Tight bounding boxes of the target groups (used by the list kernel to take most MAC decisions without
     // visiting every target).
     std::vector<v4> boxes(crit.size() * 2);
-    for (size_t gi = 0; gi < crit.size(); ++gi) {
-        const v4 &p0 = part4[crit[gi].x];
-        F lo[3] = {p0.x, p0.y, p0.z}, hi[3] = {lo[0], lo[1], lo[2]};
-        for (size_t i = crit[gi].x; i < crit[gi].y; ++i) {
-            const F pv[3] = {part4[i].x, part4[i].y, part4[i].z};
-            for (int k = 0; k < 3; ++k) {
-                lo[k] = std::min(lo[k], pv[k]);
-                hi[k] = std::max(hi[k], pv[k]);
+    host_parallel_for(crit.size(), [&](size_t gb, size_t ge) {
+        for (size_t gi = gb; gi < ge; ++gi) {
+            const v4 &p0 = part4[crit[gi].x];
+            F lo[3] = {p0.x, p0.y, p0.z}, hi[3] = {lo[0], lo[1], lo[2]};
+            for (size_t i = crit[gi].x; i < crit[gi].y; ++i) {
+                const F pv[3] = {part4[i].x, part4[i].y, part4[i].z};
+                for (int k = 0; k < 3; ++k) {
+                    lo[k] = std::min(lo[k], pv[k]);
+                    hi[k] = std::max(hi[k], pv[k]);
+                }
             }
+            boxes[2 * gi].x = lo[0], boxes[2 * gi].y = lo[1], boxes[2 * gi].z = lo[2], boxes[2 * gi].w = F(0);
+            boxes[2 * gi + 1].x = hi[0], boxes[2 * gi + 1].y = hi[1], boxes[2 * gi + 1].z = hi[2],
+                                   boxes[2 * gi + 1].w = F(0);
         }
-        boxes[2 * gi].x = lo[0], boxes[2 * gi].y = lo[1], boxes[2 * gi].z = lo[2], boxes[2 * gi].w = F(0);
-        boxes[2 * gi + 1].x = hi[0], boxes[2 * gi + 1].y = hi[1], boxes[2 * gi + 1].z = hi[2], boxes[2 * gi + 1].w = F(0);
-    }
-
+    });
+    lap("group boxes");
     build_host_mirrors(s, crit);
     s.n_internal = static_cast<int64_t>(n_internal);
     const std::vector<uint32_t> lists = concat_class_lists(s);
+    lap("mirrors + class lists");
 
     alloc_upload(s, RK_BUF_PART4, part4.data(), part4.size() * sizeof(v4));
     alloc_upload(s, RK_BUF_NODE_COM, com.data(), com.size() * sizeof(v4));
@@ -390,6 +492,7 @@ void create_impl(rk_state &s, const void *const parts[4], int64_t nparts, const 
     alloc_upload(s, RK_BUF_CLASS, lists.data(), lists.size() * sizeof(uint32_t));
     alloc_upload(s, RK_BUF_NODE_REC, recs.data(), recs.size() * sizeof(rk::node_rec<F>));
     alloc_upload(s, RK_BUF_CRIT_BOX, boxes.data(), boxes.size() * sizeof(v4));
+    lap("uploads");
 }
 
 void check_common(int fp, int mac)
