@@ -38,6 +38,9 @@
 #ifndef RK_CHUNKED_SPLITS
 #define RK_CHUNKED_SPLITS 1 // dense phase: contiguous (1) or interleaved (0) assignment of tile sources to splits
 #endif
+#ifndef RK_EXACT_TRANSPOSED
+#define RK_EXACT_TRANSPOSED 1 // exact MAC test with lane = target when only a few candidates are queued
+#endif
 #ifndef RK_WPB
 #define RK_WPB 1 // wavefronts (= target groups) per workgroup. Measured 4 -> 2.58 ms, 2 -> 2.45, 1 -> 2.35 at 4M: a block keeps its
                  // LDS and wave slots until its slowest group ends, single-wave blocks free them at once (waves never sync)
@@ -303,6 +306,9 @@ __global__ void __launch_bounds__(64 * RK_WPB, (sizeof(F) == 4 ? (R <= 2 ? RK_W1
 
     // Gather the particles of the queued leaves into the source tile, evaluating the tile when it fills.
     auto drain_leaves = [&]() __attribute__((always_inline)) {
+#ifdef RK_ABLATE_LEAVES
+        n_lq = 0; // diagnostic build: opened leaves are dropped
+#endif
         while (n_lq > 0) {
             RK_STAMP(7)
             const int free_slots = SRC_CAP - n_src;
@@ -479,9 +485,15 @@ __global__ void __launch_bounds__(64 * RK_WPB, (sizeof(F) == 4 ? (R <= 2 ? RK_W1
         const F d2p0 = rk_fma(p0z, p0z, rk_fma(p0y, p0y, p0x * p0x)), d2p1 = rk_fma(p1z, p1z, rk_fma(p1y, p1y, p1x * p1x));
         const bool probe_open = mac_lh >= rk_min(d2p0, d2p1);
         RK_STAMP(1)
+#ifdef RK_ABLATE_EXACT
+        const bool accept = test && (box_accept || !probe_open); // diagnostic build: no exact all-targets test
+        const bool open = (test && !box_accept && probe_open) || (anc && !self);
+        const bool undecided = false;
+#else
         const bool accept = test && box_accept;
         const bool open = (test && !box_accept && probe_open) || (anc && !self);
         const bool undecided = test && !box_accept && !probe_open;
+#endif
         route(accept, open, undecided, bt);
         RK_STAMP(2)
     };
@@ -502,20 +514,53 @@ __global__ void __launch_bounds__(64 * RK_WPB, (sizeof(F) == 4 ? (R <= 2 ? RK_W1
         bt.rb = rec->b;
         const v4 com = bt.com;
         const F mac_lh = mac_lhs<F>(MAC, bt.mp, mac_value);
-        // min over the targets of the unsoftened squared distance to the node's centre of mass. The target
-        // coordinates are wave-uniform: they arrive through the scalar cache as SGPR operands.
-        F mind2 = std::numeric_limits<F>::infinity();
-        for (int t = 0; t < T; t += 4) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int ti = (t + u < T) ? t + u : T - 1;
-                const v4 tg = P.part4[tb + static_cast<uint32_t>(ti)];
-                const F dx = com.x - tg.x, dy = com.y - tg.y, dz = com.z - tg.z;
-                const F d2 = rk_fma(dz, dz, rk_fma(dy, dy, dx * dx));
-                mind2 = rk_min(mind2, d2);
+        bool fail;
+#if RK_EXACT_TRANSPOSED
+        if (k * (7 * R + 3) < T * 7) {
+            // Few candidates: lane = target. Every lane already keeps R targets of the group in registers (unused
+            // slots repeat target 0), so a candidate costs one broadcast LDS read and 7 R + 3 instructions instead of
+            // a share of the 7 T of the loop below. Same formula, same operands: same decision.
+            // The main loop keeps 64 free slots behind n_src in the source tile; the candidates are staged there.
+            v4 cd;
+            cd.x = com.x, cd.y = com.y, cd.z = com.z, cd.w = mac_lh;
+            if (bt.active) {
+                L.src[n_src + lane] = cd;
             }
+            wave_sync();
+            unsigned long long fail_mask = 0ull;
+            for (int c = 0; c < k; ++c) {
+                const v4 cand = L.src[n_src + c];
+                bool f = false;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const F dx = cand.x - tp[r].x, dy = cand.y - tp[r].y, dz = cand.z - tp[r].z;
+                    const F d2 = rk_fma(dz, dz, rk_fma(dy, dy, dx * dx));
+                    f |= cand.w >= d2;
+                }
+                if (__builtin_amdgcn_ballot_w64(f) != 0ull) {
+                    fail_mask |= 1ull << c;
+                }
+            }
+            fail = ((fail_mask >> lane) & 1ull) != 0ull;
+            wave_sync();
+        } else
+#endif
+        {
+            // min over the targets of the unsoftened squared distance to the node's centre of mass. The target
+            // coordinates are wave-uniform: they arrive through scalar loads as SGPR operands.
+            F mind2 = std::numeric_limits<F>::infinity();
+            for (int t = 0; t < T; t += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ti = (t + u < T) ? t + u : T - 1;
+                    const v4 tg = P.part4[tb + static_cast<uint32_t>(ti)];
+                    const F dx = com.x - tg.x, dy = com.y - tg.y, dz = com.z - tg.z;
+                    const F d2 = rk_fma(dz, dz, rk_fma(dy, dy, dx * dx));
+                    mind2 = rk_min(mind2, d2);
+                }
+            }
+            fail = mac_lh >= mind2;
         }
-        const bool fail = mac_lh >= mind2;
         route(bt.active && !fail, bt.active && fail, false, bt);
         RK_STAMP(3)
     };
@@ -524,6 +569,9 @@ __global__ void __launch_bounds__(64 * RK_WPB, (sizeof(F) == 4 ? (R <= 2 ? RK_W1
     // Sources accepted for the whole supergroup: stream them from the pre-pass list through the tile.
     {
         const v4 *common = P.sup_common + static_cast<size_t>(sup_S) * SUP_CAPC;
+#ifdef RK_ABLATE_COMMON
+        sup_ncommon = 0; // diagnostic build: the supergroup's common sources are dropped
+#endif
         for (uint32_t base = 0; base < sup_ncommon;) {
             const uint32_t room = static_cast<uint32_t>(SRC_CAP - n_src), left = sup_ncommon - base;
             const uint32_t take = left < room ? left : room;
