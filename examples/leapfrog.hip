@@ -192,12 +192,15 @@ static int run(const options &o)
         step(false);
     }
     HIP_OK(hipDeviceSynchronize());
+    size_t free0 = 0, free1 = 0, total = 0;
+    HIP_OK(hipMemGetInfo(&free0, &total));
     const auto t0 = now();
     for (int i = 0; i < o.steps; ++i) {
         step(true);
     }
     HIP_OK(hipDeviceSynchronize());
     const double wall = secs(t0, now());
+    HIP_OK(hipMemGetInfo(&free1, &total));
     if (o.integrals) {
         energy(k1, w1);
     }
@@ -206,10 +209,10 @@ static int run(const options &o)
     std::printf("{\"metric\": \"leapfrog steps/s (KDK, tree rebuilt every step, all arrays resident in HBM; native harness)\", "
                 "\"value\": %.3f, \"unit\": \"steps/s\", \"nparts\": %u, \"steps\": %d, \"ms_per_step\": %.4f, "
                 "\"ms_rebuild\": %.4f, \"ms_traversal\": %.4f, \"dtype\": \"%s\", \"theta\": %g, \"timestep\": %g, "
-                "\"eps\": %.6g, \"tree_size\": %lld, \"n_crit\": %lld",
+                "\"eps\": %.6g, \"tree_size\": %lld, \"n_crit\": %lld, \"device_mem_growth_mb\": %.1f",
                 o.steps / wall, n, o.steps, 1e3 * wall / o.steps, 1e3 * t_build / o.steps, 1e3 * t_trav / o.steps,
                 o.f64 ? "f64" : "f32", o.theta, o.timestep, eps, static_cast<long long>(info[1]),
-                static_cast<long long>(info[2]));
+                static_cast<long long>(info[2]), (double(free0) - double(free1)) / 1048576.);
     if (o.integrals) {
         std::printf(", \"energy_start\": %.12g, \"energy_end\": %.12g, \"energy_rel_drift\": %.3e, \"virial_2K_over_W\": %.6f",
                     k0 + w0, k1 + w1, std::fabs((k1 + w1) - (k0 + w0)) / std::fabs(k0 + w0), -2. * k0 / w0);

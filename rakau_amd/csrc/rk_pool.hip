@@ -16,7 +16,20 @@ struct pool {
     // device -> (rounded size -> cached blocks)
     std::map<int, std::multimap<size_t, void *>> free_blocks;
     std::unordered_map<void *, std::pair<int, size_t>> live; // block -> (device, rounded size)
+    std::map<int, size_t> cached_bytes;                      // device -> bytes sitting in free_blocks
 };
+
+// Upper bound of the bytes kept per device (RK_POOL_MAX_MB, default 16 GiB): beyond it freed blocks go back to the
+// driver, so that a long run whose buffer sizes drift from bin to bin cannot accumulate dead bins without limit.
+size_t pool_limit()
+{
+    static const size_t v = [] {
+        const char *e = std::getenv("RK_POOL_MAX_MB");
+        const long long mb = e ? std::atoll(e) : 16384;
+        return static_cast<size_t>(mb < 0 ? 0 : mb) << 20;
+    }();
+    return v;
+}
 
 pool &the_pool()
 {
@@ -86,6 +99,7 @@ void *pool_alloc_raw(size_t bytes)
         if (it != fb.end()) {
             p = it->second;
             fb.erase(it);
+            P.cached_bytes[dev] -= rs;
             P.live.emplace(p, std::make_pair(dev, rs));
             return p;
         }
@@ -112,12 +126,19 @@ void pool_free(void *p) noexcept
         std::lock_guard<std::mutex> lk(P.mtx);
         auto it = P.live.find(p);
         if (it != P.live.end()) {
-            P.free_blocks[it->second.first].emplace(it->second.second, p);
+            const int dev = it->second.first;
+            const size_t rs = it->second.second;
             P.live.erase(it);
-            return;
+            if (P.cached_bytes[dev] + rs <= pool_limit()) {
+                P.free_blocks[dev].emplace(rs, p);
+                P.cached_bytes[dev] += rs;
+                return;
+            }
+            // Over the limit: hand the block back to the driver (hipFree waits for the device, so this is safe
+            // whatever is still in flight).
         }
     }
-    (void)hipFree(p); // not ours (pool disabled)
+    (void)hipFree(p); // not ours (pool disabled), or over the cache limit
 }
 
 void pool_trim() noexcept
@@ -127,6 +148,7 @@ void pool_trim() noexcept
     {
         std::lock_guard<std::mutex> lk(P.mtx);
         blocks.swap(P.free_blocks);
+        P.cached_bytes.clear();
     }
     int prev = 0;
     (void)hipGetDevice(&prev);
