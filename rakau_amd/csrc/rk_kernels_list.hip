@@ -38,6 +38,10 @@
 #ifndef RK_CHUNKED_SPLITS
 #define RK_CHUNKED_SPLITS 1 // dense phase: contiguous (1) or interleaved (0) assignment of tile sources to splits
 #endif
+#ifndef RK_CARRY_REMAINDER
+#define RK_CARRY_REMAINDER 0 // dense phase: carry the sources that do not fill a round of NS to the next tile instead of a
+                             // masked step per tile (measured slower: 2.30 vs 2.27 ms; the extra LDS shuffle costs more)
+#endif
 #ifndef RK_EXACT_TRANSPOSED
 #define RK_EXACT_TRANSPOSED 1 // exact MAC test with lane = target when only a few candidates are queued
 #endif
@@ -169,11 +173,12 @@ __device__ __forceinline__ void lk_interact_src(const typename vt<F>::v4 &s, int
     }
 }
 
-// Dense targets x sources evaluation of one LDS tile. Lane (ts, sp) walks sources sp, sp + ns, ...;
-// the trip count of the main loop is uniform (n_src / ns), the remainder is one masked step.
+// Dense targets x sources evaluation of one LDS tile. The trip count of the main loop is uniform (full = n_src / ns,
+// computed by the caller); the n_src - full * ns sources left over at the end of the tile are one masked step when
+// `with_rem` is set, otherwise the caller carries them over to the next tile.
 template <typename F, int Q, int R, bool SELF>
-__device__ __forceinline__ void lk_eval_tile(const typename vt<F>::v4 *__restrict__ src, int n_src, int sp, int ns,
-                                             bool lane_on, const typename vt<F>::v4 (&tp)[R],
+__device__ __forceinline__ void lk_eval_tile(const typename vt<F>::v4 *__restrict__ src, int n_src, int full, int sp,
+                                             int ns, bool with_rem, bool lane_on, const typename vt<F>::v4 (&tp)[R],
                                              F (&acc)[R][nres_of(Q)], F eps2, const int (&tidx)[R])
 {
     using v4 = typename vt<F>::v4;
@@ -183,7 +188,7 @@ __device__ __forceinline__ void lk_eval_tile(const typename vt<F>::v4 *__restric
     // Keep about four interactions in flight per lane whatever R is.
     constexpr int UNR = R >= 4 ? RK_UNR4 : (R == 3 ? RK_UNR3 : (R == 2 ? RK_UNR2 : RK_UNR1));
     static_assert(R <= 6);
-    const int full = n_src / ns, rem = n_src - full * ns;
+    const int rem = with_rem ? n_src - full * ns : 0;
 #if RK_CHUNKED_SPLITS
     // Split sp owns the contiguous sources [sp * full, (sp + 1) * full): consecutive iterations read consecutive
     // LDS slots (immediate offsets, no address arithmetic in the loop); the remainder sits at the end of the tile.
@@ -294,11 +299,31 @@ __global__ void __launch_bounds__(64 * RK_WPB, (sizeof(F) == 4 ? (R <= 2 ? RK_W1
     }
     wave_sync();
 
-    auto flush = [&]() __attribute__((always_inline)) {
+    // n / NS for n <= SRC_CAP without a division per tile: exact for n * NS < 2^16.
+    const int inv_ns = (65536 + NS - 1) / NS;
+    static_assert(SRC_CAP * 64 < 65536);
+    // Evaluate the tile. Unless `final`, only whole rounds of NS sources are consumed and the (< NS) sources left
+    // over move to the front of the tile, so that no masked remainder step is paid per tile.
+    auto flush = [&](bool final) __attribute__((always_inline)) {
         if (n_src > 0) {
             RK_STAMP(7)
-            lk_eval_tile<F, Q, R, false>(L.src, n_src, sp, NS, lane_on, tp, acc, eps2, tidx);
+            const int full = (n_src * inv_ns) >> 16;
+            lk_eval_tile<F, Q, R, false>(L.src, n_src, full, sp, NS, final || !RK_CARRY_REMAINDER, lane_on, tp, acc, eps2,
+                                         tidx);
+#if RK_CARRY_REMAINDER
+            const int left = final ? 0 : n_src - full * NS;
+            v4 keep;
+            if (lane < left) {
+                keep = L.src[full * NS + lane];
+            }
+            wave_sync();
+            if (lane < left) {
+                L.src[lane] = keep;
+            }
+            n_src = left;
+#else
             n_src = 0;
+#endif
             wave_sync();
             RK_STAMP(4)
         }
@@ -323,7 +348,7 @@ __global__ void __launch_bounds__(64 * RK_WPB, (sizeof(F) == 4 ? (R <= 2 ? RK_W1
             const int m = __builtin_popcountll(m_fit); // leaves [0, m) fit (prefix property)
             if (m == 0) {
                 if (n_src > 0) {
-                    flush();
+                    flush(true); // everything, so that the tile really is empty afterwards
                     continue;
                 }
                 // A single leaf larger than the whole tile: take SRC_CAP of its particles.
@@ -336,7 +361,7 @@ __global__ void __launch_bounds__(64 * RK_WPB, (sizeof(F) == 4 ? (R <= 2 ? RK_W1
                 }
                 n_src = SRC_CAP;
                 wave_sync();
-                flush();
+                flush(true);
                 continue;
             }
             // Lane l copies the particles of leaf l, eight loads in flight at a time.
@@ -377,7 +402,7 @@ __global__ void __launch_bounds__(64 * RK_WPB, (sizeof(F) == 4 ? (R <= 2 ? RK_W1
             n_lq = tail;
             RK_STAMP(3)
             if (n_src + 64 > SRC_CAP) {
-                flush();
+                flush(false);
             }
         }
     };
@@ -582,7 +607,7 @@ __global__ void __launch_bounds__(64 * RK_WPB, (sizeof(F) == 4 ? (R <= 2 ? RK_W1
             base += take;
             wave_sync();
             if (n_src == SRC_CAP) {
-                flush();
+                flush(false);
             }
         }
     }
@@ -618,7 +643,7 @@ __global__ void __launch_bounds__(64 * RK_WPB, (sizeof(F) == 4 ? (R <= 2 ? RK_W1
             drain_leaves();
         }
         if (n_src + 64 > SRC_CAP || done) {
-            flush();
+            flush(done);
         }
         if (done) {
             break;
@@ -654,7 +679,7 @@ __global__ void __launch_bounds__(64 * RK_WPB, (sizeof(F) == 4 ? (R <= 2 ? RK_W1
         for (int r = 0; r < R; ++r) {
             tloc[r] = tidx[r] < 0 ? -1 : tidx[r] - b0;
         }
-        lk_eval_tile<F, Q, R, true>(L.src, n, sp, NS, lane_on, tp, acc, eps2, tloc);
+        lk_eval_tile<F, Q, R, true>(L.src, n, (n * inv_ns) >> 16, sp, NS, true, lane_on, tp, acc, eps2, tloc);
         wave_sync();
     }
 
