@@ -1,0 +1,17 @@
+#!/bin/bash
+# AddressSanitizer + UBSan on the CPU-side code (GPU sanitizers are not available on the pool):
+#  1. the C++ front door's host checks (tests/cpp/test_tree_api.cpp: tree builders, accessors, error paths),
+#  2. the oracle, by running its pytest files against a sanitized liboracle.so (restored afterwards).
+set -e
+cd "$(dirname "$0")/.."
+g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -pthread tests/cpp/test_tree_api.cpp \
+    -o /tmp/test_tree_asan -Lrakau_amd/lib -lrakau_amd -Wl,-rpath,$PWD/rakau_amd/lib
+ASAN_OPTIONS=detect_leaks=0 /tmp/test_tree_asan
+mkdir -p /tmp/orc_asan
+cp oracle/liboracle.so /tmp/orc_asan/liboracle.orig.so
+trap 'cp /tmp/orc_asan/liboracle.orig.so oracle/liboracle.so' EXIT
+g++ -O1 -g -std=c++17 -fPIC -shared -fsanitize=address,undefined -fno-omit-frame-pointer -ffp-contract=off -mfma -mavx2 \
+    -pthread oracle/rakau_oracle.cpp -o oracle/liboracle.so
+ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 \
+LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" \
+    python -m pytest tests/test_oracle_quadtree.py tests/test_oracle_reference_tests.py tests/test_golden.py -x -q -m "not gpu"
