@@ -15,3 +15,7 @@ g++ -O1 -g -std=c++17 -fPIC -shared -fsanitize=address,undefined -fno-omit-frame
 ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 \
 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" \
     python -m pytest tests/test_oracle_quadtree.py tests/test_oracle_reference_tests.py tests/test_golden.py -x -q -m "not gpu"
+#  3. ThreadSanitizer over the parallel host tree builders (300k particles: parallel merge sort + task-parallel build).
+g++ -O1 -g -std=c++17 -fsanitize=thread -pthread tests/cpp/tsan_tree_build.cpp -o /tmp/tsan_tree_build \
+    -Lrakau_amd/lib -lrakau_amd -Wl,-rpath,$PWD/rakau_amd/lib
+/tmp/tsan_tree_build
