@@ -72,7 +72,8 @@ __device__ __forceinline__ F mac_lhs(int mac, typename vt<F>::v2 mp, F mac_value
 // One monopole interaction on a target: d = source - target, d2 = softened squared distance.
 // Q == 0: acc[0..2] += d * m / r^3.  Q == 1: acc[0] -= m_tgt * m / r.  Q == 2: both (pot in acc[3]).
 // Arithmetic of tree.hpp:2008-2068 / 2564-2589 of the reference with 1/sqrt in place of sqrt + divide.
-template <typename F, int Q>
+// ND = 2 (quadtrees in the z = 0 plane): the z component is identically zero and is not accumulated.
+template <typename F, int Q, int ND = 3>
 __device__ __forceinline__ void interact(F (&acc)[nres_of(Q)], F dx, F dy, F dz, F d2, F m_src, F m_tgt)
 {
     const F rinv = rk_rsqrt(d2);
@@ -81,7 +82,9 @@ __device__ __forceinline__ void interact(F (&acc)[nres_of(Q)], F dx, F dy, F dz,
         const F mr3 = mr * (rinv * rinv);
         acc[0] = rk_fma(dx, mr3, acc[0]);
         acc[1] = rk_fma(dy, mr3, acc[1]);
-        acc[2] = rk_fma(dz, mr3, acc[2]);
+        if constexpr (ND == 3) {
+            acc[2] = rk_fma(dz, mr3, acc[2]);
+        }
     }
     if constexpr (Q == 1) {
         acc[0] = rk_fma(-m_tgt, mr, acc[0]);
