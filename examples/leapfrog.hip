@@ -11,6 +11,8 @@
 // The integrator kernels are the caller's own (below). Build: make -C examples   Run: examples/leapfrog [options]
 //   --nparts N (1000000) --steps K (20) --warmup W (2) --timestep dt (1e-4) --mac_value theta (0.75)
 //   --fp_type float|double --mac_type bh|bh_geom --track-integrals
+//   --reorder K (8): every K steps the harness permutes its own arrays into the Morton order of the current tree
+//                    (0 = never: the arrays keep their initial, random order)
 // Prints one JSON line (steps/s, per-step split, optional energy drift).
 #include <hip/hip_runtime.h>
 
@@ -61,6 +63,21 @@ __global__ void k_kick(F *vx, F *vy, F *vz, const F *ax, const F *ay, const F *a
         vx[i] = fma(ax[i], h, vx[i]), vy[i] = fma(ay[i], h, vy[i]), vz[i] = fma(az[i], h, vz[i]);
     }
 }
+// dst[i] = src[perm[i]] for seven arrays at once: puts the caller's arrays into the Morton order of the last tree, so
+// that the next rebuild reads them (and the ordered outputs are written) almost sequentially -- the device-side
+// counterpart of the reference keeping its particles in tree order (benchmark_leapfrog.cpp:263-281).
+template <typename F>
+__global__ void k_reorder(const unsigned *perm, unsigned n, const F *const *src, F *const *dst)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const unsigned j = perm[i];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            dst[k][i] = src[k][j];
+        }
+    }
+}
 // Partial sums of the kinetic energy and of the mutual potential energies (double accumulation, fixed order).
 template <typename F>
 __global__ void k_energy(const F *vx, const F *vy, const F *vz, const F *m, const F *pot, unsigned n, double *partial)
@@ -87,7 +104,7 @@ __global__ void k_energy(const F *vx, const F *vy, const F *vz, const F *m, cons
 
 struct options {
     unsigned long nparts = 1000000;
-    int steps = 20, warmup = 2;
+    int steps = 20, warmup = 2, reorder = 8;
     double timestep = 1e-4, theta = 0.75, a = 1.;
     bool f64 = false, geom = false, integrals = false;
 };
@@ -139,6 +156,14 @@ static int run(const options &o)
     }
     double *d_partial = nullptr;
     HIP_OK(hipMalloc(&d_partial, 2 * 256 * sizeof(double)));
+    // Double buffers + pointer tables for the periodic reordering of {x, y, z, vx, vy, vz, m}.
+    F *alt[7];
+    for (auto &p : alt) {
+        HIP_OK(hipMalloc(&p, bytes));
+    }
+    F **d_src = nullptr, **d_dst = nullptr;
+    HIP_OK(hipMalloc(&d_src, 7 * sizeof(F *)));
+    HIP_OK(hipMalloc(&d_dst, 7 * sizeof(F *)));
 
     const int q = o.integrals ? 2 : 0;
     const F th = F(o.theta);
@@ -146,6 +171,7 @@ static int run(const options &o)
     const double eps2 = double(F(eps) * F(eps));
     const void *parts[4] = {pos[0], pos[1], pos[2], mass};
     void *outs[4] = {out[0], out[1], out[2], out[3]};
+    int step_no = 0;
     rk_state *st = nullptr;
     RK_OK_OR_DIE(rk_state_build_nd(&st, 3, o.f64 ? RK_F64 : RK_F32, o.geom ? RK_MAC_BH_GEOM : RK_MAC_BH, 0, parts, 1, n,
                                    0., 16, 128));
@@ -172,6 +198,22 @@ static int run(const options &o)
     auto step = [&](bool timed) {
         hipLaunchKernelGGL((k_kick_drift<F>), grid, block, 0, nullptr, pos[0], pos[1], pos[2], vel[0], vel[1], vel[2], out[0],
                            out[1], out[2], h, dt, n);
+        if (o.reorder > 0 && ++step_no % o.reorder == 0) {
+            // The accelerations of the old order have just been consumed: move everything to tree order.
+            void *perm = nullptr;
+            int64_t pbytes = 0;
+            RK_OK_OR_DIE(rk_state_device_ptr(st, 1, &perm, &pbytes));
+            F *cur[7] = {pos[0], pos[1], pos[2], vel[0], vel[1], vel[2], mass};
+            HIP_OK(hipMemcpyAsync(d_src, cur, sizeof(cur), hipMemcpyHostToDevice, nullptr));
+            HIP_OK(hipMemcpyAsync(d_dst, alt, sizeof(alt), hipMemcpyHostToDevice, nullptr));
+            hipLaunchKernelGGL((k_reorder<F>), grid, block, 0, nullptr, static_cast<const unsigned *>(perm), n, d_src, d_dst);
+            for (int k = 0; k < 3; ++k) {
+                std::swap(pos[k], alt[k]);
+                std::swap(vel[k], alt[3 + k]);
+            }
+            std::swap(mass, alt[6]);
+            parts[0] = pos[0], parts[1] = pos[1], parts[2] = pos[2], parts[3] = mass;
+        }
         if (timed) {
             HIP_OK(hipDeviceSynchronize());
         }
@@ -209,9 +251,9 @@ static int run(const options &o)
     std::printf("{\"metric\": \"leapfrog steps/s (KDK, tree rebuilt every step, all arrays resident in HBM; native harness)\", "
                 "\"value\": %.3f, \"unit\": \"steps/s\", \"nparts\": %u, \"steps\": %d, \"ms_per_step\": %.4f, "
                 "\"ms_rebuild\": %.4f, \"ms_traversal\": %.4f, \"dtype\": \"%s\", \"theta\": %g, \"timestep\": %g, "
-                "\"eps\": %.6g, \"tree_size\": %lld, \"n_crit\": %lld, \"device_mem_growth_mb\": %.1f",
+                "\"eps\": %.6g, \"reorder_every\": %d, \"tree_size\": %lld, \"n_crit\": %lld, \"device_mem_growth_mb\": %.1f",
                 o.steps / wall, n, o.steps, 1e3 * wall / o.steps, 1e3 * t_build / o.steps, 1e3 * t_trav / o.steps,
-                o.f64 ? "f64" : "f32", o.theta, o.timestep, eps, static_cast<long long>(info[1]),
+                o.f64 ? "f64" : "f32", o.theta, o.timestep, eps, o.reorder, static_cast<long long>(info[1]),
                 static_cast<long long>(info[2]), (double(free0) - double(free1)) / 1048576.);
     if (o.integrals) {
         std::printf(", \"energy_start\": %.12g, \"energy_end\": %.12g, \"energy_rel_drift\": %.3e, \"virial_2K_over_W\": %.6f",
@@ -225,6 +267,11 @@ static int run(const options &o)
     }
     HIP_OK(hipFree(mass));
     HIP_OK(hipFree(d_partial));
+    for (auto &p : alt) {
+        HIP_OK(hipFree(p));
+    }
+    HIP_OK(hipFree(d_src));
+    HIP_OK(hipFree(d_dst));
     for (auto &p : out) {
         HIP_OK(hipFree(p));
     }
@@ -240,6 +287,7 @@ int main(int argc, char **argv)
         if (a == "--nparts") o.nparts = std::strtoul(next(), nullptr, 10);
         else if (a == "--steps") o.steps = std::atoi(next());
         else if (a == "--warmup") o.warmup = std::atoi(next());
+        else if (a == "--reorder") o.reorder = std::atoi(next());
         else if (a == "--timestep") o.timestep = std::atof(next());
         else if (a == "--mac_value") o.theta = std::atof(next());
         else if (a == "--a") o.a = std::atof(next());
