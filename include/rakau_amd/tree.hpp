@@ -422,6 +422,54 @@ inline void throw_status(int rc)
 
 } // namespace detail
 
+// Morton encoding / decoding of NDim discretised coordinates (the functors of tree.hpp:218-374 of the reference):
+// the encoder reads NDim values of cbits_v<UInt, NDim> bits each from an iterator, the decoder writes them back.
+template <std::size_t NDim, typename UInt>
+struct morton_encoder {
+    static_assert(NDim == 2u || NDim == 3u);
+    template <typename It>
+    UInt operator()(It it) const
+    {
+        std::uint64_t d[NDim];
+        for (std::size_t j = 0; j < NDim; ++j) {
+            d[j] = static_cast<std::uint64_t>(*(it + static_cast<std::ptrdiff_t>(j)));
+        }
+        return static_cast<UInt>(detail::morton_encode<NDim>(d));
+    }
+};
+template <std::size_t NDim, typename UInt>
+struct morton_decoder {
+    static_assert(NDim == 2u || NDim == 3u);
+    template <typename It>
+    void operator()(It it, UInt code) const
+    {
+        for (std::size_t j = 0; j < NDim; ++j) {
+            *(it + static_cast<std::ptrdiff_t>(j)) = static_cast<UInt>(detail::morton_coord<NDim>(code, j));
+        }
+    }
+};
+
+// Size of a node at `node_level`, and geometric centre of the node with nodal code `node_code`, in a domain of size
+// `box_size` (tree.hpp:444-482 of the reference; same arithmetic as tree::node_centre()).
+template <typename UInt, typename F>
+inline F get_node_dim(UInt node_level, F box_size)
+{
+    return box_size / static_cast<F>(UInt(1) << node_level);
+}
+template <typename F, std::size_t NDim, typename UInt>
+inline void get_node_centre(F (&out)[NDim], UInt node_code, F box_size)
+{
+    constexpr unsigned cbits = cbits_v<UInt, NDim>;
+    const unsigned level = tree_level<NDim>(node_code);
+    const UInt first_cell = static_cast<UInt>((node_code - (UInt(1) << (level * NDim))) << ((cbits - level) * NDim));
+    const F half_dim = get_node_dim(static_cast<UInt>(level), box_size) * (F(1) / F(2));
+    const F cell = box_size * (F(1) / static_cast<F>(UInt(1) << cbits));
+    for (std::size_t j = 0; j < NDim; ++j) {
+        out[j] = std::fma(static_cast<F>(detail::morton_coord<NDim>(first_cell, j)), cell,
+                          half_dim - box_size * (F(1) / F(2)));
+    }
+}
+
 template <typename F>
 using f_vector = std::vector<F>;
 

@@ -142,6 +142,101 @@ static void gpu_checks()
     }
 }
 
+// test/morton.cpp:35-62: encode random coordinate tuples and decode them back, for both code widths and dimensions.
+template <std::size_t ND, typename UInt>
+static void morton_checks()
+{
+    constexpr auto cbits = cbits_v<UInt, ND>;
+    morton_encoder<ND, UInt> me;
+    morton_decoder<ND, UInt> md;
+    std::mt19937_64 rng(ND * 100 + sizeof(UInt));
+    std::uniform_int_distribution<UInt> udist(0, (UInt(1) << cbits) - 1u);
+    UInt b1[ND], b2[ND];
+    for (int i = 0; i < 10000; ++i) {
+        for (auto &v : b1) v = udist(rng);
+        const UInt code = me(&b1[0]);
+        md(&b2[0], code);
+        CHECK(std::equal(b1, b1 + ND, b2));
+    }
+    // x -> bit 0, y -> bit 1 (, z -> bit 2): the child order the node-centre tests rely on.
+    UInt unit[ND] = {};
+    unit[0] = 1;
+    CHECK(me(&unit[0]) == UInt(1));
+    unit[0] = 0, unit[1] = 1;
+    CHECK(me(&unit[0]) == UInt(2));
+}
+
+// test/update_masses.cpp:36-150: mass updates change node masses (and nothing else) exactly; all-zero masses turn the
+// centres of mass into the geometric node centres; _u and _o flavours.
+template <typename F, mac M>
+static void update_masses_checks()
+{
+    std::mt19937 rng(0);
+    const std::size_t s = 10000;
+    auto parts = uniform_particles<F>(s, F(1), rng);
+    octree<F, M> t{x_coords = parts.begin() + s, y_coords = parts.begin() + 2 * s, z_coords = parts.begin() + 3 * s,
+                   masses = parts.begin(),       nparts = s,                      box_size = F(10)};
+    const auto t2(t);
+    t.update_masses_u([](auto) {});
+    CHECK(t.nodes() == t2.nodes());
+    t.update_masses_o([](auto) {});
+    CHECK(t.nodes() == t2.nodes());
+    auto doubled = [&](const auto &tr) {
+        bool ok = tr.nodes().size() == t2.nodes().size();
+        for (std::size_t i = 0; ok && i < tr.nodes().size(); ++i) {
+            ok = tr.nodes()[i].props[3] == t2.nodes()[i].props[3] * 2
+                 && std::equal(tr.nodes()[i].props, tr.nodes()[i].props + 3, t2.nodes()[i].props);
+        }
+        return ok;
+    };
+    t.update_masses_u([s](auto it) {
+        for (std::size_t i = 0; i < s; ++i) *(it + static_cast<std::ptrdiff_t>(i)) *= 2;
+    });
+    CHECK(!(t.nodes() == t2.nodes()));
+    CHECK(doubled(t));
+    t = t2;
+    t.update_masses_o([s](auto it) {
+        for (std::size_t i = 0; i < s; ++i) *(it + static_cast<std::ptrdiff_t>(i)) *= 2;
+    });
+    CHECK(doubled(t));
+    auto zeroed = [&](const auto &tr) {
+        bool ok = true;
+        for (std::size_t i = 0; ok && i < tr.nodes().size(); ++i) {
+            F c[3];
+            get_node_centre(c, tr.nodes()[i].code, F(10));
+            ok = tr.nodes()[i].props[3] == F(0) && std::equal(c, c + 3, tr.nodes()[i].props);
+        }
+        return ok;
+    };
+    t = t2;
+    t.update_masses_u([s](auto it) {
+        for (std::size_t i = 0; i < s; ++i) *(it + static_cast<std::ptrdiff_t>(i)) = 0;
+    });
+    CHECK(zeroed(t));
+    t = t2;
+    t.update_masses_o([s](auto it) {
+        for (std::size_t i = 0; i < s; ++i) *(it + static_cast<std::ptrdiff_t>(i)) = 0;
+    });
+    CHECK(zeroed(t));
+    // A few individual particles (update_masses.cpp:118-150).
+    const std::vector<std::size_t> indices{1, 100, 123, 1045, 9800};
+    t = t2;
+    t.update_masses_u([&indices](auto it) {
+        for (auto idx : indices) *(it + static_cast<std::ptrdiff_t>(idx)) += 1;
+    });
+    for (auto idx : indices) CHECK(t.p_its_u()[3][idx] == t2.p_its_u()[3][idx] + 1);
+    CHECK(!(t.nodes()[0] == t2.nodes()[0]));
+    t = t2;
+    t.update_masses_o([&indices](auto it) {
+        for (auto idx : indices) *(it + static_cast<std::ptrdiff_t>(idx)) += 1;
+    });
+    for (auto idx : indices) {
+        CHECK(t.p_its_o()[3][static_cast<std::ptrdiff_t>(idx)] == t2.p_its_o()[3][static_cast<std::ptrdiff_t>(idx)] + 1);
+    }
+    // Positions, codes and permutations are untouched by a mass update.
+    CHECK(std::equal(t.c_it_u(), t.c_it_u() + s, t2.c_it_u()) && t.perm() == t2.perm());
+}
+
 // Quadtrees: the call shapes of test/node_centre.cpp:23-53 and the 2-D flavour of the accuracy checks.
 template <typename F, mac M>
 static void quadtree_host_checks()
@@ -258,6 +353,12 @@ int main(int argc, char **argv)
     const bool gpu = argc > 1 && std::strcmp(argv[1], "gpu") == 0;
     host_checks<float, mac::bh>();
     host_checks<double, mac::bh_geom>();
+    morton_checks<2, std::uint32_t>();
+    morton_checks<3, std::uint32_t>();
+    morton_checks<2, std::uint64_t>();
+    morton_checks<3, std::uint64_t>();
+    update_masses_checks<double, mac::bh>();
+    update_masses_checks<float, mac::bh_geom>();
     quadtree_host_checks<double, mac::bh>();
     quadtree_host_checks<float, mac::bh_geom>();
     narrow_code_checks<3, double>(gpu);

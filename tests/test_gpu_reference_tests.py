@@ -171,3 +171,27 @@ def test_state_range_and_replication():
     c = st.count_interactions(mv)
     _, stats = oracle.Tree(x, y, z, m).acc_pot(0, 0.75, nthreads=8, want_stats=True)
     assert (c["mac"], c["com"], c["pp"], c["self"]) == (stats["w_visits"], stats["w_com"], stats["w_pp"], stats["w_self"])
+
+
+@pytest.mark.parametrize("mac", ["bh", "bh_geom"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_median_error(mac, dtype):
+    """median_error_acc.cpp:44-80: 5000 uniform particles in a box of 100, theta in {0.2, 0.4, 0.6, 0.8}; the reference
+    only prints the median of |a_tree - a_exact| / |a_exact|. Here: the medians grow with theta, stay in the Barnes-Hut
+    range, and equal the CPU oracle's medians for the same tree to 1 % (same interaction lists)."""
+    rng = oracle.Rng(1)
+    n = 5000
+    m, x, y, z = rng.uniform_particles(n, 100.0, dtype)
+    t = rakau_amd.Octree(x, y, z, m, mac=mac)
+    ot = oracle.Tree(x, y, z, m, mac=mac)
+    ex = np.stack([t.exact_acc_u(i).astype(np.float64) for i in range(0, n, 5)])
+    meds = []
+    for theta in (0.2, 0.4, 0.6, 0.8):
+        acc = np.stack(t.accs_u(theta, split=[0.5, 0.5]), axis=1).astype(np.float64)[::5]
+        ref = np.stack(ot.acc_pot(0, theta, nthreads=4), axis=1).astype(np.float64)[::5]
+        err = np.linalg.norm(acc - ex, axis=1) / np.linalg.norm(ex, axis=1)
+        err_o = np.linalg.norm(ref - ex, axis=1) / np.linalg.norm(ex, axis=1)
+        meds.append(float(np.median(err)))
+        assert abs(np.median(err) - np.median(err_o)) <= 0.01 * np.median(err_o) + 1e-7
+    print("\nmedian errors (theta 0.2, 0.4, 0.6, 0.8), mac=%s, %s: %s" % (mac, np.dtype(dtype).name, ["%.2e" % v for v in meds]))
+    assert all(a < b for a, b in zip(meds, meds[1:])) and meds[0] < 2e-3 and meds[-1] < 3e-2
