@@ -237,6 +237,91 @@ static void update_masses_checks()
     CHECK(std::equal(t.c_it_u(), t.c_it_u() + s, t2.c_it_u()) && t.perm() == t2.perm());
 }
 
+// test/update.cpp:34-213: position updates through update_particles_u / _o -- ordered iterators, perm / last_perm /
+// inv_perm bookkeeping across no-op updates, coordinate swaps, shifts and rescalings.
+template <typename F, mac M>
+static void update_positions_checks()
+{
+    std::mt19937 rng(5);
+    const std::size_t s = 10000;
+    auto parts = uniform_particles<F>(s, F(1), rng);
+    octree<F, M> t{x_coords = parts.begin() + s, y_coords = parts.begin() + 2 * s, z_coords = parts.begin() + 3 * s,
+                   masses = parts.begin(),       nparts = s,                      box_size = F(10)};
+    const auto t2(t);
+    using size_type = typename decltype(t)::size_type;
+    using diff_t = std::ptrdiff_t;
+    CHECK(t.perm() == t.last_perm());
+    std::vector<size_type> track(1000);
+    std::uniform_int_distribution<size_type> idist(0, s - 1);
+    for (auto &v : track) v = idist(rng);
+    auto tracked_ok = [&](const auto &tr, F shift, F scale, int rot) {
+        // rot = 0: (x, y, z); 1: (y, z, x) in the x, y, z slots. Values = (orig + shift) * scale.
+        auto pro = tr.p_its_o();
+        bool ok = true;
+        for (auto idx : track) {
+            const F ox = parts[s + idx], oy = parts[2 * s + idx], oz = parts[3 * s + idx];
+            const F e0 = rot ? oy : ox, e1 = rot ? oz : oy, e2 = rot ? ox : oz;
+            ok = ok && pro[0][static_cast<diff_t>(idx)] == (e0 + shift) * scale
+                 && pro[1][static_cast<diff_t>(idx)] == (e1 + shift) * scale
+                 && pro[2][static_cast<diff_t>(idx)] == (e2 + shift) * scale && pro[3][static_cast<diff_t>(idx)] == parts[idx];
+        }
+        return ok;
+    };
+    CHECK(tracked_ok(t, F(0), F(1), 0));
+    auto orig_perm = t.perm(), orig_inv = t.inv_perm();
+    std::vector<size_type> iota(s);
+    for (std::size_t i = 0; i < s; ++i) iota[i] = i;
+    t.update_particles_u([](const auto &) {});
+    CHECK(orig_perm == t.perm() && iota == t.last_perm() && orig_inv == t.inv_perm() && tracked_ok(t, F(0), F(1), 0));
+    t.update_particles_o([](const auto &) {});
+    CHECK(orig_perm == t.perm() && iota == t.last_perm() && orig_inv == t.inv_perm() && tracked_ok(t, F(0), F(1), 0));
+    for (int k = 0; k < 4; ++k) CHECK(std::equal(t.p_its_u()[k], t.p_its_u()[k] + s, t2.p_its_u()[k]));
+    // x, y, z -> y, z, x through the ordered iterators; the old x (Morton order) must reappear as z through last_perm.
+    std::vector<F> x_old(t.p_its_u()[0], t.p_its_u()[0] + s), x_orig(x_old), x_new(s);
+    t.update_particles_o([s](const auto &its) {
+        for (std::size_t i = 0; i < s; ++i) {
+            const auto d = static_cast<diff_t>(i);
+            std::swap(*(its[0] + d), *(its[1] + d));
+            std::swap(*(its[1] + d), *(its[2] + d));
+        }
+    });
+    CHECK(tracked_ok(t, F(0), F(1), 1));
+    auto follow = [&](F shift, F scale) {
+        const auto lp = t.last_perm();
+        for (std::size_t i = 0; i < s; ++i) x_new[i] = (x_old[lp[i]] + shift) * scale;
+        x_old = x_new;
+    };
+    follow(F(0), F(1));
+    CHECK(std::equal(x_new.begin(), x_new.end(), t.p_its_u()[2]));
+    t.update_particles_o([s](const auto &its) {
+        for (std::size_t i = 0; i < s; ++i) {
+            const auto d = static_cast<diff_t>(i);
+            std::swap(*(its[2] + d), *(its[1] + d));
+            std::swap(*(its[0] + d), *(its[1] + d));
+        }
+    });
+    CHECK(tracked_ok(t, F(0), F(1), 0));
+    follow(F(0), F(1));
+    CHECK(std::equal(x_new.begin(), x_new.end(), t.p_its_u()[0]) && x_new == x_orig);
+    t.update_particles_u([s](const auto &its) {
+        for (std::size_t i = 0; i < s; ++i)
+            for (std::size_t j = 0; j < 3; ++j) *(its[j] + static_cast<diff_t>(i)) += F(1);
+    });
+    CHECK(tracked_ok(t, F(1), F(1), 0));
+    follow(F(1), F(1));
+    CHECK(std::equal(x_new.begin(), x_new.end(), t.p_its_u()[0]));
+    t.update_particles_u([s](const auto &its) {
+        for (std::size_t i = 0; i < s; ++i)
+            for (std::size_t j = 0; j < 3; ++j) *(its[j] + static_cast<diff_t>(i)) /= F(2);
+    });
+    CHECK(tracked_ok(t, F(1), F(0.5), 0));
+    follow(F(0), F(0.5));
+    CHECK(std::equal(x_new.begin(), x_new.end(), t.p_its_u()[0]));
+    // Moving a particle out of the box is an error, as at construction (tree.hpp:381-429).
+    CHECK_THROWS(t.update_particles_u([](const auto &its) { *(its[0]) = F(100); }), std::invalid_argument,
+                 "outside the allowed bounds");
+}
+
 // Quadtrees: the call shapes of test/node_centre.cpp:23-53 and the 2-D flavour of the accuracy checks.
 template <typename F, mac M>
 static void quadtree_host_checks()
@@ -357,6 +442,8 @@ int main(int argc, char **argv)
     morton_checks<3, std::uint32_t>();
     morton_checks<2, std::uint64_t>();
     morton_checks<3, std::uint64_t>();
+    update_positions_checks<double, mac::bh>();
+    update_positions_checks<float, mac::bh_geom>();
     update_masses_checks<double, mac::bh>();
     update_masses_checks<float, mac::bh_geom>();
     quadtree_host_checks<double, mac::bh>();
