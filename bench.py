@@ -4,13 +4,17 @@
     python bench.py --gpus N --steps K --warmup W
 
 A "step" is one accs_u() call (one traversal of the resident tree for all target particles) with the
-tree and the particles already in HBM and the accelerations left in HBM. For N > 1 (launched through
-torch.distributed.run, one rank per GPU) rank 0 builds the tree and uploads it, the device buffers are
-replicated with RCCL broadcasts, and every rank traverses its contiguous Morton shard of the targets
-(cut at critical-node boundaries, equal interaction counts): no data-path collective. Per-GPU work is fixed as N
-grows ("scaling": "weak"): the N-GPU problem is ONE Plummer sphere of N x 4M particles in one replicated tree, each
-GPU computing the accelerations of its 4M-particle shard. RK_BENCH_SCALING=strong keeps the total at 4M instead
-(0.5M targets per GPU at N = 8: the launch is then too small to fill a 256-CU device; tools/shard_sim.py).
+tree and the particles already in HBM and the accelerations left in HBM. For N > 1 there is one rank per GPU:
+either launched by torch.distributed.run (the driver's form) or -- when WORLD_SIZE is not set -- spawned by this
+script itself as N child processes before anything touches a GPU (the reference needs no launcher either,
+tree.hpp:3150-3240). Rank 0 builds the tree and uploads it, the device buffers are replicated with RCCL
+broadcasts, and every rank traverses its contiguous Morton shard of the targets (cut at critical-node boundaries,
+equal interaction counts): no data-path collective.
+
+Default for N > 1 is the BASELINE.json metric: the SAME 4M-particle problem split over the N GPUs ("scaling":
+"strong"). `--scaling weak` makes the N-GPU problem ONE sphere of N x 4M particles in one replicated tree (4M targets
+per GPU); `--workload plummer64m_f32 --gpus 8` is BASELINE config 5 (64M particles sharded over 8 GPUs). The
+`metric` / `config.workload` strings always state the real particle count of the run.
 
 Rank 0 prints ONE JSON line. Besides the contract's fields it carries `roofline` (compute bound on the FP32/FP64
 vector ALU: the path is rsqrt/FMA bound; reported in the contract's "mfma" class, whose peak is
@@ -101,6 +105,43 @@ def shard_cuts(crit_ranges, nparts, world, work=None):
     return [max(c, cuts[i - 1]) if i else c for i, c in enumerate(cuts)]
 
 
+def self_launch(world):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes of THIS process (which never
+    initialises a GPU), with the environment torch.distributed.run would give them, and return their exit status.
+    Rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                r = p.poll()
+                if r is None:
+                    continue
+                pending.remove(p)
+                if r != 0 and rc == 0:
+                    rc = r
+                    for q in pending:  # a dead rank leaves the others waiting in a collective: stop them
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,9 +153,15 @@ def main():
     ap.add_argument("--builder", default="host", choices=["device", "host"],
                     help="where the tree of the timed state is built (host = the C++ header's builder, whose trees are "
                          "bit-identical to the CPU oracle's; device = rk_state_build, centres of mass differ by rounding)")
+    ap.add_argument("--scaling", default=os.environ.get("RK_BENCH_SCALING", "strong"), choices=["strong", "weak"],
+                    help="N > 1: strong = the workload's particle count in total (BASELINE metric), weak = per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all host cores)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # No launcher: become one. Nothing in this process has touched (or will touch) a GPU.
+        raise SystemExit(self_launch(args.gpus))
 
     import torch
     import rakau_amd
@@ -125,10 +172,7 @@ def main():
         wl["n"] = args.nparts
     n, dtype, theta, q = wl["n"], wl["dtype"], wl["theta"], wl["q"]
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    scaling = os.environ.get("RK_BENCH_SCALING", "weak")
-    if scaling not in ("weak", "strong"):
-        raise SystemExit("RK_BENCH_SCALING must be weak or strong")
-    n_per_gpu = n
+    scaling = args.scaling
     if scaling == "weak":
         n = n * world  # one sphere of world x n particles; every GPU owns n of them
     # Softening of the reference's leapfrog benchmark, eps = 0.45 * N^-0.73 (benchmark_leapfrog.cpp:218-223).
@@ -138,9 +182,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                             % (args.gpus, args.gpus))
+        raise SystemExit("bench.py --gpus %d was launched with WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     # RK_BENCH_SINGLE_DEVICE=1 + RK_BENCH_BACKEND=gloo: rehearsal of the multi-rank code path on a 1-GPU box
@@ -148,6 +190,9 @@ def main():
     backend = os.environ.get("RK_BENCH_BACKEND", "nccl")
     single_dev = os.environ.get("RK_BENCH_SINGLE_DEVICE", "0") == "1"
     dev = local_rank if (world > 1 and not single_dev) else 0
+    if dev >= torch.cuda.device_count():
+        raise SystemExit("bench.py --gpus %d needs %d GPUs, %d visible (RK_BENCH_SINGLE_DEVICE=1 RK_BENCH_BACKEND=gloo "
+                         "rehearses the multi-rank path on one GPU)" % (args.gpus, args.gpus, torch.cuda.device_count()))
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
@@ -293,9 +338,20 @@ def main():
             traffic = int(tj["hbm_bytes_per_step"])
     except Exception:
         pass
+    def count_str(k):
+        return "%dM" % (k // 1_000_000) if k % 1_000_000 == 0 else ("%dk" % (k // 1000) if k % 1000 == 0 else str(k))
+
+    call = {0: "accs_u()", 1: "pots_u()", 2: "accs_pots_u()"}[q]
+    fp_name = "fp32" if dtype == "float32" else "fp64"
+    # Always states the REAL particle count of the run (n = whole problem, all GPUs together).
+    what = "%s %s Plummer %s theta=%g%s" % (call, count_str(n), fp_name, theta, " with softening" if eps else "")
+    workload = "3D %s, %s-particle Plummer, theta=%g, %s%s" % (fp_name, count_str(n), theta, call,
+                                                             " with softening" if eps else "")
+    if world > 1:
+        workload += (", Morton-sharded across %d GPUs (%s targets per GPU), tree replicated by RCCL broadcast"
+                     % (world, count_str(n // world) if n % world == 0 else "~%d" % (n // world)))
     line = {
-        "metric": "Mparticles/s, accs_u() 4M Plummer fp32 theta=0.75" if args.workload == "plummer4m_f32"
-        else "Mparticles/s, %s" % wl["desc"],
+        "metric": "Mparticles/s, " + what,
         "value": round(value, 2),
         "unit": "Mparticles/s",
         "n_gpus": world,
@@ -306,9 +362,11 @@ def main():
         "scaling": scaling,
         "vs_baseline": None,
         "dtype": "f32" if dtype == "float32" else "f64",
-        "data": "synthetic Plummer sphere (numpy PCG64 seed 20261002), tree built on host, resident in HBM",
-        "config": {"workload": wl["desc"] + ("" if world == 1 or scaling == "strong" else " x %d GPUs (one sphere of %d particles)" % (world, n)),
-                   "nparts": n, "nparts_per_gpu": n // world if scaling == "strong" else n_per_gpu, "theta": theta, "q": q, "eps": eps, "max_leaf_n": 16,
+        "data": "synthetic Plummer sphere (numpy PCG64 seed 20261002), tree built on %s, resident in HBM; `value` = "
+                "results left in HBM (device-resident caller), `value_host_outputs` = the seam's own signature "
+                "(rk_acc_pot() into host arrays, SURVEY 8(d) t)" % args.builder,
+        "config": {"workload": workload, "workload_key": args.workload,
+                   "nparts": n, "nparts_per_gpu": n // world, "theta": theta, "q": q, "eps": eps, "max_leaf_n": 16,
                    "ncrit": 128, "mac": mac, "nodes": n_nodes, "critical_nodes": int(state.n_crit),
                    "sharding": ("contiguous Morton range per GPU (equal %s), tree replicated by RCCL broadcast" % ("interaction counts" if work is not None else "particle counts")) if world > 1
                    else "single GPU", "kernel_variant": args.variant},
@@ -340,11 +398,14 @@ def main():
         if world == 1:
             host_out = [np.zeros(n, dtype=dtype) for _ in range(nres)]
             ts = []
-            for _ in range(5):  # the first call touches the arrays, the second captures the launch graph
+            for _ in range(7):  # the first call touches the arrays, the second captures the launch graph
                 t0 = time.perf_counter()
                 state.acc_pot(q, mac_value, eps2=eps2, out=host_out)
                 ts.append(time.perf_counter() - t0)
-            line["host"]["acc_pot_host_outputs_ms"] = round(min(ts[2:]) * 1e3, 3)
+            t_host = float(np.median(ts[2:]))
+            line["host"]["acc_pot_host_outputs_ms"] = round(t_host * 1e3, 3)
+            line["value_host_outputs"] = round(n / t_host / 1e6, 2)
+            line["ms_per_call_host_outputs"] = round(t_host * 1e3, 4)
     except Exception as e:  # pragma: no cover
         line["host"]["acc_pot_host_outputs_error"] = str(e)
 

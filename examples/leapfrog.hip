@@ -198,15 +198,18 @@ static int run(const options &o)
     auto step = [&](bool timed) {
         hipLaunchKernelGGL((k_kick_drift<F>), grid, block, 0, nullptr, pos[0], pos[1], pos[2], vel[0], vel[1], vel[2], out[0],
                            out[1], out[2], h, dt, n);
+        HIP_OK(hipGetLastError());
         if (o.reorder > 0 && ++step_no % o.reorder == 0) {
             // The accelerations of the old order have just been consumed: move everything to tree order.
             void *perm = nullptr;
             int64_t pbytes = 0;
             RK_OK_OR_DIE(rk_state_device_ptr(st, 1, &perm, &pbytes));
             F *cur[7] = {pos[0], pos[1], pos[2], vel[0], vel[1], vel[2], mass};
-            HIP_OK(hipMemcpyAsync(d_src, cur, sizeof(cur), hipMemcpyHostToDevice, nullptr));
-            HIP_OK(hipMemcpyAsync(d_dst, alt, sizeof(alt), hipMemcpyHostToDevice, nullptr));
+            // Synchronous copies: the tables live in pageable stack arrays that change right after the launch.
+            HIP_OK(hipMemcpy(d_src, cur, sizeof(cur), hipMemcpyHostToDevice));
+            HIP_OK(hipMemcpy(d_dst, alt, sizeof(alt), hipMemcpyHostToDevice));
             hipLaunchKernelGGL((k_reorder<F>), grid, block, 0, nullptr, static_cast<const unsigned *>(perm), n, d_src, d_dst);
+            HIP_OK(hipGetLastError());
             for (int k = 0; k < 3; ++k) {
                 std::swap(pos[k], alt[k]);
                 std::swap(vel[k], alt[3 + k]);
@@ -229,6 +232,7 @@ static int run(const options &o)
             t_build += secs(t0, t1), t_trav += secs(t1, now());
         }
         hipLaunchKernelGGL((k_kick<F>), grid, block, 0, nullptr, vel[0], vel[1], vel[2], out[0], out[1], out[2], h, n);
+        HIP_OK(hipGetLastError());
     };
     for (int i = 0; i < o.warmup; ++i) {
         step(false);

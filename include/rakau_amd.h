@@ -160,7 +160,9 @@ RK_EXPORT int rk_last_kernel_ms(rk_state *s, float *ms);
  * (count <= RK_MAX_BUFFERS; ptrs/bytes are filled). A peer process allocates buffers of the same sizes
  * on its own GPU, receives the contents (e.g. torch.distributed.broadcast over RCCL/xGMI) and calls
  * rk_state_import() with the same meta block to obtain an equivalent state. Buffers passed to import are
- * copied device-to-device; the caller keeps ownership of them.
+ * copied device-to-device; the caller keeps ownership of them. The last buffer of the list is the permutation
+ * (0 bytes for a state that has none): replicas of a state that can do RK_OUT_ORDERED can do it too. import
+ * checks every buffer size against the meta block and applies the limits of rk_state_create.
  */
 #define RK_MAX_BUFFERS 16
 #define RK_META_WORDS 32
@@ -174,7 +176,9 @@ RK_EXPORT int rk_state_import(rk_state **out, int device, int count, void *const
  * properties, critical nodes (include/rakau/tree.hpp:1330-1487, 932-1111, 1116-1237) -- executed on `device`;
  * the result is a traversal state like rk_state_create()'s, without any host tree.
  *  parts        {x, y, z, m}: HOST arrays of nparts values of type F in the caller's ORIGINAL order.
- *  box_size     0 = deduce from the data (2 * max|coord| * 1.05), otherwise the domain size.
+ *  box_size     0 = deduce from the data (2 * max|coord| * 1.05), otherwise the domain size. (A caller that must
+ *               distinguish an EXPLICIT zero box -- an error in the reference -- does so before the call, as
+ *               include/rakau_amd/tree.hpp does.)
  *  max_leaf_n, ncrit   tree parameters (rakau defaults 16 and 128).
  * Errors and messages follow the reference's constructor (invalid_argument for coordinates outside the box...).
  * Node centres of mass are aggregated child -> parent, so they agree with the host builder to rounding.

@@ -913,6 +913,13 @@ private:
     void sort_and_build_on_device_impl()
     {
         const size_type np = m_parts[0].size();
+        if (!m_box_size_deduced && m_box_size == F(0) && np) {
+            // The C ABI spells "deduce the box" as box_size == 0. An EXPLICIT zero box cannot hold a particle: report
+            // it as the host path (and the reference, tree.hpp:381-429) do instead of silently deducing one.
+            for (std::size_t j = 0; j < NDim; ++j) {
+                disc_single_coord(m_parts[j][0], F(1) / m_box_size);
+            }
+        }
         const void *parts[4] = {};
         for (std::size_t j = 0; j < NDim + 1u; ++j) {
             parts[j] = m_parts[j].data();

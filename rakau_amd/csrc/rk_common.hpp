@@ -229,6 +229,7 @@ struct rk_state {
         int64_t p_begin, p_end;
         double mac_value, G, eps2;
         void *out[4];
+        const void *perm; // permutation buffer the ordered epilogue reads (null: Morton-order output)
     };
     graph_key gkey{};
     graph_key last_key{}; // key of the previous call: a graph is only captured when a call repeats

@@ -658,6 +658,13 @@ __global__ void __launch_bounds__(64 * RK_WPB, (sizeof(F) == 4 ? (R <= 2 ? RK_W1
             process_exact();
             continue;
         }
+        // Near the stack bound pop_and_load() descends one entry at a time, and LK_DFS_RESERVE (7 pending entries per
+        // level) only bounds a STRICT depth-first descent: settle the parked candidates first, so that everything an
+        // entry can push is on the stack before the next entry is popped.
+        if (n_uq > 0 && LK_STACK_CAP - LK_DFS_RESERVE - n_uq - size < 7) {
+            process_exact();
+            continue;
+        }
         RK_STAMP(7)
         batch_t A;
         if (next_batch(A) == 0) {

@@ -17,6 +17,9 @@ namespace
 
 thread_local std::string g_err;
 
+// Layout tag of rk_state_export / rk_state_import ("rk04"): bump it whenever the buffer list or the meta block changes.
+constexpr int64_t state_layout_tag = 0x726b3034;
+
 template <typename Fn>
 int guard(Fn &&f) noexcept
 {
@@ -762,6 +765,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
             for (int k = 0; k < rk::nres_of(q); ++k) {
                 key.out[k] = d_out[k];
             }
+            key.perm = p.perm;
             const bool replay = s.graph_exec && std::memcmp(&key, &s.gkey, sizeof(key)) == 0;
             const bool repeats = s.have_last_key && std::memcmp(&key, &s.last_key, sizeof(key)) == 0;
             s.last_key = key;
@@ -1126,13 +1130,16 @@ int rk_state_export(const rk_state *s, int *count, void **ptrs, int64_t *bytes, 
             device_guard dg(s->device);
             ensure_mirrors(*const_cast<rk_state *>(s)); // the class-list buffer must be complete before it travels
         }
-        *count = RK_NBUF;
+        // The RK_NBUF traversal buffers, then the permutation (uint32 per particle; 0 bytes if the state has none).
+        *count = RK_NBUF + 1;
         for (int i = 0; i < RK_NBUF; ++i) {
             ptrs[i] = s->buf[i];
             bytes[i] = s->buf_bytes[i];
         }
+        ptrs[RK_NBUF] = s->bld_perm;
+        bytes[RK_NBUF] = s->bld_perm ? s->nparts * static_cast<int64_t>(sizeof(uint32_t)) : 0;
         std::fill(meta, meta + RK_META_WORDS, int64_t(0));
-        meta[0] = 0x726b3033; // layout tag "rk02"
+        meta[0] = state_layout_tag;
         meta[1] = s->fp;
         meta[2] = s->mac;
         meta[3] = s->nparts;
@@ -1141,9 +1148,12 @@ int rk_state_export(const rk_state *s, int *count, void **ptrs, int64_t *bytes, 
         meta[6] = static_cast<int64_t>(s->ncrit);
         meta[7] = s->n_internal;
         meta[24] = s->ndim;
-        for (int i = 0; i < RK_NBUF; ++i) {
-            meta[8 + i] = s->buf_bytes[i];
+        for (int i = 0; i <= RK_NBUF; ++i) {
+            meta[8 + i] = bytes[i];
         }
+        std::memcpy(&meta[25], &s->box_size, sizeof(double));
+        meta[26] = s->box_deduced;
+        meta[27] = static_cast<int64_t>(s->max_leaf_n);
     });
 }
 
@@ -1155,26 +1165,51 @@ int rk_state_import(rk_state **out, int device, int count, void *const *ptrs, co
             throw rk::error(RK_EINVAL, "null argument");
         }
         *out = nullptr;
-        if (meta[0] != 0x726b3033 || count != RK_NBUF) {
+        if (meta[0] != state_layout_tag || count != RK_NBUF + 1) {
             throw rk::error(RK_EINVAL, "unrecognised state layout");
         }
         check_common(static_cast<int>(meta[1]), static_cast<int>(meta[2]));
+        check_ndim(static_cast<int>(meta[24]));
         check_device(device);
+        // The meta block is trusted no further than the buffers it describes: every count must match the byte size
+        // of its buffer, and the limits of rk_state_create apply.
+        const int64_t nparts = meta[3], tree_size = meta[4], n_crit = meta[5], n_internal = meta[7];
+        const int64_t fsz = meta[1] == RK_F32 ? 4 : 8;
+        if (nparts < 0 || tree_size < 0 || n_crit < 0 || n_internal < 0 || n_crit > tree_size || n_internal > tree_size
+            || static_cast<uint64_t>(nparts) >= 0xffffffffull || static_cast<uint64_t>(tree_size) >= rk::max_list_nodes
+            || (nparts > 0 && (tree_size == 0 || n_crit == 0)) || meta[6] <= 0) {
+            throw rk::error(RK_EINVAL, "inconsistent counts in the meta block of rk_state_import");
+        }
+        const int64_t rec_bytes = meta[1] == RK_F32 ? int64_t(sizeof(rk::node_rec<float>)) : int64_t(sizeof(rk::node_rec<double>));
+        const int64_t expect[RK_NBUF] = {nparts * 4 * fsz, tree_size * 4 * fsz, tree_size * 2 * fsz, tree_size * 16,
+                                         n_crit * 16,      n_internal * 8 * 4,  -1 /* class lists: checked below */,
+                                         tree_size * rec_bytes, n_crit * 2 * 4 * fsz};
+        for (int i = 0; i < RK_NBUF; ++i) {
+            if (bytes[i] != meta[8 + i] || (expect[i] >= 0 && bytes[i] != expect[i])) {
+                throw rk::error(RK_EINVAL, "buffer " + std::to_string(i) + " of rk_state_import has " + std::to_string(bytes[i])
+                                               + " bytes, which does not match the meta block");
+            }
+        }
+        if (bytes[RK_BUF_CLASS] != 2 * n_crit * 4) {
+            throw rk::error(RK_EINVAL, "class-list buffer size mismatch in rk_state_import");
+        }
+        if (bytes[RK_NBUF] != meta[8 + RK_NBUF] || (bytes[RK_NBUF] != 0 && bytes[RK_NBUF] != nparts * 4)) {
+            throw rk::error(RK_EINVAL, "permutation buffer size mismatch in rk_state_import");
+        }
         device_guard dg(device);
         state_ptr s(new rk_state);
         s->fp = static_cast<int>(meta[1]);
         s->mac = static_cast<int>(meta[2]);
         s->device = device;
-        s->nparts = meta[3];
-        s->tree_size = meta[4];
+        s->nparts = nparts;
+        s->tree_size = tree_size;
         s->ncrit = static_cast<uint64_t>(meta[6]);
-        s->n_internal = meta[7];
+        s->n_internal = n_internal;
         s->ndim = static_cast<int>(meta[24]);
-        check_ndim(s->ndim);
+        std::memcpy(&s->box_size, &meta[25], sizeof(double));
+        s->box_deduced = meta[26] != 0;
+        s->max_leaf_n = static_cast<uint64_t>(meta[27]);
         for (int i = 0; i < RK_NBUF; ++i) {
-            if (bytes[i] != meta[8 + i]) {
-                throw rk::error(RK_EINVAL, "buffer size mismatch in rk_state_import");
-            }
             s->buf_bytes[i] = bytes[i];
             if (bytes[i]) {
                 if (!ptrs[i]) {
@@ -1183,6 +1218,14 @@ int rk_state_import(rk_state **out, int device, int count, void *const *ptrs, co
                 s->buf[i] = rk::pool_alloc(static_cast<size_t>(bytes[i]));
                 RK_HIP(hipMemcpy(s->buf[i], ptrs[i], static_cast<size_t>(bytes[i]), hipMemcpyDeviceToDevice));
             }
+        }
+        if (bytes[RK_NBUF]) {
+            // With the permutation a replica serves RK_OUT_ORDERED like the state it was exported from.
+            if (!ptrs[RK_NBUF]) {
+                throw rk::error(RK_EINVAL, "null buffer in rk_state_import");
+            }
+            s->bld_perm = rk::pool_alloc(static_cast<size_t>(bytes[RK_NBUF]));
+            RK_HIP(hipMemcpy(s->bld_perm, ptrs[RK_NBUF], static_cast<size_t>(bytes[RK_NBUF]), hipMemcpyDeviceToDevice));
         }
         std::vector<uint4> crit(static_cast<size_t>(meta[5]));
         if (!crit.empty()) {
@@ -1342,6 +1385,14 @@ int rk_state_set_perm(rk_state *s, const uint64_t *perm)
             throw rk::error(RK_EINVAL, "null argument");
         }
         device_guard dg(s->device);
+        // A traversal still in flight (any stream) may be reading the old permutation, and a captured launch sequence
+        // must not outlive the buffer it was recorded with.
+        RK_HIP(hipDeviceSynchronize());
+        if (s->graph_exec) {
+            (void)hipGraphExecDestroy(s->graph_exec);
+            s->graph_exec = nullptr;
+        }
+        s->have_last_key = false;
         std::vector<uint32_t> p32(static_cast<size_t>(s->nparts));
         for (size_t i = 0; i < p32.size(); ++i) {
             if (perm[i] >= static_cast<uint64_t>(s->nparts)) {

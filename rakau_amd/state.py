@@ -49,6 +49,13 @@ class State:
         self.dtype = arrs[0].dtype
         if self.dtype not in _FP or any(v.dtype != self.dtype for v in arrs):
             raise TypeError("coordinates and masses must share a float32 or float64 dtype")
+        if any(v.size != arrs[0].size for v in arrs):
+            raise ValueError("The input ranges for the particle coordinates and masses have inconsistent sizes")
+        if codes is not None:
+            # rocm_state's ctor takes the sorted codes (rocm_fwd.hpp:29-30); this engine accepts and ignores them.
+            codes = np.ascontiguousarray(codes, dtype=np.uint64)
+            if codes.size != arrs[0].size:
+                raise ValueError("codes must have one entry per particle")
         nodes = np.ascontiguousarray(nodes)
         if nodes.dtype != node_dtype(self.dtype, mac, ndim):
             raise TypeError("nodes must have dtype node_dtype(%s, %r, %d)" % (self.dtype, mac, ndim))

@@ -1,7 +1,8 @@
-"""Rehearsal of bench.py's multi-rank path on a 1-GPU box: two ranks launched by torch.distributed.run share
-GPU 0 (RK_BENCH_SINGLE_DEVICE=1) and replicate the tree through host memory (RK_BENCH_BACKEND=gloo). Everything
-but the RCCL transport is the code the driver runs at N = 2, 4, 8: export -> broadcast -> import, Morton shards,
-max-over-ranks timing, one JSON line from rank 0."""
+"""Rehearsal of bench.py's multi-rank path on a 1-GPU box: two ranks share GPU 0 (RK_BENCH_SINGLE_DEVICE=1) and
+replicate the tree through host memory (RK_BENCH_BACKEND=gloo). Everything but the RCCL transport is the code the
+driver runs at N = 2, 4, 8: export -> broadcast -> import, Morton shards, max-over-ranks timing, one JSON line from
+rank 0. Two launch forms: `python bench.py --gpus 2` by itself (bench.py spawns its ranks, like the reference needs no
+launcher: tree.hpp:3150-3240) and the driver's torch.distributed.run form."""
 import json
 import os
 import socket
@@ -14,21 +15,32 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("scaling", ["weak", "strong"])
-def test_two_ranks_one_gpu(scaling):
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    env = dict(os.environ, RK_BENCH_SINGLE_DEVICE="1", RK_BENCH_BACKEND="gloo", RK_BENCH_SCALING=scaling)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--workload", "plummer100k_f32"]
+def run_bench(launcher, extra):
+    env = dict(os.environ, RK_BENCH_SINGLE_DEVICE="1", RK_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RK_BENCH_SCALING"):
+        env.pop(k, None)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload",
+            "plummer100k_f32"] + extra
+    if launcher == "self":
+        cmd = [sys.executable] + tail
+    else:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port)] + tail
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
-    d = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("launcher,scaling", [("self", None), ("self", "weak"), ("torchrun", "strong")])
+def test_two_ranks_one_gpu(launcher, scaling):
+    d = run_bench(launcher, ["--scaling", scaling] if scaling else [])
+    scaling = scaling or "strong"  # the default is the BASELINE metric: same problem, more GPUs
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0
     assert d["scaling"] == scaling and d["unit"] == "Mparticles/s"
     assert "roofline" in d and "cpu_baseline" not in d
@@ -37,7 +49,10 @@ def test_two_ranks_one_gpu(scaling):
         # Both shards together evaluate every interaction of the full 100k problem.
         assert d["config"]["nparts"] == 100000 and d["config"]["nparts_per_gpu"] == 50000
         assert abs(d["interactions_per_particle"] - 1218.45) < 1.0
+        assert "100k Plummer" in d["metric"] and "100k-particle" in d["config"]["workload"]
     else:
-        # One sphere of 2 x 100k particles, 100k targets per rank.
+        # One sphere of 2 x 100k particles, 100k targets per rank: the labels say 200k, never 100k.
         assert d["config"]["nparts"] == 200000 and d["config"]["nparts_per_gpu"] == 100000
         assert 1218.45 < d["interactions_per_particle"] < 1500
+        assert "200k Plummer" in d["metric"] and "200k-particle" in d["config"]["workload"]
+    assert "across 2 GPUs" in d["config"]["workload"]

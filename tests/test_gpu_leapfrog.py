@@ -93,6 +93,50 @@ def test_ordered_output_needs_perm_and_set_perm_provides_it():
         _capi.check(_capi.lib().rk_acc_pot(st._h, 0, 0, 5000, ptrs, mv, 1.0, 0.0, _capi.RK_OUT_ORDERED))
 
 
+def test_set_perm_between_identical_ordered_calls():
+    """Two identical ordered calls replay a captured launch graph; a set_perm() in between must take effect (the
+    graph key covers the permutation, and set_perm drops the captured graph), also for replicas made by
+    rk_state_export/import, which carry the permutation."""
+    torch, dev = torch_dev()
+    m, x, y, z = oracle.plummer(20000, np.float32)
+    t = rakau_amd.Octree(x, y, z, m)
+    st = t.state()
+    mv = rakau_amd.mac_value_of(0.75, "bh", np.float32)
+    perm = t.perm()
+    st.set_perm(perm)
+    outs = [torch.zeros(20000, dtype=torch.float32, device=dev) for _ in range(3)]
+    ptrs = [o.data_ptr() for o in outs]
+    for _ in range(3):  # direct launch, capture, replay
+        st.acc_pot_device(0, mv, ptrs, ordered=True)
+    torch.cuda.synchronize()
+    first = [o.cpu().numpy().copy() for o in outs]
+    ref = t.accs_o(0.75)
+    for g, r in zip(first, ref):
+        assert np.array_equal(g, r)
+    # A different permutation (reversed original order), same outputs, same parameters.
+    perm2 = (np.uint64(19999) - perm).astype(np.uint64)
+    st.set_perm(perm2)
+    for _ in range(3):
+        st.acc_pot_device(0, mv, ptrs, ordered=True)
+    torch.cuda.synchronize()
+    for o, r in zip(outs, ref):
+        assert np.array_equal(o.cpu().numpy(), r[::-1])
+    # Replica: ordered output works and follows the exported permutation.
+    eptrs, nbytes, meta = st.export()
+    clone = rakau_amd.State.from_buffers(0, eptrs, nbytes, meta)
+    outs2 = [torch.zeros(20000, dtype=torch.float32, device=dev) for _ in range(3)]
+    clone.acc_pot_device(0, mv, [o.data_ptr() for o in outs2], ordered=True)
+    torch.cuda.synchronize()
+    for o, r in zip(outs2, ref):
+        assert np.array_equal(o.cpu().numpy(), r[::-1])
+    # A meta block that disagrees with the buffers is rejected (no out-of-bounds device reads).
+    bad = list(meta)
+    bad[3] += 64
+    with pytest.raises(ValueError, match="does not match the meta block"):
+        rakau_amd.State.from_buffers(0, eptrs, nbytes, bad)
+    clone.close()
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_build_from_device_pointers_and_rebuild(dtype):
     """rk_state_build_device == rk_state_build on the same particles; rk_state_rebuild_device == a fresh build, through
