@@ -43,6 +43,7 @@
 #include <vector>
 
 #include "../rakau_amd.h"
+#include "cpu_engine.hpp"
 #include "kwargs.hpp"
 
 namespace rakau_amd
@@ -260,11 +261,10 @@ public:
     }
 };
 
-// Number of host threads used by the builder.
+// Number of host threads used by the builder (hardware threads narrowed by affinity and the cgroup CPU quota).
 inline unsigned host_threads()
 {
-    const unsigned hc = std::thread::hardware_concurrency();
-    return std::clamp(hc ? hc : 1u, 1u, 64u);
+    return std::clamp(usable_hw_threads(), 1u, 64u);
 }
 
 // Run f(begin, end) over [0, n) on several threads (contiguous blocks).
@@ -1314,12 +1314,9 @@ private:
     // acc/pot dispatch (behaviour of tree.hpp:2853-3357).
     // ------------------------------------------------------------------------------------------
 
-    // Particle indices at which the work is cut between devices. cuts[0] = 0, cuts.back() = nparts;
-    // every cut sits on a critical-node boundary (the snapping rule of tree.hpp:3053-3063 applied to
-    // every boundary). Entry d of the result is the range of device d.
-    std::vector<size_type> device_cuts(const std::vector<double> &split) const
+    // Validation of `split` common to all code paths (tree.hpp:2857-2868).
+    static void check_split(const std::vector<double> &split)
     {
-        // Validation common to all code paths (tree.hpp:2857-2868).
         if (std::any_of(split.begin(), split.end(), [](double x) { return !std::isfinite(x); })) {
             throw std::invalid_argument("The 'split' parameter cannot contain non-finite values");
         }
@@ -1329,8 +1326,22 @@ private:
         if (!split.empty() && std::all_of(split.begin(), split.end(), [](double x) { return x == 0.; })) {
             throw std::invalid_argument("The values in the 'split' parameter cannot all be zero");
         }
+    }
+
+    // Particle indices at which the work is cut: split = {cpu, dev0, dev1, ...} (tree.hpp:3150-3187). The result has
+    // split.size() + 1 entries: [cuts[0], cuts[1]) is the share of the CPU engine, [cuts[d + 1], cuts[d + 2]) the share
+    // of device d. Every cut sits on a critical-node boundary (the snapping rule of tree.hpp:3053-3063 applied to every
+    // boundary: this engine's unit of work is the critical node on the devices too).
+    // An EMPTY split means "everything on device 0" here (the reference's default is the CPU; this library exists to
+    // offload), a split of size one is the reference's "CPU only".
+    std::vector<size_type> split_cuts(const std::vector<double> &split) const
+    {
+        check_split(split);
         const size_type np = nparts();
-        if (split.size() <= 1u) {
+        if (split.empty()) {
+            return {size_type(0), size_type(0), np};
+        }
+        if (split.size() == 1u) {
             return {size_type(0), np};
         }
         const auto n_dev = static_cast<std::size_t>(rk_device_count());
@@ -1341,42 +1352,68 @@ private:
                 + std::to_string(split.size() - 1u) + " accelerators, but only " + std::to_string(n_dev)
                 + " were detected");
         }
-        // split = {host, dev0, dev1, ...}; the host share is executed by device 0.
         const double total = std::accumulate(split.begin(), split.end(), 0.);
-        std::vector<size_type> cuts(split.size());
+        std::vector<size_type> cuts(split.size() + 1u);
         cuts[0] = 0;
-        double acc = split[0];
-        for (std::size_t d = 1; d + 1u < split.size(); ++d) {
+        double acc = 0.;
+        for (std::size_t d = 0; d + 1u < split.size(); ++d) {
             acc += split[d];
             auto idx = checked_cast<size_type>(acc / total * static_cast<double>(np));
             const auto it = std::lower_bound(m_crit_nodes.begin(), m_crit_nodes.end(), idx,
                                              [](const cnode_type &cn, size_type v) { return cn.begin < v; });
             idx = (it == m_crit_nodes.end()) ? np : it->begin;
-            cuts[d] = std::max(idx, cuts[d - 1u]);
+            cuts[d + 1u] = std::max(idx, cuts[d]);
         }
         cuts.back() = np;
-        // Chunks that are too small for a device collapse the whole call onto device 0
-        // (the reference falls back to a single engine in that case, tree.hpp:3191-3199).
-        for (std::size_t d = 1; d < cuts.size(); ++d) {
-            if (cuts[d] - cuts[d - 1u] < rk_min_size()) {
+        // A device share below the minimum size sends the whole call to the CPU engine (tree.hpp:3191-3199,
+        // 3114-3117: "not enough particles, run on the cpu").
+        for (std::size_t d = 1; d + 1u < cuts.size(); ++d) {
+            if (cuts[d + 1u] - cuts[d] < rk_min_size()) {
                 return {size_type(0), np};
             }
         }
         return cuts;
     }
 
-    // Run the device engine for [0, nparts) and leave the results in res[j][0..nparts) (Morton order).
+    // The CPU engine on the critical nodes whose particles are [0, p_end) (p_end is a critical-node boundary).
+    template <unsigned Q>
+    void cpu_run(const std::array<F *, nvecs_res<Q>> &res, size_type p_end, F mac_value, F G, F eps2,
+                 detail::cpu_flavour flavour = detail::cpu_flavour::automatic, unsigned nthreads = 0) const
+    {
+        const auto it = std::lower_bound(m_crit_nodes.begin(), m_crit_nodes.end(), p_end,
+                                         [](const cnode_type &cn, size_type v) { return cn.begin < v; });
+        const auto c_end = static_cast<std::size_t>(it - m_crit_nodes.begin());
+        std::array<const F *, NDim + 1u> parts;
+        for (std::size_t j = 0; j < NDim + 1u; ++j) {
+            parts[j] = m_parts[j].data();
+        }
+        F *out[NDim + 1u] = {};
+        for (std::size_t j = 0; j < nvecs_res<Q>; ++j) {
+            out[j] = res[j];
+        }
+        detail::cpu::run<Q, NDim, MAC == mac::bh>(m_tree.data(), m_tree.size(), m_crit_nodes.data(), std::size_t(0), c_end,
+                                                  parts, out, mac_value, G, eps2, flavour, nthreads);
+    }
+
+    // Run the engines for [0, nparts) and leave the results in res[j][0..nparts) (Morton order): the devices on one
+    // host thread each (rocm_state::acc_pot / cuda_acc_pot_impl of the reference), the CPU share on the calling
+    // thread meanwhile; every future is joined so that exceptions propagate (tree.hpp:3071-3113).
     template <unsigned Q>
     void device_run(const std::array<F *, nvecs_res<Q>> &res, F mac_value, F G, F eps2,
                     const std::vector<double> &split) const
     {
-        const auto cuts = device_cuts(split);
+        const auto cuts = split_cuts(split);
         if (!nparts()) {
             return;
         }
-        if (!rk_has_accelerator()) {
-            throw std::runtime_error("rakau_amd: no gfx950 accelerator is available; the engine has no CPU "
-                                     "traversal path");
+        const std::size_t n_dev = cuts.size() - 2u; // devices with a share
+        bool any_dev = false;
+        for (std::size_t d = 0; d < n_dev; ++d) {
+            any_dev = any_dev || cuts[d + 2u] > cuts[d + 1u];
+        }
+        if (any_dev && !rk_has_accelerator()) {
+            throw std::runtime_error("rakau_amd: no gfx950 accelerator is available for the device share of the "
+                                     "computation (split = {1} selects the CPU engine)");
         }
         void *out[4] = {};
         for (std::size_t j = 0; j < nvecs_res<Q>; ++j) {
@@ -1390,19 +1427,23 @@ private:
                                     static_cast<std::int64_t>(e), out, static_cast<double>(mac_value),
                                     static_cast<double>(G), static_cast<double>(eps2), 1));
         };
-        if (cuts.size() == 2u) {
-            run_one(0, cuts[0], cuts[1]);
+        const bool cpu_share = cuts[1] > cuts[0];
+        if (!cpu_share && n_dev == 1u) {
+            run_one(0, cuts[1], cuts[2]); // the common case: no thread
             return;
         }
-        // One host thread per additional device; futures are always joined so that exceptions
-        // propagate (as the reference does for its accelerator future, tree.hpp:3071-3113).
         std::vector<std::future<void>> futs;
-        for (std::size_t d = 1; d + 1u < cuts.size(); ++d) {
-            futs.emplace_back(std::async(std::launch::async, run_one, static_cast<int>(d), cuts[d], cuts[d + 1u]));
+        // Device 0 gets a thread of its own only if this thread is busy with the CPU share.
+        for (std::size_t d = cpu_share ? 0u : 1u; d < n_dev; ++d) {
+            futs.emplace_back(std::async(std::launch::async, run_one, static_cast<int>(d), cuts[d + 1u], cuts[d + 2u]));
         }
         std::exception_ptr ep;
         try {
-            run_one(0, cuts[0], cuts[1]);
+            if (cpu_share) {
+                cpu_run<Q>(res, cuts[1], mac_value, G, eps2);
+            } else {
+                run_one(0, cuts[1], cuts[2]);
+            }
         } catch (...) {
             ep = std::current_exception();
         }
@@ -1599,6 +1640,27 @@ public:
     void accs_pots_##NAME(std::initializer_list<It> out, F mac_value, KwArgs &&... args) const                         \
     {                                                                                                                  \
         accs_pots_##NAME(ilist_to_array<2>(out), mac_value, std::forward<KwArgs>(args)...);                            \
+    }
+
+    // Engine hook for tests and benchmarks: the CPU engine alone on the whole tree (what split = {1} runs) with an
+    // explicit arithmetic flavour and thread count (0 = all usable host threads). Q = 0 / 1 / 2 as in
+    // accs_u / pots_u / accs_pots_u; results in Morton order; same checks and transforms as every acc/pot call.
+    template <unsigned Q>
+    void cpu_acc_pot_u(const std::array<F *, nvecs_res<Q>> &out, F orig_mac_value, F G, F eps, cpu_flavour flavour,
+                       unsigned nthreads) const
+    {
+        if (!std::isfinite(orig_mac_value) || orig_mac_value <= F(0)) {
+            throw std::domain_error("The MAC value must be finite and positive, but it is "
+                                    + std::to_string(orig_mac_value) + " instead");
+        }
+        const F mac_value = MAC == mac::bh ? F(1) / (orig_mac_value * orig_mac_value) : F(1) / orig_mac_value;
+        if (!std::isfinite(mac_value) || mac_value <= F(0)) {
+            throw std::domain_error("The transformed MAC value must be finite and positive, but it is "
+                                    + std::to_string(mac_value) + " instead");
+        }
+        const F eps2 = compute_eps2(eps);
+        check_G_const(G);
+        cpu_run<Q>(out, nparts(), mac_value, G, eps2, flavour, nthreads);
     }
 
     // accs_u / pots_u / accs_pots_u: results in Morton order (tree.hpp:3406-3451).

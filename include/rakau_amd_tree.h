@@ -42,6 +42,12 @@ RK_EXPORT int rk_tree_state(const rk_tree *t, rk_state **state);
  * arrays of nparts values. theta is the un-transformed MAC value. */
 RK_EXPORT int rk_tree_acc_pot(const rk_tree *t, int q, int ordered, void *const *out, double theta, double G,
                               double eps, const double *split, int n_split);
+/* The CPU engine of the header alone (the engine that runs the host share of kwargs::split, tree.hpp:3047-3113 of the
+ * reference; tree::cpu_acc_pot_u): Morton-order results for the whole tree. flavour: 0 = automatic (widest SIMD, fp32
+ * rsqrt + Newton step), 1 = scalar (the arithmetic and summation order of the reference's scalar branch), 2 = SIMD with
+ * sqrt + divide. nthreads 0 = all usable host threads. Needs no GPU. */
+RK_EXPORT int rk_tree_cpu_acc_pot(const rk_tree *t, int q, void *const *out, double theta, double G, double eps,
+                                  int flavour, unsigned nthreads);
 /* exact_{acc,pot,acc_pot}_{u,o}(idx, G, eps): out receives 3/1/4 values. */
 RK_EXPORT int rk_tree_exact(const rk_tree *t, int q, int ordered, int64_t idx, double G, double eps, void *out);
 /* update_particles_u with a functor that overwrites the Morton-ordered x, y, z, masses with the given

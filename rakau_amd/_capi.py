@@ -29,7 +29,7 @@ SYMBOLS = [
     "rk_state_ndim",
     # host-side tree builder (include/rakau_amd_tree.h)
     "rk_tree_create", "rk_tree_create_nd", "rk_tree_destroy", "rk_tree_info", "rk_tree_get", "rk_tree_nodes", "rk_tree_state",
-    "rk_tree_acc_pot", "rk_tree_exact", "rk_tree_update_particles",
+    "rk_tree_acc_pot", "rk_tree_exact", "rk_tree_update_particles", "rk_tree_cpu_acc_pot",
 ]
 
 _lib = None
@@ -109,6 +109,7 @@ def lib():
         L.rk_tree_state.argtypes = [vp, C.POINTER(vp)]
         L.rk_tree_acc_pot.argtypes = [vp, ci, ci, C.POINTER(vp), dbl, dbl, dbl, C.POINTER(dbl), ci]
         L.rk_tree_exact.argtypes = [vp, ci, ci, i64, dbl, dbl, vp]
+        L.rk_tree_cpu_acc_pot.argtypes = [vp, ci, C.POINTER(vp), dbl, dbl, dbl, ci, C.c_uint]
         L.rk_tree_update_particles.argtypes = [vp, vp, vp, vp, vp]
     _lib = L
     return L

@@ -279,6 +279,10 @@ __global__ void __launch_bounds__(64 * RK_WPB, (sizeof(F) == 4 ? (R <= 2 ? RK_W1
     const v4 blo = P.crit_box[2u * g], bhi = P.crit_box[2u * g + 1u];
     const v4 pr0 = P.part4[tb], pr1 = P.part4[te - 1u];
     RK_STAMP_DECL
+#ifdef RK_TRACE
+    // Diagnostic build: wall-clock interval (100 MHz counter) and placement of every wave, for occupancy timelines.
+    const unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     int size = 0, n_src = 0, n_lq = 0, n_uq = 0;
     // Supergroup pre-pass results for this group's supergroup (if enabled and not overflowed).
     uint32_t sup_S = 0, sup_ncommon = 0, sup_nresid = 0, sup_rpos = 0;
@@ -741,6 +745,15 @@ __global__ void __launch_bounds__(64 * RK_WPB, (sizeof(F) == 4 ? (R <= 2 ? RK_W1
     }
     RK_STAMP(7)
     RK_STAMP_FLUSH
+#ifdef RK_TRACE
+    if (lane == 0 && P.dbg) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+        P.dbg[4u * g] = tr_t0;
+        P.dbg[4u * g + 1u] = __builtin_amdgcn_s_memrealtime();
+        P.dbg[4u * g + 2u] = (static_cast<unsigned long long>(xcc) << 32) | hw;
+        P.dbg[4u * g + 3u] = (static_cast<unsigned long long>(R) << 32) | static_cast<unsigned>(T);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

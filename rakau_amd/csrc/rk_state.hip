@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -667,6 +668,34 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                 h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
         RK_HIP(hipMemset(d_dbg, 0, sizeof(h)));
         p.dbg = d_dbg;
+    }
+#endif
+#ifdef RK_TRACE
+    {
+        // Diagnostic build: per-wave {start, end, placement, size} records of the PREVIOUS call go to $RK_TRACE_FILE.
+        static unsigned long long *d_tr = nullptr;
+        static size_t tr_n = 0;
+        const size_t n = static_cast<size_t>(s.n_crit) * 4;
+        if (d_tr && tr_n == n) {
+            RK_HIP(hipDeviceSynchronize());
+            std::vector<unsigned long long> h(n);
+            RK_HIP(hipMemcpy(h.data(), d_tr, n * 8, hipMemcpyDeviceToHost));
+            if (const char *f = std::getenv("RK_TRACE_FILE")) {
+                if (FILE *fp = std::fopen(f, "wb")) {
+                    std::fwrite(h.data(), 8, n, fp);
+                    std::fclose(fp);
+                }
+            }
+        }
+        if (tr_n != n) {
+            if (d_tr) {
+                (void)hipFree(d_tr);
+            }
+            RK_HIP(hipMalloc(&d_tr, n * 8));
+            tr_n = n;
+        }
+        RK_HIP(hipMemset(d_tr, 0, n * 8));
+        p.dbg = d_tr;
     }
 #endif
     if (!s.ev0) {

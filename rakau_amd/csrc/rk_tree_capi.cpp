@@ -313,6 +313,40 @@ int rk_tree_acc_pot(const rk_tree *t, int q, int ordered, void *const *out, doub
     });
 }
 
+int rk_tree_cpu_acc_pot(const rk_tree *t, int q, void *const *out, double theta, double G, double eps, int flavour,
+                        unsigned nthreads)
+{
+    return guard([&] {
+        if (!t || !out) {
+            throw std::invalid_argument("null argument");
+        }
+        if (flavour < 0 || flavour > 2) {
+            throw std::invalid_argument("flavour must be 0 (automatic), 1 (scalar) or 2 (SIMD, exact arithmetic)");
+        }
+        std::visit(
+            [&](const auto &tr) {
+                using F = typename fp_of<std::decay_t<decltype(tr)>>::type;
+                constexpr std::size_t ND = fp_of<std::decay_t<decltype(tr)>>::ndim;
+                const auto fl = static_cast<cpu_flavour>(flavour);
+                const F th = static_cast<F>(theta), g = static_cast<F>(G), e = static_cast<F>(eps);
+                auto ptrs = [&](auto tag) {
+                    std::array<F *, decltype(tag)::value> a;
+                    for (std::size_t k = 0; k < a.size(); ++k) {
+                        a[k] = static_cast<F *>(out[k]);
+                    }
+                    return a;
+                };
+                switch (q) {
+                    case 0: tr.template cpu_acc_pot_u<0>(ptrs(std::integral_constant<std::size_t, ND>{}), th, g, e, fl, nthreads); break;
+                    case 1: tr.template cpu_acc_pot_u<1>(ptrs(std::integral_constant<std::size_t, 1>{}), th, g, e, fl, nthreads); break;
+                    case 2: tr.template cpu_acc_pot_u<2>(ptrs(std::integral_constant<std::size_t, ND + 1u>{}), th, g, e, fl, nthreads); break;
+                    default: throw std::invalid_argument("q must be 0, 1 or 2");
+                }
+            },
+            t->t);
+    });
+}
+
 int rk_tree_exact(const rk_tree *t, int q, int ordered, int64_t idx, double G, double eps, void *out)
 {
     return guard([&] {

@@ -122,6 +122,14 @@ class Octree:
         _capi.check(_capi.lib().rk_tree_acc_pot(self._h, q, int(ordered), ptrs, theta, G, eps, sp, len(split)))
         return outs
 
+    def cpu_acc_pot_u(self, q, theta, G=1.0, eps=0.0, flavour="auto", nthreads=0):
+        """tree::cpu_acc_pot_u: the header's CPU engine alone (no GPU involved). flavour: 'auto' | 'scalar' | 'simd_exact'."""
+        outs = [np.zeros(self.nparts, dtype=self.dtype) for _ in range(nres(q, self.ndim))]
+        ptrs = (C.c_void_p * 4)(*[o.ctypes.data for o in outs], *([None] * (4 - len(outs))))
+        fl = {"auto": 0, "scalar": 1, "simd_exact": 2}[flavour]
+        _capi.check(_capi.lib().rk_tree_cpu_acc_pot(self._h, q, ptrs, theta, G, eps, fl, nthreads))
+        return outs
+
     def accs_u(self, theta, **kw):
         return self._acc_pot(0, False, theta, **kw)
 

@@ -127,8 +127,27 @@ static void gpu_checks()
     std::vector<F> ax(s), ay(s), az(s);
     t.accs_u(std::array{ax.begin(), ay.begin(), az.begin()}, F(0.75));
     std::vector<F> bx(s), by(s), bz(s);
-    t.accs_u({bx.data(), by.data(), bz.data()}, F(0.75), split = std::vector<double>{0.5, 0.5});
+    t.accs_u({bx.data(), by.data(), bz.data()}, F(0.75), split = std::vector<double>{0., 1.});
     CHECK(ax == bx && ay == by && az == bz);
+    // split = {cpu, dev0}: the CPU engine of the header computes the first half while the GPU computes the rest
+    // (tree.hpp:3047-3113 of the reference); same interaction lists, so the halves agree with the GPU-only result to
+    // rounding, and the device half exactly.
+    t.accs_u({bx.data(), by.data(), bz.data()}, F(0.75), split = std::vector<double>{0.5, 0.5});
+    {
+        double worst = 0;
+        std::size_t n_same = 0;
+        for (std::size_t i = 0; i < s; ++i) {
+            const double d[3] = {double(ax[i]) - bx[i], double(ay[i]) - by[i], double(az[i]) - bz[i]};
+            const double nrm = std::sqrt(double(ax[i]) * ax[i] + double(ay[i]) * ay[i] + double(az[i]) * az[i]);
+            worst = std::max(worst, std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) / nrm);
+            n_same += ax[i] == bx[i] && ay[i] == by[i] && az[i] == bz[i];
+        }
+        CHECK(worst < (std::is_same_v<F, double> ? 1e-12 : 2e-5));
+        CHECK(n_same >= s / 2 - 200 && ax[s - 1] == bx[s - 1]);
+    }
+    // CPU only (split = {1}): the reference's default engine.
+    t.accs_u({bx.data(), by.data(), bz.data()}, F(0.75), split = std::vector<double>{1.});
+    for (std::size_t i = 0; i < s; i += 97) CHECK(std::abs(double(ax[i]) - bx[i]) <= 2e-5 * (std::abs(double(ax[i])) + 1e-3));
     t.accs_u({bx.data(), by.data(), bz.data()}, F(0.75), G = 0);
     for (std::size_t i = 0; i < s; ++i) CHECK(bx[i] == F(0) && by[i] == F(0) && bz[i] == F(0));
     // update_particles_o: shift everything; accelerations are translation invariant up to rounding.

@@ -119,7 +119,7 @@ def test_4m_accs_pots_softened():
     """BASELINE config 3. The reference's only in-repo softening choice for this workload:
     eps = 0.45 * N^-0.73 (benchmark/benchmark_leapfrog.cpp:218-223)."""
     n = 4_000_000
-    check_full_size(n, "float32", 0.75, 2, 0.45 * n ** -0.73, n_shards=8, width=600, tol_max=2e-4, tol_med=1e-6,
+    check_full_size(n, "float32", 0.75, 2, 0.45 * n ** -0.73, n_shards=8, width=600, tol_max=2e-4, tol_med=3e-6,
                     n_direct=20)
 
 
@@ -132,7 +132,7 @@ def test_16m_fp64_theta05():
 def test_64m_sharded():
     """BASELINE config 5 on one GPU: the whole 64M problem, then as 8 Morton shards run back to back (what the 8
     GPUs of the sharded run compute, one shard each, on the replicated tree); the union is bit-identical."""
-    check_full_size(64_000_000, "float32", 0.75, 0, 0.0, n_shards=8, width=600, tol_max=2e-4, tol_med=1e-6,
+    check_full_size(64_000_000, "float32", 0.75, 0, 0.0, n_shards=8, width=600, tol_max=2e-4, tol_med=3e-6,
                     n_direct=3)
 
 

@@ -145,7 +145,10 @@ def test_quadtree_front_door(dtype, builder):
         assert abs(t.exact_pot_o(i, G=2.0, eps=0.1) - t.pots_o(0.01, G=2.0, eps=0.1)[i]) <= tol * abs(t.exact_pot_o(i, G=2.0, eps=0.1))
     a1, a2, a3 = t.accs_u(0.75), t.accs_u(0.75, G=2.0), t.accs_u(0.75, split=[0.3, 0.7])
     for u, v, w in zip(a1, a2, a3):
-        assert np.array_equal(2 * u, v) and np.array_equal(u, w)
+        # split = {cpu, dev0}: the first 30 % (snapped to a critical node) come from the CPU engine (rounding-level
+        # agreement), the rest from the GPU (identical).
+        assert np.array_equal(2 * u, v) and np.array_equal(u[s // 2:], w[s // 2:])
+        assert np.abs(u - w).max() <= (1e-5 if dtype == np.float32 else 1e-13) * np.abs(u).max()
     ot = oracle.Tree(x, y, None, m, box_size=4.0, ndim=2)
     e = rel_err_vec(a1, ot.acc_pot(0, 0.75, nthreads=4), ndim=2)
     assert np.median(e) < (1e-6 if dtype == np.float32 else 1e-14) and e.max() < tol

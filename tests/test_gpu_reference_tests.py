@@ -126,10 +126,29 @@ def test_split_and_errors():
     m, x, y, z = rng.uniform_particles(5000, 1.0, np.float32)
     t = rakau_amd.Octree(x, y, z, m, box_size=1.0)
     base = t.accs_u(0.75)
-    # {host, dev0}: the host share is executed by device 0 -> identical results for every split.
-    for sp in ((0.5, 0.5), (0.0, 1.0), (1.0, 0.0), (0.3,)):
-        for r, b in zip(t.accs_u(0.75, split=sp), base):
-            assert np.array_equal(r, b)
+    cpu = t.cpu_acc_pot_u(0, 0.75)
+    # split = {cpu, dev0} (tree.hpp:3047-3113): the CPU engine computes the critical nodes below the cut while the GPU
+    # computes the rest. Every particle's result is the one its engine gives alone, bit for bit (critical nodes are
+    # independent); the two engines agree with each other to rounding (same interaction lists).
+    assert max(float(np.abs(c - b).max() / np.abs(b).max()) for c, b in zip(cpu, base)) < 1e-5
+    for r, b in zip(t.accs_u(0.75, split=(0.0, 1.0)), base):
+        assert np.array_equal(r, b)
+    for sp in ((1.0, 0.0), (0.3,), (1.0, 1e-9)):  # no device share, CPU only, device share below rk_min_size()
+        for r, c in zip(t.accs_u(0.75, split=sp), cpu):
+            assert np.array_equal(r, c)
+    crit = t.crit_nodes()
+    for sp in ((0.5, 0.5), (0.2, 0.8), (3.0, 1.0)):
+        want = int(sp[0] / (sp[0] + sp[1]) * t.nparts)
+        i = int(np.searchsorted(crit[:, 1].astype(np.int64), want, side="left"))
+        cut = int(crit[i, 1]) if i < len(crit) else t.nparts  # snapped to a critical node (tree.hpp:3053-3063)
+        assert 0 < cut < t.nparts
+        for r, c, b in zip(t.accs_pots_u(0.75, split=sp, eps=1e-3, G=2.0), t.cpu_acc_pot_u(2, 0.75, eps=1e-3, G=2.0),
+                           t.accs_pots_u(0.75, eps=1e-3, G=2.0)):
+            assert np.array_equal(r[:cut], c[:cut]) and np.array_equal(r[cut:], b[cut:])
+    # _o outputs of a split call: the same values scattered through perm.
+    perm = t.perm().astype(np.int64)
+    for u, o in zip(t.accs_u(0.75, split=(0.5, 0.5)), t.accs_o(0.75, split=(0.5, 0.5))):
+        assert np.array_equal(o[perm], u)
     with pytest.raises(ValueError, match="cannot contain non-finite"):
         t.accs_u(0.75, split=(float("nan"), 1.0))
     with pytest.raises(ValueError, match="only non-negative"):
