@@ -132,7 +132,7 @@ def test_16m_fp64_theta05():
 def test_64m_sharded():
     """BASELINE config 5 on one GPU: the whole 64M problem, then as 8 Morton shards run back to back (what the 8
     GPUs of the sharded run compute, one shard each, on the replicated tree); the union is bit-identical."""
-    check_full_size(64_000_000, "float32", 0.75, 0, 0.0, n_shards=8, width=600, tol_max=2e-4, tol_med=3e-6,
+    check_full_size(64_000_000, "float32", 0.75, 0, 0.0, n_shards=8, width=600, tol_max=2e-4, tol_med=1e-5,
                     n_direct=3)
 
 
