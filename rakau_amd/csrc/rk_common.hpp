@@ -225,7 +225,7 @@ struct rk_state {
     hipEvent_t ev_fork = nullptr, ev_join[rk::n_list_R] = {};
     // hipGraph of the launch sequence of the last call (replayed when a call repeats it).
     struct graph_key {
-        int q, offset_output, super_k, pad;
+        int q, offset_output, super_k, variant;
         int64_t p_begin, p_end;
         double mac_value, G, eps2;
         void *out[4];
@@ -260,6 +260,9 @@ void launch_traversal(const rk_state &s, int q, const kparams<F> &p, const int64
 template <typename F>
 void launch_list(const rk_state &s, int q, const kparams<F> &p, const int64_t cls_begin[n_classes],
                  const int64_t cls_end[n_classes], hipStream_t const streams[n_list_R]);
+template <typename F>
+void launch_pc(const rk_state &s, int q, int kc, const kparams<F> &p, const int64_t cls_begin[n_classes],
+               const int64_t cls_end[n_classes], hipStream_t const streams[n_list_R]);
 template <typename F>
 void launch_super(const rk_state &s, const kparams<F> &p, int64_t s_begin, int64_t s_end, hipStream_t stream);
 template <typename F>

@@ -1,0 +1,634 @@
+// Variant 3 of the traversal: producer / consumer wavefronts per target group.
+//
+// The list kernel (rk_kernels_list.hip) alternates list building and dense evaluation inside ONE wavefront per critical
+// node: the two phases serialise, the live registers of both are allocated together (spills), and a launch with few
+// critical nodes leaves the device half empty while every wave walks its long serial chain. Here a workgroup of
+// 1 + KC wavefronts serves one critical node:
+//
+//   * the PRODUCER wave builds the interaction list exactly as the list kernel does (same stack of sibling runs, same
+//     box / probe / exact MAC tests, same leaf gathering, same supergroup pre-pass inputs) into a double-buffered LDS tile;
+//   * the KC CONSUMER waves evaluate the published tile with the dense targets x sources loop while the producer fills
+//     the other buffer. One workgroup barrier per tile: the producer arrives when tile k is complete, the consumers when
+//     they have finished tile k - 1.
+//
+// With KC = 1 the sequence of tiles, their contents and the lane mapping of the dense phase are those of the list
+// kernel, so the results are bit-identical to it (tests assert this); the critical path of a group becomes
+// max(list building, dense) instead of their sum, the device holds twice as many waves for the same number of groups,
+// and neither role keeps the other's registers alive. KC = 2 splits every tile between two consumers (fixed shares,
+// partial sums added in a fixed order): a different, equally deterministic summation order -- selected per STATE
+// (rk_set_kernel_variant), never per call, so that shards and full-range calls of one state always agree bit for bit.
+//
+// The MAC decisions are those of the reference's CPU engine (include/rakau/tree.hpp:2662-2672 of the reference).
+#include "rk_list_common.hpp"
+
+#ifndef RK_PC_W12
+#define RK_PC_W12 8 // waves per SIMD the R <= 2 kernels are compiled for
+#endif
+#ifndef RK_PC_W34
+#define RK_PC_W34 6 // R = 3, 4
+#endif
+#ifndef RK_PC_W64
+#define RK_PC_W64 4 // fp64
+#endif
+
+namespace rk
+{
+
+constexpr uint32_t PC_LAST = 0x80000000u;
+
+// Workgroup LDS: producer-private stack and queues, two tiles of KC x src_cap sources, the published counts.
+// fp32, KC = 1: 2 + 1 + 0.5 + 4 KiB = 7.5 KiB per group.
+template <typename F, int KC>
+struct pc_lds {
+    uint32_t stack[LK_STACK_CAP];
+    uint2 lq[LK_LQ_CAP];
+    uint32_t uq[LK_UQ_CAP];
+    uint32_t tile_n[2];
+    typename vt<F>::v4 tile[2][lk_cfg<F>::src_cap * KC];
+};
+
+template <typename F, int Q, int MAC, int R, int ND, int KC>
+__global__ void __launch_bounds__(64 * (1 + KC), (sizeof(F) == 4 ? (R <= 2 ? RK_PC_W12 : RK_PC_W34) : RK_PC_W64))
+    k_pc(const kparams<F> P, const uint32_t *__restrict__ list, int n_list)
+{
+    using v4 = typename vt<F>::v4;
+    using v2 = typename vt<F>::v2;
+    constexpr int NR = nres_of(Q);
+    constexpr int SRC_CAP = lk_cfg<F>::src_cap; // sources one consumer takes from a tile
+    constexpr int TILE_CAP = SRC_CAP * KC;
+    static_assert(KC == 1 || KC == 2);
+    static_assert(sizeof(uint32_t) * LK_STACK_CAP >= 64 * 4 * sizeof(F) || KC == 1, "cross-consumer scratch does not fit");
+    __shared__ pc_lds<F, KC> L;
+
+    const int role = threadIdx.x >> 6; // 0 = producer, 1.. = consumers
+    const int lane = threadIdx.x & 63;
+    const unsigned blk = xcd_map_block(blockIdx.x, gridDim.x, P.xcd_mode);
+    if (static_cast<int>(blk) >= n_list) {
+        return;
+    }
+    const uint32_t g = __builtin_amdgcn_readfirstlane(list[blk]);
+    const uint4 c = P.crit[g];
+    const uint32_t tb = c.x, te = c.y, cnode = c.z;
+    const int T = static_cast<int>(te - tb);
+#ifdef RK_TRACE
+    const unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+
+    // Lane mapping of the dense phase (also used by the producer's lane = target exact test): TP target slots,
+    // NS source splits.
+    const int TP = (T + R - 1) / R;
+    const int NS = 64 / TP;
+    const int ts = lane % TP, sp_raw = lane / TP;
+    const bool lane_on = sp_raw < NS;
+    const int sp = lane_on ? sp_raw : 0; // idle lanes shadow split 0; their results are never stored
+
+    v4 tp[R];
+    int tidx[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        tidx[r] = ts + r * TP;
+        const bool valid = tidx[r] < T;
+        tp[r] = P.part4[tb + (valid ? tidx[r] : 0)];
+        if (!valid) {
+            tidx[r] = -1;
+        }
+    }
+    const F eps2 = P.eps2;
+
+    if (role != 0) {
+        // =====================================================================================================
+        // Consumer: dense evaluation of the published tiles.
+        // =====================================================================================================
+        const int cons = role - 1;
+        F acc[R][NR];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+            for (int k = 0; k < NR; ++k) {
+                acc[r][k] = F(0);
+            }
+        }
+        // n / NS for n <= SRC_CAP without a division per tile: exact for n * NS < 2^16.
+        const int inv_ns = (65536 + NS - 1) / NS;
+        static_assert(lk_cfg<F>::src_cap * 64 < 65536);
+        int buf = 0;
+        for (;;) {
+            __syncthreads(); // tile `buf` is published; the producer now owns the other buffer
+            const uint32_t word = L.tile_n[buf];
+            const int n_all = static_cast<int>(word & ~PC_LAST);
+            // Consumer c takes the sources [c * SRC_CAP, (c + 1) * SRC_CAP) of the tile.
+            int n = n_all - cons * SRC_CAP;
+            n = n < 0 ? 0 : (n > SRC_CAP ? SRC_CAP : n);
+            if (n > 0) {
+                lk_eval_tile<F, Q, R, false, ND>(L.tile[buf] + cons * SRC_CAP, n, (n * inv_ns) >> 16, sp, NS, true, lane_on, tp,
+                                                 acc, eps2, tidx);
+            }
+            if (word & PC_LAST) {
+                break;
+            }
+            buf ^= 1;
+        }
+        // ---- interactions inside the group: its own particles as sources, self pair masked (consumer 0) ----
+        // The producer has published its last tile: the buffer it would fill next is free.
+        if (cons == 0) {
+            v4 *self = L.tile[buf ^ 1];
+            for (int b0 = 0; b0 < T; b0 += SRC_CAP) {
+                const int n = (T - b0) < SRC_CAP ? (T - b0) : SRC_CAP;
+                for (int j = lane; j < n; j += 64) {
+                    self[j] = P.part4[tb + static_cast<uint32_t>(b0 + j)];
+                }
+                wave_sync();
+                int tloc[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    tloc[r] = tidx[r] < 0 ? -1 : tidx[r] - b0;
+                }
+                lk_eval_tile<F, Q, R, true, ND>(self, n, (n * inv_ns) >> 16, sp, NS, true, lane_on, tp, acc, eps2, tloc);
+                wave_sync();
+            }
+        }
+        // ---- sum the source splits in a fixed order ----
+        if (NS > 1) {
+            // Scratch: this consumer's share of the buffer it read last (nobody else touches it any more; 64 * NR values).
+            F *red = reinterpret_cast<F *>(L.tile[buf] + cons * SRC_CAP);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (lane_on) {
+#pragma unroll
+                    for (int k = 0; k < NR; ++k) {
+                        red[(sp_raw * TP + ts) * NR + k] = acc[r][k];
+                    }
+                }
+                wave_sync();
+                if (lane_on && sp_raw == 0) {
+#pragma unroll
+                    for (int k = 0; k < NR; ++k) {
+                        F sum = F(0);
+                        for (int s = 0; s < NS; ++s) {
+                            sum += red[(s * TP + ts) * NR + k];
+                        }
+                        acc[r][k] = sum;
+                    }
+                }
+                wave_sync();
+            }
+        }
+        if constexpr (KC > 1) {
+            // ---- add the consumers' partial sums in consumer order (scratch: the producer's stack, idle by now) ----
+            F *xr = reinterpret_cast<F *>(L.stack);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (cons == 1 && lane_on && sp_raw == 0) {
+#pragma unroll
+                    for (int k = 0; k < NR; ++k) {
+                        xr[ts * NR + k] = acc[r][k];
+                    }
+                }
+                __syncthreads();
+                if (cons == 0 && lane_on && sp_raw == 0) {
+#pragma unroll
+                    for (int k = 0; k < NR; ++k) {
+                        acc[r][k] += xr[ts * NR + k];
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // ---- scale by G, write out ----
+        if (cons == 0 && lane_on && sp_raw == 0) {
+            const F G = P.G;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (tidx[r] >= 0) {
+                    const uint32_t o = out_index(P, tb + static_cast<uint32_t>(tidx[r]));
+#pragma unroll
+                    for (int k = 0; k < NR; ++k) {
+                        if (ND == 3 || Q == 1 || k != 2) { // a quadtree has no z acceleration (and no array for it)
+                            P.out[k][o] = acc[r][k] * G;
+                        }
+                    }
+                }
+            }
+        }
+#ifdef RK_TRACE
+        if (cons == 0 && lane == 0 && P.dbg) {
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+            P.dbg[4u * g] = tr_t0;
+            P.dbg[4u * g + 1u] = __builtin_amdgcn_s_memrealtime();
+            P.dbg[4u * g + 2u] = (static_cast<unsigned long long>(xcc) << 32) | hw;
+            P.dbg[4u * g + 3u] = (static_cast<unsigned long long>(R) << 32) | static_cast<unsigned>(T);
+        }
+#endif
+        return;
+    }
+
+    // =========================================================================================================
+    // Producer: list building (the code of the list kernel, with flush() replaced by publish()).
+    // =========================================================================================================
+    const F mac_value = P.mac_value;
+    // Bounding box of the group's particles and two probe targets (first and last): wave-uniform.
+    const v4 blo = P.crit_box[2u * g], bhi = P.crit_box[2u * g + 1u];
+    const v4 pr0 = P.part4[tb], pr1 = P.part4[te - 1u];
+    int size = 0, n_src = 0, n_lq = 0, n_uq = 0, cur = 0;
+    v4 *src = L.tile[0];
+    // Supergroup pre-pass results for this group's supergroup (if enabled and not overflowed).
+    uint32_t sup_S = 0, sup_ncommon = 0, sup_nresid = 0, sup_rpos = 0;
+    bool from_root = true;
+    if (P.super_k != 0u) {
+        sup_S = g / P.super_k;
+        const uint2 cnt = P.sup_cnt[sup_S];
+        if ((cnt.y >> 31) == 0u) {
+            from_root = false;
+            sup_ncommon = cnt.x;
+            sup_nresid = cnt.y;
+        }
+    }
+    if (from_root) {
+        // The root is an ancestor of every group (or the group itself): start from its children.
+        const node_rec<F> *root = P.node_rec;
+        const uint32_t r_nch = root->nch, r_a = root->a, r_b = root->b;
+        if (cnode != 0u && r_nch != 0u) {
+            if (lane == 0) {
+                L.stack[0] = (r_a << 3) | (r_b - 1u);
+            }
+            size = 1;
+        }
+    }
+    wave_sync();
+
+    // Hand the current tile to the consumers and take the other buffer (which they have finished with once they
+    // arrive at this barrier).
+    auto publish = [&](bool last) __attribute__((always_inline)) {
+        if (lane == 0) {
+            L.tile_n[cur] = static_cast<uint32_t>(n_src) | (last ? PC_LAST : 0u);
+        }
+        __syncthreads();
+        cur ^= 1;
+        src = L.tile[cur];
+        n_src = 0;
+    };
+    // The list kernel evaluates a tile as soon as another batch (up to 64 sources) might not fit; so does this one
+    // (KC = 1: identical tile boundaries).
+    auto flush = [&]() __attribute__((always_inline)) {
+        if (n_src > 0) {
+            publish(false);
+        }
+    };
+
+    // Gather the particles of the queued leaves into the source tile, publishing the tile when it fills.
+    auto drain_leaves = [&]() __attribute__((always_inline)) {
+        while (n_lq > 0) {
+            const int free_slots = TILE_CAP - n_src;
+            uint2 lf = make_uint2(0u, 0u);
+            if (lane < n_lq) {
+                lf = L.lq[lane];
+            }
+            const unsigned cnt = lane < n_lq ? lf.y - lf.x : 0u;
+            const unsigned incl = wave_incl_scan(cnt);
+            const bool fits = lane < n_lq && incl <= static_cast<unsigned>(free_slots);
+            const unsigned long long m_fit = __builtin_amdgcn_ballot_w64(fits);
+            const int m = __builtin_popcountll(m_fit); // leaves [0, m) fit (prefix property)
+            if (m == 0) {
+                if (n_src > 0) {
+                    flush();
+                    continue;
+                }
+                // A single leaf larger than the whole tile: take TILE_CAP of its particles.
+                const uint32_t b0 = __builtin_amdgcn_readfirstlane(lf.x);
+                for (int j = lane; j < TILE_CAP; j += 64) {
+                    src[j] = P.part4[b0 + static_cast<uint32_t>(j)];
+                }
+                if (lane == 0) {
+                    L.lq[0] = make_uint2(b0 + static_cast<uint32_t>(TILE_CAP), lf.y);
+                }
+                n_src = TILE_CAP;
+                wave_sync();
+                flush();
+                continue;
+            }
+            // Lane l copies the particles of leaf l, eight loads in flight at a time.
+            const unsigned mycnt = fits ? cnt : 0u;
+            const int dst = n_src + static_cast<int>(incl - cnt);
+            // Unconditional loads (index clamped into the leaf; particle 0 for idle lanes), all issued before the first
+            // store. Written out by hand: as an array the eight records end up in scratch memory in this kernel.
+            const uint32_t lbase = mycnt ? lf.x : 0u, llast = mycnt ? mycnt - 1u : 0u;
+            for (unsigned j0 = 0; __builtin_amdgcn_ballot_w64(j0 < mycnt) != 0ull; j0 += 8u) {
+#define RK_PC_LD(u) const v4 t##u = P.part4[lbase + (j0 + u##u < llast ? j0 + u##u : llast)];
+                RK_PC_LD(0) RK_PC_LD(1) RK_PC_LD(2) RK_PC_LD(3) RK_PC_LD(4) RK_PC_LD(5) RK_PC_LD(6) RK_PC_LD(7)
+#undef RK_PC_LD
+#define RK_PC_ST(u)                                                                                                    \
+    if (j0 + u##u < mycnt) {                                                                                           \
+        src[dst + static_cast<int>(j0 + u##u)] = t##u;                                                                 \
+    }
+                RK_PC_ST(0) RK_PC_ST(1) RK_PC_ST(2) RK_PC_ST(3) RK_PC_ST(4) RK_PC_ST(5) RK_PC_ST(6) RK_PC_ST(7)
+#undef RK_PC_ST
+            }
+            n_src += __builtin_amdgcn_readlane(static_cast<int>(incl), m - 1);
+            // Drop the consumed leaves from the queue (move the rest down, 64 entries at a time).
+            const int tail = n_lq - m;
+            wave_sync();
+            for (int j0 = 0; j0 < tail; j0 += 64) {
+                const int j = j0 + lane;
+                uint2 mv = make_uint2(0u, 0u);
+                if (j < tail) {
+                    mv = L.lq[j + m];
+                }
+                wave_sync();
+                if (j < tail) {
+                    L.lq[j] = mv;
+                }
+                wave_sync();
+            }
+            n_lq = tail;
+            if (n_src + 64 > TILE_CAP) {
+                flush();
+            }
+        }
+    };
+
+    // A batch of up to 64 candidate nodes held in registers (lane = candidate).
+    struct batch_t {
+        bool active;
+        v4 com;
+        v2 mp;
+        uint32_t node, nch, ra, rb, rec;
+    };
+    auto load_rec = [&](batch_t &bt) __attribute__((always_inline)) {
+        // Everything about the candidate in three independent 16-byte loads (record 0 for idle lanes).
+        const node_rec<F> *rec = P.node_rec + bt.rec;
+        bt.com = rec->com;
+        bt.mp = rec->mac;
+        bt.node = rec->dfs;
+        bt.nch = rec->nch;
+        bt.ra = rec->a;
+        bt.rb = rec->b;
+    };
+    // Pop up to 8 sibling runs and issue the loads of their records. Returns the number of entries popped.
+    auto pop_and_load = [&](batch_t &bt) __attribute__((always_inline)) -> int {
+        if (size == 0) {
+            return 0;
+        }
+        int k = size < 8 ? size : 8;
+        // Keep the stack within bounds even if every candidate is opened (8 pushes per popped entry);
+        // otherwise fall back to one entry at a time (depth-first), whose growth is bounded by LK_DFS_RESERVE.
+        const int room = (LK_STACK_CAP - LK_DFS_RESERVE - n_uq - size) / 7;
+        if (room < k) {
+            k = room >= 1 ? room : 1;
+        }
+        const int e_idx = lane >> 3, e_sub = lane & 7;
+        uint32_t entry = 0u;
+        if (e_idx < k) {
+            entry = L.stack[size - 1 - e_idx];
+        }
+        size -= k;
+        bt.active = e_idx < k && static_cast<uint32_t>(e_sub) <= (entry & 7u);
+        bt.rec = bt.active ? (entry >> 3) + static_cast<uint32_t>(e_sub) : 0u;
+        load_rec(bt);
+        return k;
+    };
+
+    // Route classified candidates: accepted nodes go to the source tile, opened leaves to the leaf queue,
+    // opened internal nodes push their run of children, undecided ones go to the exact-test queue.
+    auto route = [&](bool accept, bool open, bool undecided, const batch_t &bt) __attribute__((always_inline)) {
+        const bool leaf = open && bt.nch == 0u;
+        const bool expand = open && bt.nch != 0u;
+        const unsigned long long m_acc = __builtin_amdgcn_ballot_w64(accept);
+        if (accept) {
+            src[n_src + static_cast<int>(wave_prefix_count(m_acc))] = bt.com;
+        }
+        n_src += __builtin_popcountll(m_acc);
+        const unsigned long long m_leaf = __builtin_amdgcn_ballot_w64(leaf);
+        if (leaf) {
+            L.lq[n_lq + static_cast<int>(wave_prefix_count(m_leaf))] = make_uint2(bt.ra, bt.rb);
+        }
+        n_lq += __builtin_popcountll(m_leaf);
+        const unsigned long long m_exp = __builtin_amdgcn_ballot_w64(expand);
+        if (expand) {
+            L.stack[size + static_cast<int>(wave_prefix_count(m_exp))] = (bt.ra << 3) | (bt.rb - 1u);
+        }
+        size += __builtin_popcountll(m_exp);
+        const unsigned long long m_und = __builtin_amdgcn_ballot_w64(undecided);
+        if (undecided) {
+            L.uq[n_uq + static_cast<int>(wave_prefix_count(m_und))] = bt.rec;
+        }
+        n_uq += __builtin_popcountll(m_und);
+        wave_sync();
+    };
+
+    // First-stage MAC test of one batch: accept if the squared distance from the centre of mass to the group's
+    // bounding box exceeds mac_lh by a margin; open if one of two probe targets already violates the criterion; the rest
+    // is queued for the exact all-targets test (see rk_kernels_list.hip), so every decision equals the reference's.
+    auto process = [&](const batch_t &bt) __attribute__((always_inline)) {
+        const v4 com = bt.com;
+        // Ancestor-or-self of the target group (tree.hpp:2828-2838 of the reference) on the depth-first
+        // index interval of the subtree.
+        const bool anc = bt.active && bt.node <= cnode && cnode <= bt.node + bt.nch;
+        const bool self = anc && bt.node == cnode;
+        const bool test = bt.active && !anc;
+        const F mac_lh = mac_lhs<F>(MAC, bt.mp, mac_value);
+        const F bx = rk_max3(blo.x - com.x, com.x - bhi.x, F(0)), by = rk_max3(blo.y - com.y, com.y - bhi.y, F(0)),
+                bz = rk_max3(blo.z - com.z, com.z - bhi.z, F(0));
+        const F dbox2 = rk_fma(bz, bz, rk_fma(by, by, bx * bx));
+        const bool box_accept = dbox2 > mac_lh * F(1.00001);
+        const F p0x = com.x - pr0.x, p0y = com.y - pr0.y, p0z = com.z - pr0.z;
+        const F p1x = com.x - pr1.x, p1y = com.y - pr1.y, p1z = com.z - pr1.z;
+        const F d2p0 = rk_fma(p0z, p0z, rk_fma(p0y, p0y, p0x * p0x)), d2p1 = rk_fma(p1z, p1z, rk_fma(p1y, p1y, p1x * p1x));
+        const bool probe_open = mac_lh >= rk_min(d2p0, d2p1);
+        const bool accept = test && box_accept;
+        const bool open = (test && !box_accept && probe_open) || (anc && !self);
+        const bool undecided = test && !box_accept && !probe_open;
+        route(accept, open, undecided, bt);
+    };
+
+    // Exact MAC test (all targets) of up to 64 queued candidates.
+    auto process_exact = [&]() __attribute__((always_inline)) {
+        const int k = n_uq < 64 ? n_uq : 64;
+        batch_t bt;
+        bt.active = lane < k;
+        bt.rec = bt.active ? L.uq[n_uq - 1 - lane] : 0u;
+        n_uq -= k;
+        load_rec(bt);
+        const v4 com = bt.com;
+        const F mac_lh = mac_lhs<F>(MAC, bt.mp, mac_value);
+        bool fail;
+        if (k * (7 * R + 3) < T * 7) {
+            // Few candidates: lane = target (every lane keeps R targets of the group in registers; unused slots repeat
+            // target 0). The main loop keeps 64 free slots behind n_src in the tile; the candidates are staged there.
+            v4 cd;
+            cd.x = com.x, cd.y = com.y, cd.z = com.z, cd.w = mac_lh;
+            if (bt.active) {
+                src[n_src + lane] = cd;
+            }
+            wave_sync();
+            unsigned long long fail_mask = 0ull;
+            for (int ci = 0; ci < k; ++ci) {
+                const v4 cand = src[n_src + ci];
+                bool f = false;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const F dx = cand.x - tp[r].x, dy = cand.y - tp[r].y, dz = cand.z - tp[r].z;
+                    const F d2 = rk_fma(dz, dz, rk_fma(dy, dy, dx * dx));
+                    f |= cand.w >= d2;
+                }
+                if (__builtin_amdgcn_ballot_w64(f) != 0ull) {
+                    fail_mask |= 1ull << ci;
+                }
+            }
+            fail = ((fail_mask >> lane) & 1ull) != 0ull;
+            wave_sync();
+        } else {
+            // min over the targets of the unsoftened squared distance to the node's centre of mass. The target
+            // coordinates are wave-uniform: they arrive through scalar loads as SGPR operands.
+            F mind2 = std::numeric_limits<F>::infinity();
+            for (int t = 0; t < T; t += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ti = (t + u < T) ? t + u : T - 1;
+                    const v4 tg = P.part4[tb + static_cast<uint32_t>(ti)];
+                    const F dx = com.x - tg.x, dy = com.y - tg.y, dz = com.z - tg.z;
+                    const F d2 = rk_fma(dz, dz, rk_fma(dy, dy, dx * dx));
+                    mind2 = rk_min(mind2, d2);
+                }
+            }
+            fail = mac_lh >= mind2;
+        }
+        route(bt.active && !fail, bt.active && fail, false, bt);
+    };
+
+    // ---- sources accepted for the whole supergroup: stream them from the pre-pass list through the tile ----
+    {
+        const v4 *common = P.sup_common + static_cast<size_t>(sup_S) * SUP_CAPC;
+        for (uint32_t base = 0; base < sup_ncommon;) {
+            const uint32_t room = static_cast<uint32_t>(TILE_CAP - n_src), left = sup_ncommon - base;
+            const uint32_t take = left < room ? left : room;
+            for (uint32_t j = lane; j < take; j += 64u) {
+                src[n_src + static_cast<int>(j)] = common[base + j];
+            }
+            n_src += static_cast<int>(take);
+            base += take;
+            wave_sync();
+            if (n_src == TILE_CAP) {
+                flush();
+            }
+        }
+    }
+    // Candidates the pre-pass left to the member groups: taken 64 at a time whenever the stack runs empty.
+    auto resid_load = [&](batch_t &bt) __attribute__((always_inline)) -> int {
+        if (sup_rpos >= sup_nresid) {
+            return 0;
+        }
+        const uint32_t left = sup_nresid - sup_rpos, k = left < 64u ? left : 64u;
+        bt.active = static_cast<uint32_t>(lane) < k;
+        bt.rec = bt.active ? P.sup_resid[static_cast<size_t>(sup_S) * SUP_CAPR + sup_rpos + static_cast<uint32_t>(lane)] : 0u;
+        sup_rpos += k;
+        load_rec(bt);
+        return 1;
+    };
+    // ---- list building ----
+    bool done = false;
+    for (;;) {
+        // Room for the worst-case output of one pass (64 sources, 64 leaves); everything is settled at the end.
+        if (n_lq + 64 > LK_LQ_CAP || done) {
+            drain_leaves();
+        }
+        if (done) {
+            break;
+        }
+        if (n_src + 64 > TILE_CAP) {
+            flush();
+        }
+        if (n_uq >= 64) {
+            process_exact();
+            continue;
+        }
+        // Near the stack bound the descent is one entry at a time, and LK_DFS_RESERVE only bounds a STRICT depth-first
+        // descent: settle the parked candidates first.
+        if (n_uq > 0 && LK_STACK_CAP - LK_DFS_RESERVE - n_uq - size < 7) {
+            process_exact();
+            continue;
+        }
+        batch_t A;
+        int k = pop_and_load(A);
+        if (k == 0) {
+            k = resid_load(A);
+        }
+        if (k == 0) {
+            // Stack and residual list exhausted: settle the undecided candidates (they may open new runs).
+            if (n_uq > 0) {
+                process_exact();
+            } else {
+                done = true;
+            }
+            continue;
+        }
+        process(A);
+    }
+    publish(true);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Launch.
+// ------------------------------------------------------------------------------------------------
+template <typename F, int Q, int MAC, int KC>
+static void launch_pc_qm(const rk_state &s, const kparams<F> &p, const int64_t cb[n_classes], const int64_t ce[n_classes],
+                         hipStream_t const streams[n_list_R])
+{
+    const auto *lists = static_cast<const uint32_t *>(s.buf[RK_BUF_CLASS]);
+    auto go = [&](auto Rtag, int c) {
+        constexpr int R = decltype(Rtag)::value;
+        const int64_t n = ce[c] - cb[c];
+        if (n <= 0) {
+            return;
+        }
+        const auto grid = static_cast<unsigned>(n);
+        if (s.ndim == 3 || !RK_QUAD_BODY) {
+            hipLaunchKernelGGL((k_pc<F, Q, MAC, R, 3, KC>), dim3(grid), dim3(64 * (1 + KC)), 0, streams[c], p,
+                               lists + s.class2_off[c] + cb[c], static_cast<int>(n));
+        } else {
+            hipLaunchKernelGGL((k_pc<F, Q, MAC, R, 2, KC>), dim3(grid), dim3(64 * (1 + KC)), 0, streams[c], p,
+                               lists + s.class2_off[c] + cb[c], static_cast<int>(n));
+        }
+    };
+    static_assert(RK_MAX_R == 4, "the producer / consumer kernel is instantiated for R = 1..4");
+    go(std::integral_constant<int, 3>{}, 2);
+    go(std::integral_constant<int, 1>{}, 0);
+    go(std::integral_constant<int, 2>{}, 1);
+    go(std::integral_constant<int, 4>{}, 3);
+}
+
+template <typename F>
+void launch_pc(const rk_state &s, int q, int kc, const kparams<F> &p, const int64_t cb[n_classes],
+               const int64_t ce[n_classes], hipStream_t const streams[n_list_R])
+{
+    for (int c = RK_MAX_R; c < big_class; ++c) {
+        if (ce[c] != cb[c]) {
+            throw error(RK_ERUNTIME, "internal error: target group in a lane-mapping class beyond RK_MAX_R");
+        }
+    }
+    if (kc != 1 && kc != 2) {
+        throw error(RK_EINVAL, "invalid number of consumer waves");
+    }
+    switch ((q * 2 + s.mac) * 2 + (kc - 1)) {
+        case 0: launch_pc_qm<F, 0, 0, 1>(s, p, cb, ce, streams); break;
+        case 1: launch_pc_qm<F, 0, 0, 2>(s, p, cb, ce, streams); break;
+        case 2: launch_pc_qm<F, 0, 1, 1>(s, p, cb, ce, streams); break;
+        case 3: launch_pc_qm<F, 0, 1, 2>(s, p, cb, ce, streams); break;
+        case 4: launch_pc_qm<F, 1, 0, 1>(s, p, cb, ce, streams); break;
+        case 5: launch_pc_qm<F, 1, 0, 2>(s, p, cb, ce, streams); break;
+        case 6: launch_pc_qm<F, 1, 1, 1>(s, p, cb, ce, streams); break;
+        case 7: launch_pc_qm<F, 1, 1, 2>(s, p, cb, ce, streams); break;
+        case 8: launch_pc_qm<F, 2, 0, 1>(s, p, cb, ce, streams); break;
+        case 9: launch_pc_qm<F, 2, 0, 2>(s, p, cb, ce, streams); break;
+        case 10: launch_pc_qm<F, 2, 1, 1>(s, p, cb, ce, streams); break;
+        case 11: launch_pc_qm<F, 2, 1, 2>(s, p, cb, ce, streams); break;
+        default: throw error(RK_EINVAL, "invalid q / mac combination");
+    }
+    RK_HIP(hipGetLastError());
+}
+
+template void launch_pc<float>(const rk_state &, int, int, const kparams<float> &, const int64_t[n_classes],
+                               const int64_t[n_classes], hipStream_t const[n_list_R]);
+template void launch_pc<double>(const rk_state &, int, int, const kparams<double> &, const int64_t[n_classes],
+                                const int64_t[n_classes], hipStream_t const[n_list_R]);
+
+} // namespace rk

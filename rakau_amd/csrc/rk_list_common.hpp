@@ -1,0 +1,216 @@
+// Pieces shared by the interaction-list kernels (rk_kernels_list.hip: one wave per target group; rk_kernels_pc.hip:
+// producer / consumer waves per target group): tuning knobs, per-wave LDS layout, block -> group mapping, the dense
+// targets x sources evaluation of one LDS tile.
+#ifndef RK_LIST_COMMON_HPP
+#define RK_LIST_COMMON_HPP
+
+#include "rk_common.hpp"
+#include "rk_device.hpp"
+
+// Tuning knobs (defaults chosen by measurement on MI355X).
+#ifndef RK_UNR1
+#define RK_UNR1 4 // sources in flight per lane in the dense loop, R = 1
+#endif
+#ifndef RK_UNR2
+#define RK_UNR2 2 // R = 2
+#endif
+#ifndef RK_UNR3
+#define RK_UNR3 1 // R = 3
+#endif
+#ifndef RK_UNR4
+#define RK_UNR4 1 // R = 4
+#endif
+#ifndef RK_CHUNKED_SPLITS
+#define RK_CHUNKED_SPLITS 1 // dense phase: contiguous (1) or interleaved (0) assignment of tile sources to splits
+#endif
+#ifndef RK_QUAD_BODY
+#define RK_QUAD_BODY 1 // quadtrees: interaction body without the z terms (0: the 3-D body on z = 0 data)
+#endif
+#ifndef RK_CARRY_REMAINDER
+#define RK_CARRY_REMAINDER 0 // dense phase: carry the sources that do not fill a round of NS to the next tile instead of a
+                             // masked step per tile (measured slower: 2.30 vs 2.27 ms; the extra LDS shuffle costs more)
+#endif
+#ifndef RK_EXACT_TRANSPOSED
+#define RK_EXACT_TRANSPOSED 1 // exact MAC test with lane = target when only a few candidates are queued
+#endif
+#ifndef RK_WPB
+#define RK_WPB 1 // wavefronts (= target groups) per workgroup. Measured 4 -> 2.58 ms, 2 -> 2.45, 1 -> 2.35 at 4M: a block keeps its
+                 // LDS and wave slots until its slowest group ends, single-wave blocks free them at once (waves never sync)
+#endif
+#ifndef RK_W64
+#define RK_W64 4 // fp64 kernels (all R): waves per SIMD they are compiled for (3: 63.3 ms, 4: 62.8, 5: 67.3 at 16M)
+#endif
+#ifndef RK_W12
+#define RK_W12 7 // waves per SIMD the R <= 2 kernels are compiled for
+#endif
+#ifndef RK_W3
+#define RK_W3 6 // R = 3
+#endif
+#ifndef RK_W4
+#define RK_W4 5 // R = 4
+#endif
+#ifndef RK_W5
+#define RK_W5 4 // R = 5
+#endif
+#ifndef RK_W6
+#define RK_W6 3 // R = 6
+#endif
+
+
+namespace rk
+{
+
+#ifdef RK_STAMPS
+// Diagnostic build: wave-lifetime cycles per section (s_memtime), summed over waves into P.dbg[].
+#define RK_STAMP_DECL unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define RK_STAMP(i)                                                                                                    \
+    {                                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        const unsigned long long st_t1 = __builtin_amdgcn_s_memtime();                                                 \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        st_acc[i] += st_t1 - st_t0;                                                                                    \
+        st_t0 = st_t1;                                                                                                 \
+    }
+#define RK_STAMP_FLUSH                                                                                                 \
+    if (lane == 0 && P.dbg) {                                                                                          \
+        for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&P.dbg[i_], st_acc[i_]);                                              \
+    }
+#else
+#define RK_STAMP_DECL
+#define RK_STAMP(i)
+#define RK_STAMP_FLUSH
+#endif
+
+// Stack of pending sibling runs; an entry = (first child record << 3) | (number of children - 1) names up to
+// 8 candidate nodes. Popping k entries can push at most 8k (every candidate opened).
+constexpr int LK_STACK_CAP = 512;
+// Worst-case growth of the stack while descending depth-first from one entry: 7 pending entries per level.
+constexpr int LK_DFS_RESERVE = 7 * 21;
+constexpr int LK_LQ_CAP = 128;
+// Queue of candidates left undecided by the bounding-box / probe tests.
+constexpr int LK_UQ_CAP = 128;
+
+template <typename F>
+struct lk_cfg {
+    static constexpr int src_cap = 128; // sources per tile (2 KiB fp32, 4 KiB fp64)
+};
+
+// Per-wave LDS: 2 + 2 + 1 + 0.5 KiB = 5.5 KiB (fp32; 7.5 KiB fp64): 28 single-wave blocks per CU = 7 waves per SIMD.
+template <typename F>
+struct lk_wave_lds {
+    uint32_t stack[LK_STACK_CAP];
+    typename vt<F>::v4 src[lk_cfg<F>::src_cap];
+    uint2 lq[LK_LQ_CAP];
+    uint32_t uq[LK_UQ_CAP]; // records whose MAC test needs the exact all-targets loop
+};
+
+// Blocks are dealt round-robin to the 8 XCDs; give each XCD a contiguous slice of the (Morton-ordered)
+// group list so that the groups resident on one XCD share most of their nodes in that XCD's L2.
+// Bijective for any grid size. Placement only affects speed.
+__device__ __forceinline__ unsigned xcd_chunked_block(unsigned b, unsigned nb)
+{
+    const unsigned q = nb >> 3, r = nb & 7u, xcd = b & 7u, pos = b >> 3;
+    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + pos;
+}
+
+// mode 0: XCD x walks chunks x, x + 8, x + 16, ... of XCD_CHUNK consecutive blocks (L2 locality inside a
+// chunk, work spread evenly over the XCDs whatever the spatial variation of the group costs);
+// mode 1: one contiguous slice per XCD; mode 2: identity (hardware round-robin);
+// modes 3, 4: mode 1 with the slice walked from both ends alternately (3) or backwards (4) -- experiments on where
+// the expensive groups of a centrally condensed system end up in the dispatch order.
+constexpr unsigned XCD_CHUNK = 16;
+__device__ __forceinline__ unsigned xcd_map_block(unsigned b, unsigned nb, int mode)
+{
+    if (mode == 2) {
+        return b;
+    }
+    if (mode == 3 || mode == 4) {
+        const unsigned q = nb >> 3, r = nb & 7u, xcd = b & 7u, pos = b >> 3;
+        const unsigned len = xcd < r ? q + 1u : q, base = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+        const unsigned p = mode == 4 ? len - 1u - pos : ((pos & 1u) ? len - 1u - (pos >> 1) : (pos >> 1));
+        return base + p;
+    }
+    if (mode == 1) {
+        return xcd_chunked_block(b, nb);
+    }
+    // Blocks beyond the last full round of 8 chunks keep their identity mapping.
+    const unsigned span = 8u * XCD_CHUNK, full = nb - nb % span;
+    if (b >= full) {
+        return b;
+    }
+    const unsigned xcd = b & 7u, pos = b >> 3;
+    return (pos / XCD_CHUNK * 8u + xcd) * XCD_CHUNK + pos % XCD_CHUNK;
+}
+
+template <typename F, int Q, int R, bool SELF, int ND>
+__device__ __forceinline__ void lk_interact_src(const typename vt<F>::v4 &s, int j, const typename vt<F>::v4 (&tp)[R],
+                                                F (&acc)[R][nres_of(Q)], F eps2, const int (&tidx)[R])
+{
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const F ex = s.x - tp[r].x, ey = s.y - tp[r].y, ez = ND == 3 ? s.z - tp[r].z : F(0);
+        F e2 = rk_fma(ey, ey, rk_fma(ex, ex, eps2));
+        if constexpr (ND == 3) {
+            e2 = rk_fma(ez, ez, e2);
+        }
+        F ms = s.w;
+        if constexpr (SELF) {
+            const bool self = (j == tidx[r]);
+            e2 = self ? F(1) : e2;
+            ms = self ? F(0) : ms;
+        }
+        interact<F, Q, ND>(acc[r], ex, ey, ez, e2, ms, tp[r].w);
+    }
+}
+
+// Dense targets x sources evaluation of one LDS tile. The trip count of the main loop is uniform (full = n_src / ns,
+// computed by the caller); the n_src - full * ns sources left over at the end of the tile are one masked step when
+// `with_rem` is set, otherwise the caller carries them over to the next tile.
+template <typename F, int Q, int R, bool SELF, int ND>
+__device__ __forceinline__ void lk_eval_tile(const typename vt<F>::v4 *__restrict__ src, int n_src, int full, int sp,
+                                             int ns, bool with_rem, bool lane_on, const typename vt<F>::v4 (&tp)[R],
+                                             F (&acc)[R][nres_of(Q)], F eps2, const int (&tidx)[R])
+{
+    using v4 = typename vt<F>::v4;
+#ifdef RK_ABLATE_DENSE
+    return; // diagnostic build: list building only
+#endif
+    // Keep about four interactions in flight per lane whatever R is.
+    constexpr int UNR = R >= 4 ? RK_UNR4 : (R == 3 ? RK_UNR3 : (R == 2 ? RK_UNR2 : RK_UNR1));
+    static_assert(R <= 6);
+    const int rem = with_rem ? n_src - full * ns : 0;
+#if RK_CHUNKED_SPLITS
+    // Split sp owns the contiguous sources [sp * full, (sp + 1) * full): consecutive iterations read consecutive
+    // LDS slots (immediate offsets, no address arithmetic in the loop); the remainder sits at the end of the tile.
+    const v4 *p = src + sp * full;
+    int j = sp * full;
+#pragma unroll UNR
+    for (int it = 0; it < full; ++it) {
+        const v4 s = p[it];
+        lk_interact_src<F, Q, R, SELF, ND>(s, j + it, tp, acc, eps2, tidx);
+    }
+    if (lane_on && sp < rem) {
+        const v4 s = src[ns * full + sp];
+        lk_interact_src<F, Q, R, SELF, ND>(s, ns * full + sp, tp, acc, eps2, tidx);
+    }
+#else
+    const v4 *p = src + sp;
+    int j = sp;
+#pragma unroll UNR
+    for (int it = 0; it < full; ++it) {
+        const v4 s = *p;
+        lk_interact_src<F, Q, R, SELF, ND>(s, j, tp, acc, eps2, tidx);
+        p += ns;
+        j += ns;
+    }
+    if (lane_on && sp < rem) {
+        const v4 s = *p;
+        lk_interact_src<F, Q, R, SELF, ND>(s, j, tp, acc, eps2, tidx);
+    }
+#endif
+}
+
+} // namespace rk
+
+#endif

@@ -772,7 +772,11 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                     RK_HIP(hipStreamWaitEvent(s.aux_stream[i], s.ev_fork, 0));
                 }
             }
-            rk::launch_list<F>(s, q, p, cb, ce, streams);
+            if (s.variant == 3 || s.variant == 4) {
+                rk::launch_pc<F>(s, q, s.variant - 2, p, cb, ce, streams); // producer / consumer waves per group
+            } else {
+                rk::launch_list<F>(s, q, p, cb, ce, streams);
+            }
             if (!serial) {
                 for (int i = 0; i < rk::n_list_R - 1; ++i) {
                     RK_HIP(hipEventRecord(s.ev_join[i], s.aux_stream[i]));
@@ -790,7 +794,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
             // one hipGraphLaunch instead of ~20 runtime calls.
             rk_state::graph_key key{};
             key.q = q, key.p_begin = p_begin, key.p_end = p_end, key.mac_value = mac_value, key.G = G, key.eps2 = eps2;
-            key.offset_output = offset_output, key.super_k = s.super_k;
+            key.offset_output = offset_output, key.super_k = s.super_k, key.variant = s.variant;
             for (int k = 0; k < rk::nres_of(q); ++k) {
                 key.out[k] = d_out[k];
             }
@@ -1622,7 +1626,7 @@ int rk_device_memcpy(void *dst, const void *src, int64_t bytes, int device)
 int rk_set_kernel_variant(rk_state *s, int variant)
 {
     return guard([&] {
-        if (!s || variant < 0 || variant > 2) {
+        if (!s || variant < 0 || variant > 4) {
             throw rk::error(RK_EINVAL, "invalid kernel variant");
         }
         s->variant = variant;

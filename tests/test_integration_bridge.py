@@ -1,0 +1,52 @@
+"""integration/rakau_amd_bridge.cpp -- the reference's accelerator seam (include/rakau/detail/rocm_fwd.hpp:22-46)
+implemented on the rakau_amd C ABI -- compiled against the reference's own headers, with every instantiation of
+src/rakau_rocm.cpp:333-370 (NDim {2,3} x F {float,double} x UInt {32,64 bit} x MAC {bh,bh_geom} x Q {0,1,2}).
+Needs a checkout of the reference at /root/reference (only its HEADERS are read, at compile time; nothing of it enters
+this repository or travels to the GPU box). The GPU test runs the driver built here, if it was built."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_INC = "/root/reference/include"
+BUILD = os.path.join(ROOT, "tests", "build")
+LIB = os.path.join(BUILD, "librakau_rocm_bridge.so")
+DRIVER = os.path.join(BUILD, "bridge_driver")
+RK_LIBDIR = os.path.join(ROOT, "rakau_amd", "lib")
+
+
+def build():
+    os.makedirs(BUILD, exist_ok=True)
+    common = ["g++", "-std=c++17", "-O2", "-fPIC", "-Wall", "-Wextra", "-Wno-comment", "-I" + REF_INC, "-I" + os.path.join(ROOT, "include")]
+    subprocess.check_call(common + ["-shared", os.path.join(ROOT, "integration", "rakau_amd_bridge.cpp"), "-L" + RK_LIBDIR,
+                                    "-lrakau_amd", "-Wl,-rpath," + RK_LIBDIR, "-o", LIB])
+    subprocess.check_call(common + ["-pthread", os.path.join(ROOT, "tests", "cpp", "bridge_driver.cpp"), "-L" + BUILD, "-lrakau_rocm_bridge",
+                                    "-L" + RK_LIBDIR, "-lrakau_amd", "-Wl,-rpath," + BUILD, "-Wl,-rpath," + RK_LIBDIR, "-o", DRIVER])
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_INC), reason="no checkout of the reference: the bridge cannot be compiled")
+def test_bridge_compiles_against_the_reference_headers():
+    build()
+    syms = subprocess.run(["nm", "-DC", "--defined-only", LIB], capture_output=True, text=True, check=True).stdout
+    for f in ("rakau::detail::rocm_min_size()", "rakau::detail::rocm_has_accelerator()", "rakau::detail::rakau_amd_set_ncrit("):
+        assert f in syms
+    for nd in (2, 3):
+        for fp in ("float", "double"):
+            for ui in ("unsigned int", "unsigned long"):
+                for mac in ("0", "1"):
+                    cls = r"rakau::detail::rocm_state<%dul, %s, %s, \(rakau::mac\)%s>::" % (nd, fp, ui, mac)
+                    assert re.search(cls + r"rocm_state\(", syms) and re.search(cls + r"~rocm_state\(", syms), cls
+                    for q in (0, 1, 2):
+                        assert re.search(r"void " + cls + r"acc_pot<%du>\(" % q, syms), (cls, q)
+
+
+@pytest.mark.gpu
+def test_bridge_driver_on_gpu():
+    if not os.path.exists(DRIVER):
+        if not os.path.isdir(REF_INC):
+            pytest.skip("bridge driver not built (no checkout of the reference where this tree was built)")
+        build()
+    out = subprocess.run([DRIVER], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "bridge checks: 0 failure(s)" in out.stdout, out.stdout + out.stderr

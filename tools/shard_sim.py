@@ -9,6 +9,7 @@ import rakau_amd
 from bench import plummer_numpy, shard_cuts
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
+variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
 m, x, y, z = plummer_numpy(n, "float32")
 t = rakau_amd.Octree(x, y, z, m)
 st = t.state()
@@ -25,11 +26,13 @@ def time_range(b, e, reps=12):
         ms.append(st.last_kernel_ms())
     return float(np.median(ms[2:]))
 
-full = time_range(0, n)
-print("full range: %.3f ms" % full)
-for world in (2, 4, 8):
-    for name, w in (("particles", None), ("work", work)):
-        cuts = shard_cuts(crit, n, world, w)
-        ts = [time_range(cuts[r], cuts[r + 1]) for r in range(world)]
-        print("N=%d %-9s per-shard ms %s  max %.3f  ideal %.3f  efficiency %.2f" % (
-            world, name, " ".join("%.3f" % v for v in ts), max(ts), full / world, full / world / max(ts)))
+for variant in variants:
+    st.set_variant(variant)
+    full = time_range(0, n)
+    print("variant %d full range: %.3f ms" % (variant, full))
+    for world in (2, 4, 8):
+        for name, w in (("work", work),) if len(variants) > 1 else (("particles", None), ("work", work)):
+            cuts = shard_cuts(crit, n, world, w)
+            ts = [time_range(cuts[r], cuts[r + 1]) for r in range(world)]
+            print("variant %d N=%d %-9s per-shard ms %s  max %.3f  ideal %.3f  efficiency %.2f" % (
+                variant, world, name, " ".join("%.3f" % v for v in ts), max(ts), full / world, full / world / max(ts)))
