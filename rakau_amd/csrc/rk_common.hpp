@@ -213,12 +213,10 @@ struct rk_state {
     // Output scratch for rk_acc_pot (host outputs).
     void *d_out = nullptr;
     size_t d_out_bytes = 0;
-    // Host-output path of rk_acc_pot(): pinned staging buffer, copy stream and per-chunk events (device-to-host
-    // chunks overlap the copies into the caller's pageable arrays).
+    // Host-output path of rk_acc_pot(): pinned staging buffer the kernels write into directly (host memory mapped into
+    // the device's address space), delivered to the caller's pageable arrays by host threads.
     void *h_stage = nullptr;
     size_t h_stage_bytes = 0;
-    hipStream_t copy_stream = nullptr;
-    hipEvent_t copy_ev[16] = {};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // Side streams (and fork/join events) that let the per-class kernels of one call overlap.
     hipStream_t aux_stream[rk::n_list_R] = {};
@@ -238,6 +236,22 @@ struct rk_state {
     hipStream_t cap_stream = nullptr;
     bool timed = false;
     int variant = 0;
+    // Group lists the class kernels of the current call read: the state's lists (ascending critical nodes per class,
+    // RK_BUF_CLASS + class2_off) or a launch plan.
+    const uint32_t *cur_lists = nullptr;
+    int64_t cur_off[rk::n_classes + 1] = {};
+    // Launch plan of a repeated small call: the critical nodes of the range, per class, reordered so that the most
+    // expensive supergroups are dispatched first (a launch with only a few rounds of waves otherwise ends in a long,
+    // badly occupied tail of expensive groups that started late). Results do not depend on the dispatch order.
+    struct launch_plan {
+        int64_t p_begin = -1, p_end = -1;
+        double mac_value = 0.;
+        void *d_lists = nullptr;
+        int64_t alloc = 0; // entries allocated
+        int64_t off[rk::n_classes + 1] = {};
+    } plan;
+    std::vector<uint64_t> work_cache; // rk_group_work() of the whole tree at work_mac_value (empty: not computed)
+    double work_mac_value = 0.;
     // Scratch of the supergroup pre-pass (allocated on first use).
     void *sup_common = nullptr, *sup_resid = nullptr, *sup_cnt = nullptr;
     int64_t sup_alloc = 0; // number of supergroups the scratch was sized for

@@ -702,7 +702,7 @@ template <typename F, int Q, int MAC>
 static void launch_list_qm(const rk_state &s, const kparams<F> &p, const int64_t cb[n_classes],
                            const int64_t ce[n_classes], hipStream_t const streams[n_list_R])
 {
-    const auto *lists = static_cast<const uint32_t *>(s.buf[RK_BUF_CLASS]);
+    const auto *lists = s.cur_lists; // class lists of the state, or the launch plan of this call
     auto go = [&](auto Rtag, int c) {
         constexpr int R = decltype(Rtag)::value;
         const int64_t n = ce[c] - cb[c];
@@ -712,11 +712,11 @@ static void launch_list_qm(const rk_state &s, const kparams<F> &p, const int64_t
         const auto grid = static_cast<unsigned>((n + RK_WPB - 1) / RK_WPB);
         if (s.ndim == 3 || !RK_QUAD_BODY) {
             hipLaunchKernelGGL((k_list<F, Q, MAC, R, 3>), dim3(grid), dim3(64 * RK_WPB), 0, streams[c], p,
-                               lists + s.class2_off[c] + cb[c], static_cast<int>(n));
+                               lists + s.cur_off[c] + cb[c], static_cast<int>(n));
         } else if constexpr (R <= RK_MAX_R) {
             // Quadtrees: the same kernel without the z terms of the interaction (10 instead of 13 operations).
             hipLaunchKernelGGL((k_list<F, Q, MAC, R, 2>), dim3(grid), dim3(64 * RK_WPB), 0, streams[c], p,
-                               lists + s.class2_off[c] + cb[c], static_cast<int>(n));
+                               lists + s.cur_off[c] + cb[c], static_cast<int>(n));
         } else {
             throw error(RK_ERUNTIME, "internal error: quadtree group in a lane-mapping class beyond RK_MAX_R");
         }

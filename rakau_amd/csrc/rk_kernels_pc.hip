@@ -313,12 +313,12 @@ __global__ void __launch_bounds__(64 * (1 + KC), (sizeof(F) == 4 ? (R <= 2 ? RK_
             // store. Written out by hand: as an array the eight records end up in scratch memory in this kernel.
             const uint32_t lbase = mycnt ? lf.x : 0u, llast = mycnt ? mycnt - 1u : 0u;
             for (unsigned j0 = 0; __builtin_amdgcn_ballot_w64(j0 < mycnt) != 0ull; j0 += 8u) {
-#define RK_PC_LD(u) const v4 t##u = P.part4[lbase + (j0 + u##u < llast ? j0 + u##u : llast)];
+#define RK_PC_LD(i) const v4 t##i = P.part4[lbase + (j0 + i##u < llast ? j0 + i##u : llast)];
                 RK_PC_LD(0) RK_PC_LD(1) RK_PC_LD(2) RK_PC_LD(3) RK_PC_LD(4) RK_PC_LD(5) RK_PC_LD(6) RK_PC_LD(7)
 #undef RK_PC_LD
-#define RK_PC_ST(u)                                                                                                    \
-    if (j0 + u##u < mycnt) {                                                                                           \
-        src[dst + static_cast<int>(j0 + u##u)] = t##u;                                                                 \
+#define RK_PC_ST(i)                                                                                                    \
+    if (j0 + i##u < mycnt) {                                                                                           \
+        src[dst + static_cast<int>(j0 + i##u)] = t##i;                                                                 \
     }
                 RK_PC_ST(0) RK_PC_ST(1) RK_PC_ST(2) RK_PC_ST(3) RK_PC_ST(4) RK_PC_ST(5) RK_PC_ST(6) RK_PC_ST(7)
 #undef RK_PC_ST
@@ -573,7 +573,7 @@ template <typename F, int Q, int MAC, int KC>
 static void launch_pc_qm(const rk_state &s, const kparams<F> &p, const int64_t cb[n_classes], const int64_t ce[n_classes],
                          hipStream_t const streams[n_list_R])
 {
-    const auto *lists = static_cast<const uint32_t *>(s.buf[RK_BUF_CLASS]);
+    const auto *lists = s.cur_lists; // class lists of the state, or the launch plan of this call
     auto go = [&](auto Rtag, int c) {
         constexpr int R = decltype(Rtag)::value;
         const int64_t n = ce[c] - cb[c];
@@ -583,10 +583,10 @@ static void launch_pc_qm(const rk_state &s, const kparams<F> &p, const int64_t c
         const auto grid = static_cast<unsigned>(n);
         if (s.ndim == 3 || !RK_QUAD_BODY) {
             hipLaunchKernelGGL((k_pc<F, Q, MAC, R, 3, KC>), dim3(grid), dim3(64 * (1 + KC)), 0, streams[c], p,
-                               lists + s.class2_off[c] + cb[c], static_cast<int>(n));
+                               lists + s.cur_off[c] + cb[c], static_cast<int>(n));
         } else {
             hipLaunchKernelGGL((k_pc<F, Q, MAC, R, 2, KC>), dim3(grid), dim3(64 * (1 + KC)), 0, streams[c], p,
-                               lists + s.class2_off[c] + cb[c], static_cast<int>(n));
+                               lists + s.cur_off[c] + cb[c], static_cast<int>(n));
         }
     };
     static_assert(RK_MAX_R == 4, "the producer / consumer kernel is instantiated for R = 1..4");

@@ -75,10 +75,12 @@ void release_tree(rk_state *s)
         s->buf[i] = nullptr;
         s->buf_bytes[i] = 0;
     }
-    for (void **b : {&s->bld_codes, &s->bld_perm, &s->bld_node_code}) {
+    for (void **b : {&s->bld_codes, &s->bld_perm, &s->bld_node_code, &s->plan.d_lists}) {
         rk::pool_free(*b);
         *b = nullptr;
     }
+    s->plan = rk_state::launch_plan{};
+    s->work_cache.clear();
     if (s->graph_exec) {
         (void)hipGraphExecDestroy(s->graph_exec);
         s->graph_exec = nullptr;
@@ -100,12 +102,6 @@ void free_state(rk_state *s)
     }
     if (s->h_stage) {
         (void)hipHostFree(s->h_stage);
-    }
-    if (s->copy_stream) {
-        (void)hipStreamDestroy(s->copy_stream);
-        for (auto &e : s->copy_ev) {
-            (void)hipEventDestroy(e);
-        }
     }
     if (s->ev0) {
         (void)hipEventDestroy(s->ev0);
@@ -609,6 +605,68 @@ void census_impl(rk_state &s, int64_t p_begin, int64_t p_end, double mac_value, 
     }
 }
 
+// Launch plan for the critical nodes [g_lo, g_hi): per class, the nodes of the range with their supergroups (runs of
+// super_k consecutive nodes: spatially compact, they share the pre-pass lists) sorted by decreasing mean traversal work.
+// The work is the integer census of rk_group_work() (computed once per tree and MAC value).
+template <typename F>
+void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64_t g_hi, double mac_value)
+{
+    ensure_mirrors(s);
+    if (s.work_cache.empty() || s.work_mac_value != mac_value) {
+        s.work_cache.assign(static_cast<size_t>(s.n_crit), 0);
+        uint64_t counts[4];
+        census_impl<F>(s, 0, s.nparts, mac_value, counts, s.work_cache.data());
+        s.work_mac_value = mac_value;
+    }
+    const int64_t K = s.super_k > 0 ? s.super_k : 16;
+    std::vector<uint32_t> lists;
+    lists.reserve(static_cast<size_t>(g_hi - g_lo));
+    struct run {
+        double mean;
+        uint32_t begin, end; // positions in `ids`
+    };
+    for (int c = 0; c < rk::n_classes; ++c) {
+        s.plan.off[c] = static_cast<int64_t>(lists.size());
+        if (c == rk::big_class) {
+            continue; // served by the block-per-group kernel from the state's own list
+        }
+        const auto &l = s.class2_list[c];
+        const auto b = std::lower_bound(l.begin(), l.end(), static_cast<uint32_t>(g_lo));
+        const auto e = std::lower_bound(l.begin(), l.end(), static_cast<uint32_t>(g_hi));
+        const std::vector<uint32_t> ids(b, e);
+        std::vector<run> runs;
+        for (size_t i = 0; i < ids.size();) {
+            size_t j = i;
+            double sum = 0.;
+            while (j < ids.size() && ids[j] / K == ids[i] / K) {
+                sum += static_cast<double>(s.work_cache[ids[j]]);
+                ++j;
+            }
+            runs.push_back(run{sum / static_cast<double>(j - i), static_cast<uint32_t>(i), static_cast<uint32_t>(j)});
+            i = j;
+        }
+        std::stable_sort(runs.begin(), runs.end(), [](const run &a, const run &b2) { return a.mean > b2.mean; });
+        for (const auto &r : runs) {
+            lists.insert(lists.end(), ids.begin() + r.begin, ids.begin() + r.end);
+        }
+    }
+    s.plan.off[rk::n_classes] = static_cast<int64_t>(lists.size());
+    if (s.plan.alloc < static_cast<int64_t>(lists.size())) {
+        RK_HIP(hipDeviceSynchronize());
+        rk::pool_free(s.plan.d_lists);
+        s.plan.d_lists = nullptr;
+        s.plan.alloc = 0;
+        s.plan.d_lists = rk::pool_alloc(std::max<size_t>(lists.size(), 1) * sizeof(uint32_t));
+        s.plan.alloc = static_cast<int64_t>(lists.size());
+    } else {
+        RK_HIP(hipDeviceSynchronize()); // a previous call may still be reading the old plan
+    }
+    if (!lists.empty()) {
+        RK_HIP(hipMemcpy(s.plan.d_lists, lists.data(), lists.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    s.plan.p_begin = p_begin, s.plan.p_end = p_end, s.plan.mac_value = mac_value;
+}
+
 template <typename F>
 void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d_out, double mac_value, double G,
               double eps2, int offset_output, hipStream_t stream)
@@ -755,6 +813,40 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
             const char *e = std::getenv("RK_GRAPH"); // 0 disables the hipGraph replay of a repeated call
             return !(e && std::atoi(e) == 0);
         }();
+        // Default group lists: the state's own (ascending critical nodes per class).
+        s.cur_lists = static_cast<const uint32_t *>(s.buf[RK_BUF_CLASS]);
+        std::copy(s.class2_off, s.class2_off + rk::n_classes + 1, s.cur_off);
+        const int64_t big_b = cb[rk::big_class], big_e = ce[rk::big_class];
+        {
+            // RK_PLAN: 0 = never reorder, 1 = reorder repeated calls with few critical nodes (default), 2 = always.
+            static const int plan_mode = [] {
+                const char *e = std::getenv("RK_PLAN");
+                return e ? std::atoi(e) : 1;
+            }();
+            static const int64_t plan_max_groups = [] {
+                const char *e = std::getenv("RK_PLAN_MAX_GROUPS");
+                return e ? std::atoll(e) : int64_t(30000);
+            }();
+            const bool cached = s.plan.d_lists && s.plan.p_begin == p_begin && s.plan.p_end == p_end
+                                && s.plan.mac_value == mac_value;
+            const bool repeats = s.have_last_key && s.last_key.p_begin == p_begin && s.last_key.p_end == p_end
+                                 && s.last_key.mac_value == mac_value;
+            const bool want = g_hi > g_lo
+                              && (plan_mode == 2 || (plan_mode == 1 && g_hi - g_lo <= plan_max_groups && (cached || repeats)));
+            if (want) {
+                if (!cached) {
+                    build_plan<F>(s, p_begin, p_end, g_lo, g_hi, mac_value);
+                }
+                s.cur_lists = static_cast<const uint32_t *>(s.plan.d_lists);
+                std::copy(s.plan.off, s.plan.off + rk::n_classes + 1, s.cur_off);
+                for (int c = 0; c < rk::n_classes; ++c) {
+                    cb[c] = 0;
+                    ce[c] = s.plan.off[c + 1] - s.plan.off[c];
+                }
+                // Heavy-first order: deal chunks of consecutive list entries round-robin to the XCDs.
+                p.xcd_mode = 0;
+            }
+        }
         // The launch sequence of one call: pre-pass, then the per-class kernels forked onto side streams (so that
         // the tail of one overlaps the others), joined back, then the big-group fallback. Stream-ordered work only,
         // so it can be recorded into a hipGraph.
@@ -785,9 +877,8 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
             }
             // Groups too large for the wave kernels are served by the block-per-group kernel.
             rk::launch_block<F>(s, q, p,
-                                static_cast<const uint32_t *>(s.buf[RK_BUF_CLASS]) + s.class2_off[rk::big_class]
-                                    + cb[rk::big_class],
-                                ce[rk::big_class] - cb[rk::big_class], st);
+                                static_cast<const uint32_t *>(s.buf[RK_BUF_CLASS]) + s.class2_off[rk::big_class] + big_b,
+                                big_e - big_b, st);
         };
         if (use_graph) {
             // A call that repeats the previous one (same range, outputs, parameters) replays a captured graph:
@@ -1058,25 +1149,31 @@ int rk_acc_pot(rk_state *s, int q, int64_t p_begin, int64_t p_end, void *const *
         for (int k = 0; k < nres; ++k) {
             d_ptrs[k] = static_cast<unsigned char *>(s->d_out) + static_cast<size_t>(k) * count * fsz;
         }
-        if (s->fp == RK_F32) {
-            run_impl<float>(*s, q, p_begin, p_end, d_ptrs, mac_value, G, eps2, 0, nullptr);
-        } else {
-            run_impl<double>(*s, q, p_begin, p_end, d_ptrs, mac_value, G, eps2, 0, nullptr);
-        }
         unsigned char *dst[4] = {};
         for (int k = 0; k < nres; ++k) {
             dst[k] = static_cast<unsigned char *>(out[k]) + (offset_output ? static_cast<size_t>(p_begin) * fsz : 0);
         }
         if (need < (size_t(1) << 20)) {
+            if (s->fp == RK_F32) {
+                run_impl<float>(*s, q, p_begin, p_end, d_ptrs, mac_value, G, eps2, 0, nullptr);
+            } else {
+                run_impl<double>(*s, q, p_begin, p_end, d_ptrs, mac_value, G, eps2, 0, nullptr);
+            }
             for (int k = 0; k < nres; ++k) {
                 RK_HIP(hipMemcpy(dst[k], d_ptrs[k], count * fsz, hipMemcpyDeviceToHost));
             }
             return;
         }
-        // Large results: device -> pinned staging in chunks on a copy stream, while host threads move finished chunks
-        // into the caller's (pageable) arrays. A plain hipMemcpy into pageable memory runs at ~7 GB/s.
+        // Large results: the kernels write straight into a pinned staging buffer (host memory mapped into the device's
+        // address space: posted PCIe writes that trickle out while the traversal computes -- 48 MB during a 2.3 ms kernel
+        // at 4M particles), so nothing is left to transfer when the kernels end; host threads then move the staging
+        // buffer into the caller's pageable arrays. Measured at 4M fp32 (ms per call, 2.3 ms of it the kernels): a plain
+        // hipMemcpy into pageable memory afterwards 6.4, device -> pinned chunks + threaded delivery after the kernels
+        // 4.2, the same with the traversal launched in 4 Morton chunks so that the copies overlap it 4.3 (four small
+        // launches lose what the overlap wins), this 3.1 (profiles/r02/host_output_path.txt).
         if (s->h_stage_bytes < need) {
             if (s->h_stage) {
+                RK_HIP(hipDeviceSynchronize());
                 RK_HIP(hipHostFree(s->h_stage));
                 s->h_stage = nullptr;
                 s->h_stage_bytes = 0;
@@ -1084,56 +1181,50 @@ int rk_acc_pot(rk_state *s, int q, int64_t p_begin, int64_t p_end, void *const *
             RK_HIP(hipHostMalloc(&s->h_stage, need, hipHostMallocDefault));
             s->h_stage_bytes = need;
         }
-        constexpr int max_chunks = 16;
-        if (!s->copy_stream) {
-            RK_HIP(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
-            for (auto &e : s->copy_ev) {
-                RK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            }
+        void *h_ptrs[4] = {};
+        for (int k = 0; k < nres; ++k) {
+            h_ptrs[k] = static_cast<unsigned char *>(s->h_stage) + static_cast<size_t>(k) * count * fsz;
         }
-        // The kernels were enqueued on the null stream; the copy stream waits for them through the timing event.
-        RK_HIP(hipStreamWaitEvent(s->copy_stream, s->ev1, 0));
-        const size_t chunk = std::max<size_t>(size_t(4) << 20, (need + max_chunks - 1) / max_chunks);
-        const int n_chunks = static_cast<int>((need + chunk - 1) / chunk);
-        auto *stage = static_cast<unsigned char *>(s->h_stage);
-        const auto *dev = static_cast<const unsigned char *>(s->d_out);
-        for (int c = 0; c < n_chunks; ++c) {
-            const size_t off = static_cast<size_t>(c) * chunk, len = std::min(chunk, need - off);
-            RK_HIP(hipMemcpyAsync(stage + off, dev + off, len, hipMemcpyDeviceToHost, s->copy_stream));
-            RK_HIP(hipEventRecord(s->copy_ev[c], s->copy_stream));
+        if (s->fp == RK_F32) {
+            run_impl<float>(*s, q, p_begin, p_end, h_ptrs, mac_value, G, eps2, 0, nullptr);
+        } else {
+            run_impl<double>(*s, q, p_begin, p_end, h_ptrs, mac_value, G, eps2, 0, nullptr);
         }
-        // The staging buffer holds the nres arrays back to back (count * fsz bytes each): map a byte range to them.
-        const size_t arr = count * fsz;
-        auto deliver = [&](size_t off, size_t len) {
-            while (len) {
-                const size_t k = off / arr, in = off % arr, n = std::min(len, arr - in);
-                std::memcpy(dst[k] + in, stage + off, n);
-                off += n;
-                len -= n;
-            }
-        };
-        const int n_thr = std::max(1, std::min<int>(4, std::min<int>(n_chunks, static_cast<int>(std::thread::hardware_concurrency()))));
-        std::atomic<int> failed{0};
-        auto worker = [&](int tid) {
-            for (int c = tid; c < n_chunks; c += n_thr) {
-                if (hipEventSynchronize(s->copy_ev[c]) != hipSuccess) {
-                    failed = 1;
+        RK_HIP(hipEventSynchronize(s->ev1));
+        const auto *stage = static_cast<const unsigned char *>(s->h_stage);
+        const size_t piece = size_t(2) << 20;
+        const int n_items = static_cast<int>((need + piece - 1) / piece);
+        static const int max_thr = [] {
+            const char *e = std::getenv("RK_HOST_THREADS"); // delivery threads (default 8; memory-bound beyond that)
+            const int v = e ? std::atoi(e) : 8;
+            return v < 1 ? 1 : v;
+        }();
+        const int n_thr = std::max(1, std::min<int>({max_thr, n_items, static_cast<int>(std::thread::hardware_concurrency())}));
+        std::atomic<int> next{0};
+        auto worker = [&]() {
+            for (;;) {
+                const int item = next.fetch_add(1);
+                if (item >= n_items) {
                     return;
                 }
-                const size_t off = static_cast<size_t>(c) * chunk;
-                deliver(off, std::min(chunk, need - off));
+                // A byte range of the staging buffer (the nres arrays back to back) -> the caller's arrays.
+                size_t off = static_cast<size_t>(item) * piece, len = std::min(piece, need - off);
+                const size_t arr = count * fsz;
+                while (len) {
+                    const size_t k = off / arr, in = off % arr, nb = std::min(len, arr - in);
+                    std::memcpy(dst[k] + in, stage + off, nb);
+                    off += nb;
+                    len -= nb;
+                }
             }
         };
         std::vector<std::thread> thr;
         for (int t = 1; t < n_thr; ++t) {
-            thr.emplace_back(worker, t);
+            thr.emplace_back(worker);
         }
-        worker(0);
+        worker();
         for (auto &t : thr) {
             t.join();
-        }
-        if (failed) {
-            throw rk::error(RK_ERUNTIME, "device-to-host copy of the results failed");
         }
     });
 }

@@ -1,0 +1,13 @@
+#!/bin/bash
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/r02_job7
+mkdir -p $OUT
+cd $ROOT
+for cfg in "RK_HOST_DIRECT=1 RK_HOST_THREADS=4" "RK_HOST_DIRECT=1 RK_HOST_THREADS=8" "RK_HOST_DIRECT=1 RK_HOST_THREADS=16" "RK_HOST_DIRECT=0 RK_HOST_CHUNKS=1"; do
+  echo "== $cfg"; env $cfg timeout 300 python3 tools/host_timing.py 2>&1 | grep "^call" | tr '\n' ' '; echo
+  env $cfg timeout 300 python3 bench.py --no-cpu-baseline 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench: value', d['value'], 'kernel_ms', d['kernel_ms'], 'host outputs', d.get('value_host_outputs'), d.get('ms_per_call_host_outputs'))"
+done
+( timeout 900 python3 -m pytest tests/test_gpu_full_size.py tests/test_gpu_reference_tests.py tests/test_gpu_parity_basic.py -m gpu -x -q ) > $OUT/pytest.log 2>&1; tail -3 $OUT/pytest.log
