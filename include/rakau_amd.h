@@ -21,7 +21,8 @@
  * The remaining entry points have no counterpart in the reference's seam; they serve the callers either side of it
  *  and the measurements:
  *   device-resident outputs      rk_acc_pot_device (+ RK_OUT_ORDERED = the accs_o/pots_o scatter, tree.hpp:3320-3330)
- *   multi-GPU replication        rk_state_export / rk_state_import / rk_device_memcpy (RCCL broadcast of the exported
+ *   multi-GPU replication        rk_state_clone (one process, peer copies over xGMI),
+ *                                rk_state_export / rk_state_import / rk_device_memcpy (RCCL broadcast of the exported
  *                                buffers: the replacement of the reference's multi-GPU split, src/rakau_cuda.cu:410-527),
  *                                rk_state_crit_ranges, rk_group_work (where to cut)
  *   tree construction on the GPU rk_state_build / _build_device / _build_nd / rk_state_rebuild_device (the constructor
@@ -73,7 +74,8 @@ RK_EXPORT const char *rk_last_error(void);
 RK_EXPORT unsigned rk_min_size(void);
 /* 1 if at least one gfx950 device is visible. Never throws. */
 RK_EXPORT int rk_has_accelerator(void);
-/* Number of visible HIP devices (0 on failure). */
+/* Number of visible HIP devices (0 on failure). Test knob: RK_ALIAS_DEVICES=<n> makes the library report n LOGICAL
+ * devices mapped round-robin onto the physical ones, so that multi-device host logic can run on a 1-GPU box. */
 RK_EXPORT int rk_device_count(void);
 
 /*
@@ -169,6 +171,11 @@ RK_EXPORT int rk_last_kernel_ms(rk_state *s, float *ms);
 RK_EXPORT int rk_state_export(const rk_state *s, int *count, void **ptrs, int64_t *bytes, int64_t meta[RK_META_WORDS]);
 RK_EXPORT int rk_state_import(rk_state **out, int device, int count, void *const *ptrs, const int64_t *bytes,
                               const int64_t meta[RK_META_WORDS]);
+/* Replica of `src` on another device of THIS process (the reference's multi-GPU host code drives all devices from one
+ * process, src/rakau_cuda.cu:410-527): every buffer travels device to device -- a peer copy over xGMI between two
+ * GPUs -- instead of being converted and uploaded from host memory again. The C++ header replicates the state of
+ * device 0 this way for kwargs::split = {cpu, dev0, dev1, ...}. */
+RK_EXPORT int rk_state_clone(rk_state **out, const rk_state *src, int device);
 
 /*
  * Device-side tree construction: what rakau::tree's constructor does on the

@@ -1274,6 +1274,12 @@ private:
             m_dev.resize(static_cast<std::size_t>(device) + 1u);
         }
         auto &d = m_dev[static_cast<std::size_t>(device)];
+        if (!d.h && device != 0 && m_dev[0].h) {
+            // Further devices get a replica of device 0's state: buffers travel device to device (xGMI peer copies)
+            // instead of being converted and uploaded from host memory once more (the reference re-uploads everything
+            // to every device on every call, src/rakau_cuda.cu:410-527).
+            throw_status(rk_state_clone(&d.h, m_dev[0].h, device));
+        }
         if (!d.h) {
             const void *parts[4] = {};
             for (std::size_t j = 0; j < NDim + 1u; ++j) {
@@ -1431,6 +1437,9 @@ private:
         if (!cpu_share && n_dev == 1u) {
             run_one(0, cuts[1], cuts[2]); // the common case: no thread
             return;
+        }
+        if (n_dev > 1u) {
+            device_state_for(0); // the other devices replicate it (rk_state_clone) instead of uploading from the host
         }
         std::vector<std::future<void>> futs;
         // Device 0 gets a thread of its own only if this thread is busy with the CPU share.

@@ -23,7 +23,7 @@ _EXC = {1: ValueError, 2: ArithmeticError, 3: OverflowError, 4: RuntimeError, 5:
 SYMBOLS = [
     "rk_last_error", "rk_min_size", "rk_has_accelerator", "rk_device_count", "rk_state_create", "rk_state_destroy",
     "rk_state_info", "rk_state_crit_ranges", "rk_acc_pot", "rk_acc_pot_device", "rk_last_kernel_ms", "rk_state_export",
-    "rk_state_import", "rk_set_kernel_variant", "rk_device_memcpy", "rk_count_interactions", "rk_state_build",
+    "rk_state_import", "rk_state_clone", "rk_set_kernel_variant", "rk_device_memcpy", "rk_count_interactions", "rk_state_build",
     "rk_state_tree_info", "rk_state_download", "rk_state_build_device", "rk_state_set_perm", "rk_state_device_ptr",
     "rk_state_rebuild_device", "rk_pool_trim", "rk_group_work", "rk_state_create_nd", "rk_state_build_nd",
     "rk_state_ndim",
@@ -82,6 +82,7 @@ def lib():
     L.rk_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.rk_state_export.argtypes = [vp, C.POINTER(ci), C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)]
     L.rk_state_import.argtypes = [C.POINTER(vp), ci, ci, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)]
+    L.rk_state_clone.argtypes = [C.POINTER(vp), vp, ci]
     L.rk_set_kernel_variant.argtypes = [vp, ci]
     L.rk_device_memcpy.argtypes = [vp, vp, i64, ci]
     L.rk_count_interactions.argtypes = [vp, i64, i64, dbl, C.POINTER(u64)]

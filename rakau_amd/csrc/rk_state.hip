@@ -39,15 +39,47 @@ int guard(Fn &&f) noexcept
     }
 }
 
+// Device ordinals of the C ABI are LOGICAL. Normally logical == physical. RK_ALIAS_DEVICES=<n> (a test knob) makes the
+// library report n devices and maps logical device d onto physical device d % (physical count): the multi-device host
+// logic of the callers (one state and one host thread per device, replication, range cuts) then runs on a box with a
+// single GPU. Speed is meaningless in that mode; results are not affected.
+int physical_device_count()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 0) {
+        return 0;
+    }
+    return n;
+}
+int alias_devices()
+{
+    static const int n = [] {
+        const char *e = std::getenv("RK_ALIAS_DEVICES");
+        const int v = e ? std::atoi(e) : 0;
+        return v > 0 ? (v > 64 ? 64 : v) : 0;
+    }();
+    return n;
+}
+int logical_device_count()
+{
+    const int real = physical_device_count();
+    return (real > 0 && alias_devices() > 0) ? alias_devices() : real;
+}
+int phys(int device)
+{
+    const int real = physical_device_count();
+    return (real > 0 && alias_devices() > 0) ? device % real : device;
+}
+
 struct device_guard {
     int prev = 0;
     explicit device_guard(int dev)
     {
         RK_HIP(hipGetDevice(&prev));
-        if (prev != dev) {
-            RK_HIP(hipSetDevice(dev));
+        cur = phys(dev);
+        if (prev != cur) {
+            RK_HIP(hipSetDevice(cur));
         }
-        cur = dev;
     }
     ~device_guard()
     {
@@ -95,7 +127,7 @@ void free_state(rk_state *s)
     }
     int prev = 0;
     (void)hipGetDevice(&prev);
-    (void)hipSetDevice(s->device);
+    (void)hipSetDevice(phys(s->device));
     release_tree(s);
     for (void *b : {s->d_out, s->sup_common, s->sup_resid, s->sup_cnt, s->z_scratch}) {
         rk::pool_free(b);
@@ -514,8 +546,8 @@ void check_ndim(int ndim)
 
 void check_device(int device)
 {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    const int n = logical_device_count();
+    if (n <= 0) {
         throw rk::error(RK_ERUNTIME, "no HIP device is available: the rakau_amd engine needs a gfx950 GPU");
     }
     if (device < 0 || device >= n) {
@@ -864,8 +896,16 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                     RK_HIP(hipStreamWaitEvent(s.aux_stream[i], s.ev_fork, 0));
                 }
             }
-            if (s.variant == 3 || s.variant == 4) {
-                rk::launch_pc<F>(s, q, s.variant - 2, p, cb, ce, streams); // producer / consumer waves per group
+            // Variant 0 (automatic): trees with few critical nodes cannot fill the device with one wave per node; they
+            // get the producer + two consumers kernel (three waves per node, shorter serial chain per node). The choice
+            // depends on the TREE only (never on the range of the call), so every call on a state sums in the same order.
+            static const int64_t pc_max_crit = [] {
+                const char *e = std::getenv("RK_PC_MAX_CRIT");
+                return e ? std::atoll(e) : int64_t(10000);
+            }();
+            const int kc = s.variant == 3 ? 1 : ((s.variant == 4 || (s.variant == 0 && s.n_crit <= pc_max_crit)) ? 2 : 0);
+            if (kc) {
+                rk::launch_pc<F>(s, q, kc, p, cb, ce, streams); // producer / consumer waves per group
             } else {
                 rk::launch_list<F>(s, q, p, cb, ce, streams);
             }
@@ -987,16 +1027,12 @@ unsigned rk_min_size(void)
 
 int rk_device_count(void)
 {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) {
-        return 0;
-    }
-    return n;
+    return logical_device_count();
 }
 
 int rk_has_accelerator(void)
 {
-    const int n = rk_device_count();
+    const int n = physical_device_count();
     for (int i = 0; i < n; ++i) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, i) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) {
@@ -1281,10 +1317,19 @@ int rk_state_export(const rk_state *s, int *count, void **ptrs, int64_t *bytes, 
     });
 }
 
-int rk_state_import(rk_state **out, int device, int count, void *const *ptrs, const int64_t *bytes,
-                    const int64_t meta[RK_META_WORDS])
+// Shared by rk_state_import (buffers already on `device`: src_device < 0) and rk_state_clone (buffers on src_device).
+static int import_impl(rk_state **out, int device, int count, void *const *ptrs, const int64_t *bytes,
+                       const int64_t meta[RK_META_WORDS], int src_device)
 {
     return guard([&] {
+        // Device-to-device on one GPU, or a peer copy over xGMI between two GPUs of this process.
+        const auto copy_in = [&](void *dst, const void *src, size_t n) {
+            if (src_device < 0 || phys(src_device) == phys(device)) {
+                RK_HIP(hipMemcpy(dst, src, n, hipMemcpyDeviceToDevice));
+            } else {
+                RK_HIP(hipMemcpyPeer(dst, phys(device), src, phys(src_device), n));
+            }
+        };
         if (!out || !ptrs || !bytes || !meta) {
             throw rk::error(RK_EINVAL, "null argument");
         }
@@ -1340,7 +1385,7 @@ int rk_state_import(rk_state **out, int device, int count, void *const *ptrs, co
                     throw rk::error(RK_EINVAL, "null buffer in rk_state_import");
                 }
                 s->buf[i] = rk::pool_alloc(static_cast<size_t>(bytes[i]));
-                RK_HIP(hipMemcpy(s->buf[i], ptrs[i], static_cast<size_t>(bytes[i]), hipMemcpyDeviceToDevice));
+                copy_in(s->buf[i], ptrs[i], static_cast<size_t>(bytes[i]));
             }
         }
         if (bytes[RK_NBUF]) {
@@ -1349,7 +1394,7 @@ int rk_state_import(rk_state **out, int device, int count, void *const *ptrs, co
                 throw rk::error(RK_EINVAL, "null buffer in rk_state_import");
             }
             s->bld_perm = rk::pool_alloc(static_cast<size_t>(bytes[RK_NBUF]));
-            RK_HIP(hipMemcpy(s->bld_perm, ptrs[RK_NBUF], static_cast<size_t>(bytes[RK_NBUF]), hipMemcpyDeviceToDevice));
+            copy_in(s->bld_perm, ptrs[RK_NBUF], static_cast<size_t>(bytes[RK_NBUF]));
         }
         std::vector<uint4> crit(static_cast<size_t>(meta[5]));
         if (!crit.empty()) {
@@ -1361,6 +1406,37 @@ int rk_state_import(rk_state **out, int device, int count, void *const *ptrs, co
         build_host_mirrors(*s, crit);
         *out = s.release();
     });
+}
+
+int rk_state_import(rk_state **out, int device, int count, void *const *ptrs, const int64_t *bytes,
+                    const int64_t meta[RK_META_WORDS])
+{
+    return import_impl(out, device, count, ptrs, bytes, meta, -1);
+}
+
+int rk_state_clone(rk_state **out, const rk_state *src, int device)
+{
+    if (!out || !src) {
+        return guard([] { throw rk::error(RK_EINVAL, "null argument"); });
+    }
+    int count = 0;
+    void *ptrs[RK_MAX_BUFFERS] = {};
+    int64_t bytes[RK_MAX_BUFFERS] = {}, meta[RK_META_WORDS] = {};
+    const int rc = rk_state_export(src, &count, ptrs, bytes, meta);
+    if (rc != RK_OK) {
+        return rc;
+    }
+    {
+        // Everything the source has enqueued (its build, an upload) must have landed before its buffers are read.
+        const int rc2 = guard([&] {
+            device_guard dg(src->device);
+            RK_HIP(hipDeviceSynchronize());
+        });
+        if (rc2 != RK_OK) {
+            return rc2;
+        }
+    }
+    return import_impl(out, device, count, ptrs, bytes, meta, src->device);
 }
 
 // Run the device build into `s` (fp, mac, device, ncrit, max_leaf_n already set; no tree buffers held).

@@ -228,6 +228,12 @@ class State:
         n = cnt.value
         return [ptrs[i] or 0 for i in range(n)], [int(nbytes[i]) for i in range(n)], [int(v) for v in meta]
 
+    def clone(self, device):
+        """rk_state_clone: replica on another device of this process (device-to-device / xGMI peer copies)."""
+        h = C.c_void_p()
+        _capi.check(_capi.lib().rk_state_clone(C.byref(h), self._h, device))
+        return State._from_handle(h, self.dtype, self.mac)
+
     @classmethod
     def from_buffers(cls, device, ptrs, nbytes, meta):
         h = C.c_void_p()
