@@ -27,7 +27,8 @@
  *                                rk_state_crit_ranges, rk_group_work (where to cut)
  *   tree construction on the GPU rk_state_build / _build_device / _build_nd / rk_state_rebuild_device (the constructor
  *                                and update_particles_u of tree.hpp:1330-1487, 3678-3765), rk_state_download,
- *                                rk_state_tree_info, rk_state_device_ptr, rk_state_set_perm, rk_pool_trim
+ *                                rk_state_tree_info, rk_state_device_ptr, rk_state_set_perm, rk_set_build_exact,
+ *                                rk_pool_trim
  *   diagnostics                  rk_state_info, rk_state_ndim, rk_last_kernel_ms, rk_count_interactions,
  *                                rk_set_kernel_variant
  *
@@ -208,6 +209,13 @@ RK_EXPORT int rk_state_build_nd(rk_state **out, int ndim, int fp, int mac, int d
  * so a time-stepping loop rebuilds without touching the driver allocator. box_size 0 = deduce again. After a
  * failure the state is empty (nparts 0) but valid. */
 RK_EXPORT int rk_state_rebuild_device(rk_state *s, const void *const d_parts[4], int64_t nparts, double box_size);
+
+/* Device builder, process-wide: on != 0 makes rk_state_build* / rk_state_rebuild_device sum the node properties in the
+ * reference's association (tree.hpp:1162-1168: serially in particle order). The node records -- hence every MAC
+ * decision and the interaction census -- are then bit-identical to the host builders', at the price
+ * of serial chains (about 12 ms more at 4M particles). Off (default): children are aggregated into their parents
+ * (fast; properties equal to rounding). The environment variable RK_BUILD_EXACT=1 sets the default. */
+RK_EXPORT void rk_set_build_exact(int on);
 
 /* Return the blocks cached by the library's device allocator to the driver (all devices). */
 RK_EXPORT void rk_pool_trim(void);

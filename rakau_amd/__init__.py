@@ -7,4 +7,11 @@ from . import _capi
 from .state import State, node_dtype, mac_value_of, NRES, nres
 from .tree import Octree, Quadtree
 
-__all__ = ["State", "Octree", "Quadtree", "node_dtype", "mac_value_of", "NRES", "nres"]
+
+
+def set_build_exact(on=True):
+    """rk_set_build_exact: device-built trees with node properties bit-identical to the host builders' (slower build)."""
+    _capi.lib().rk_set_build_exact(int(bool(on)))
+
+
+__all__ = ["set_build_exact", "State", "Octree", "Quadtree", "node_dtype", "mac_value_of", "NRES", "nres"]

@@ -464,6 +464,131 @@ __global__ void k_up_sums(const uint4 *topo, const uint64_t *ncode, uint32_t n_n
     sums[k] = s;
 }
 
+// ---- node sums in the reference's association (exact mode) ----
+// The reference sums a node's particles serially in particle order (tree.hpp:1162-1168). The first child of a node
+// starts at the node's first particle, so the node's running sum after the first child's particles IS the first
+// child's sum: a node continues from there over its remaining particles, one fused multiply-add per particle and
+// component, in order. Identical bits to the host builders, at the price of serial chains (the root's is N long).
+constexpr uint32_t EXACT_WAVE_MIN = 256; // remaining particles from which a node gets a wavefront of its own
+
+// Nodes with few remaining particles: one thread per node.
+template <typename F, int ND>
+__global__ void k_up_sums_exact(const uint4 *topo, const uint64_t *ncode, uint32_t n_nodes, unsigned lvl,
+                                const typename vt<F>::v4 *part4, typename vt<F>::v4 *sums)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_nodes || topo[k].x == 0u || level_of<ND>(ncode[k]) != lvl) {
+        return;
+    }
+    const uint32_t start = topo[k + 1u].z, end = topo[k].z;
+    if (end - start >= EXACT_WAVE_MIN) {
+        return; // k_up_sums_exact_wave
+    }
+    typename vt<F>::v4 s = sums[k + 1u];
+    for (uint32_t i = start; i < end; ++i) {
+        const typename vt<F>::v4 p = part4[i];
+        s.w += p.w;
+        s.x = d_fma(p.w, p.x, s.x);
+        s.y = d_fma(p.w, p.y, s.y);
+        s.z = d_fma(p.w, p.z, s.z);
+    }
+    sums[k] = s;
+}
+
+// List of the nodes that need a wavefront (any level).
+__global__ void k_exact_big_list(const uint4 *topo, uint32_t n_nodes, uint32_t *list, uint32_t *count)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_nodes || topo[k].x == 0u) {
+        return;
+    }
+    if (topo[k].z - topo[k + 1u].z >= EXACT_WAVE_MIN) {
+        list[atomicAdd(count, 1u)] = k;
+    }
+}
+
+// One wavefront per listed node of level lvl. Lane j < 4 carries component j of the sums {m x, m y, m z, m}: every
+// particle costs ONE dependent fused multiply-add per lane (the mass sum is fma(m, 1, sum) = m + sum exactly). The
+// particles travel through LDS in chunks of 256, stored component-major so that one 16-byte LDS read brings the next
+// four operands of a lane's chain; the next chunk's global loads are in flight while this one is consumed.
+template <typename F, int ND>
+__global__ void __launch_bounds__(256) k_up_sums_exact_wave(const uint4 *topo, const uint64_t *ncode, const uint32_t *list,
+                                                            const uint32_t *count, unsigned lvl,
+                                                            const typename vt<F>::v4 *part4, typename vt<F>::v4 *sums)
+{
+    using v4 = typename vt<F>::v4;
+    constexpr uint32_t CH = 256;
+    __shared__ __attribute__((aligned(32))) F s_tile[4][5][CH]; // rows: m x, m y, m z operands (x, y, z), m, ones
+    const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t e = blockIdx.x * 4u + static_cast<uint32_t>(wib);
+    if (e >= *count) {
+        return;
+    }
+    const uint32_t k = list[e];
+    if (level_of<ND>(ncode[k]) != lvl) {
+        return;
+    }
+    F(*tile)[CH] = s_tile[wib];
+    for (uint32_t j = static_cast<uint32_t>(lane); j < CH; j += 64u) {
+        tile[4][j] = F(1);
+    }
+    const uint32_t start = topo[k + 1u].z, end = topo[k].z;
+    const int comp = lane & 3;
+    const F *row_c = tile[comp == 3 ? 4 : comp], *row_m = tile[3];
+    F sum = reinterpret_cast<const F *>(&sums[k + 1u])[comp];
+    v4 nxt[4];
+    auto fetch = [&](uint32_t base) {
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t i = base + u * 64u + static_cast<uint32_t>(lane);
+            nxt[u] = part4[i < end ? i : end - 1u];
+        }
+    };
+    const auto sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    fetch(start);
+    for (uint32_t base = start; base < end; base += CH) {
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t j = u * 64u + static_cast<uint32_t>(lane);
+            tile[0][j] = nxt[u].x, tile[1][j] = nxt[u].y, tile[2][j] = nxt[u].z, tile[3][j] = nxt[u].w;
+        }
+        if (base + CH < end) {
+            fetch(base + CH);
+        }
+        sync();
+        const uint32_t cnt = end - base < CH ? end - base : CH, cnt8 = cnt & ~7u;
+        // The operands of the next eight particles are read from LDS while the eight dependent multiply-adds of the
+        // current ones execute.
+        v4 m0 = *reinterpret_cast<const v4 *>(row_m), m1 = *reinterpret_cast<const v4 *>(row_m + 4u);
+        v4 c0 = *reinterpret_cast<const v4 *>(row_c), c1 = *reinterpret_cast<const v4 *>(row_c + 4u);
+        for (uint32_t i = 0; i < cnt8; i += 8u) {
+            const uint32_t nx = i + 8u < CH ? i + 8u : i; // stays inside the tile
+            const v4 nm0 = *reinterpret_cast<const v4 *>(row_m + nx), nm1 = *reinterpret_cast<const v4 *>(row_m + nx + 4u);
+            const v4 nc0 = *reinterpret_cast<const v4 *>(row_c + nx), nc1 = *reinterpret_cast<const v4 *>(row_c + nx + 4u);
+            sum = d_fma(m0.x, c0.x, sum);
+            sum = d_fma(m0.y, c0.y, sum);
+            sum = d_fma(m0.z, c0.z, sum);
+            sum = d_fma(m0.w, c0.w, sum);
+            sum = d_fma(m1.x, c1.x, sum);
+            sum = d_fma(m1.y, c1.y, sum);
+            sum = d_fma(m1.z, c1.z, sum);
+            sum = d_fma(m1.w, c1.w, sum);
+            m0 = nm0, m1 = nm1, c0 = nc0, c1 = nc1;
+        }
+        for (uint32_t i = cnt8; i < cnt; ++i) {
+            sum = d_fma(row_m[i], row_c[i], sum);
+        }
+        sync();
+    }
+    if (lane < 4) {
+        reinterpret_cast<F *>(&sums[k])[lane] = sum;
+    }
+}
+
 template <typename F, int ND>
 __global__ void k_finalize(const uint4 *topo, const uint64_t *ncode, uint32_t n_nodes, const typename vt<F>::v4 *sums,
                            F box, int mac, typename vt<F>::v4 *node_com, typename vt<F>::v2 *node_mac, ctrl_block *ctrl)
@@ -894,9 +1019,26 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     auto sums = dalloc<v4>(nn);
     hipLaunchKernelGGL((k_leaf_sums<F>), dim3(nblk(nn)), dim3(256), 0, st, topo, static_cast<uint32_t>(nn),
                        static_cast<const v4 *>(p4), sums.get());
-    for (int lvl = static_cast<int>(CBITS) - 1; lvl >= 0; --lvl) {
-        hipLaunchKernelGGL((k_up_sums<F, ND>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, static_cast<uint32_t>(nn),
-                           static_cast<unsigned>(lvl), sums.get());
+    if (exact_node_sums()) {
+        // The reference's association (bit-identical node properties; serial chains: ~12 ms more at 4M particles).
+        auto big = dalloc<uint32_t>(nn + 1);
+        RK_HIP(hipMemsetAsync(big.get() + nn, 0, sizeof(uint32_t), st));
+        hipLaunchKernelGGL(k_exact_big_list, dim3(nblk(nn)), dim3(256), 0, st, topo, static_cast<uint32_t>(nn), big.get(),
+                           big.get() + nn);
+        const auto max_big = static_cast<unsigned>(static_cast<size_t>(n) / EXACT_WAVE_MIN * (CBITS + 1u) + 1u);
+        for (int lvl = static_cast<int>(CBITS) - 1; lvl >= 0; --lvl) {
+            hipLaunchKernelGGL((k_up_sums_exact<F, ND>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode,
+                               static_cast<uint32_t>(nn), static_cast<unsigned>(lvl), static_cast<const v4 *>(p4), sums.get());
+            // Per level the listed nodes are disjoint in particles: at most n / EXACT_WAVE_MIN of them exist.
+            hipLaunchKernelGGL((k_up_sums_exact_wave<F, ND>), dim3((std::min<unsigned>(max_big, static_cast<unsigned>(nn)) + 3u) / 4u),
+                               dim3(256), 0, st, topo, ncode, big.get(), big.get() + nn, static_cast<unsigned>(lvl),
+                               static_cast<const v4 *>(p4), sums.get());
+        }
+    } else {
+        for (int lvl = static_cast<int>(CBITS) - 1; lvl >= 0; --lvl) {
+            hipLaunchKernelGGL((k_up_sums<F, ND>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, static_cast<uint32_t>(nn),
+                               static_cast<unsigned>(lvl), sums.get());
+        }
     }
     hipLaunchKernelGGL((k_finalize<F, ND>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, static_cast<uint32_t>(nn), sums.get(),
                        box, s.mac, node_com, node_mac, ctrl.get());

@@ -284,6 +284,8 @@ void launch_block(const rk_state &s, int q, const kparams<F> &p, const uint32_t 
 template <typename F, int ND>
 void build_device(rk_state &s, const void *const parts[4], bool parts_on_device, int64_t nparts, double box_size,
                   uint64_t max_leaf_n, std::string &bad_coord_msg);
+// Device builder: sum node properties in the reference's serial association (rk_set_build_exact / RK_BUILD_EXACT).
+bool exact_node_sums();
 template <typename F>
 void launch_census(const rk_state &s, const kparams<F> &p, int64_t g_begin, int64_t g_end,
                    unsigned long long *d_counts, unsigned long long *d_per_group, hipStream_t stream);

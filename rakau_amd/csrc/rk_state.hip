@@ -18,6 +18,9 @@ namespace
 
 thread_local std::string g_err;
 
+// -1: not set (the environment variable RK_BUILD_EXACT decides, default off).
+std::atomic<int> g_build_exact{-1};
+
 // Layout tag of rk_state_export / rk_state_import ("rk04"): bump it whenever the buffer list or the meta block changes.
 constexpr int64_t state_layout_tag = 0x726b3034;
 
@@ -701,7 +704,7 @@ void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64
 
 template <typename F>
 void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d_out, double mac_value, double G,
-              double eps2, int offset_output, hipStream_t stream)
+              double eps2, int offset_output, hipStream_t stream, bool allow_graph = true)
 {
     // Variant 2 (LDS interaction lists) is the default; variant 1 is kept for cross-checks.
     const bool v2 = s.variant != 1;
@@ -920,7 +923,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                                 static_cast<const uint32_t *>(s.buf[RK_BUF_CLASS]) + s.class2_off[rk::big_class] + big_b,
                                 big_e - big_b, st);
         };
-        if (use_graph) {
+        if (use_graph && allow_graph) {
             // A call that repeats the previous one (same range, outputs, parameters) replays a captured graph:
             // one hipGraphLaunch instead of ~20 runtime calls.
             rk_state::graph_key key{};
@@ -1005,6 +1008,22 @@ void check_call(const rk_state *s, int q, void *const *out, double mac_value, do
 }
 
 } // namespace
+
+namespace rk
+{
+bool exact_node_sums()
+{
+    const int v = g_build_exact.load();
+    if (v >= 0) {
+        return v != 0;
+    }
+    static const bool env = [] {
+        const char *e = std::getenv("RK_BUILD_EXACT");
+        return e && std::atoi(e) != 0;
+    }();
+    return env;
+}
+} // namespace rk
 
 extern "C" {
 
@@ -1185,15 +1204,18 @@ int rk_acc_pot(rk_state *s, int q, int64_t p_begin, int64_t p_end, void *const *
         for (int k = 0; k < nres; ++k) {
             d_ptrs[k] = static_cast<unsigned char *>(s->d_out) + static_cast<size_t>(k) * count * fsz;
         }
+        // No hipGraph capture on this path: the callers of the host entry point drive several devices from several host
+        // threads (kwargs::split), and a capture in one thread makes legacy-stream operations of the others fail
+        // (hipErrorStreamCaptureImplicit). The 35 us a replay saves vanish next to the transfer of the results.
         unsigned char *dst[4] = {};
         for (int k = 0; k < nres; ++k) {
             dst[k] = static_cast<unsigned char *>(out[k]) + (offset_output ? static_cast<size_t>(p_begin) * fsz : 0);
         }
         if (need < (size_t(1) << 20)) {
             if (s->fp == RK_F32) {
-                run_impl<float>(*s, q, p_begin, p_end, d_ptrs, mac_value, G, eps2, 0, nullptr);
+                run_impl<float>(*s, q, p_begin, p_end, d_ptrs, mac_value, G, eps2, 0, nullptr, false);
             } else {
-                run_impl<double>(*s, q, p_begin, p_end, d_ptrs, mac_value, G, eps2, 0, nullptr);
+                run_impl<double>(*s, q, p_begin, p_end, d_ptrs, mac_value, G, eps2, 0, nullptr, false);
             }
             for (int k = 0; k < nres; ++k) {
                 RK_HIP(hipMemcpy(dst[k], d_ptrs[k], count * fsz, hipMemcpyDeviceToHost));
@@ -1222,9 +1244,9 @@ int rk_acc_pot(rk_state *s, int q, int64_t p_begin, int64_t p_end, void *const *
             h_ptrs[k] = static_cast<unsigned char *>(s->h_stage) + static_cast<size_t>(k) * count * fsz;
         }
         if (s->fp == RK_F32) {
-            run_impl<float>(*s, q, p_begin, p_end, h_ptrs, mac_value, G, eps2, 0, nullptr);
+            run_impl<float>(*s, q, p_begin, p_end, h_ptrs, mac_value, G, eps2, 0, nullptr, false);
         } else {
-            run_impl<double>(*s, q, p_begin, p_end, h_ptrs, mac_value, G, eps2, 0, nullptr);
+            run_impl<double>(*s, q, p_begin, p_end, h_ptrs, mac_value, G, eps2, 0, nullptr, false);
         }
         RK_HIP(hipEventSynchronize(s->ev1));
         const auto *stage = static_cast<const unsigned char *>(s->h_stage);
@@ -1576,6 +1598,11 @@ int rk_state_rebuild_device(rk_state *s, const void *const d_parts[4], int64_t n
 void rk_pool_trim(void)
 {
     rk::pool_trim();
+}
+
+void rk_set_build_exact(int on)
+{
+    g_build_exact.store(on ? 1 : 0);
 }
 
 int rk_state_set_perm(rk_state *s, const uint64_t *perm)
