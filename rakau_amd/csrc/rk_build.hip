@@ -544,11 +544,9 @@ __global__ void __launch_bounds__(256) k_up_sums_exact_wave(const uint4 *topo, c
             nxt[u] = part4[i < end ? i : end - 1u];
         }
     };
-    const auto sync = [] {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    };
+    // LDS operations of one wavefront execute in order: what the lanes exchange through the tile only needs the compiler
+    // to keep the program order (and must NOT wait for the global loads of the next chunk, which a memory fence would).
+    const auto sync = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
     fetch(start);
     for (uint32_t base = start; base < end; base += CH) {
 #pragma unroll

@@ -30,6 +30,13 @@
 #ifndef RK_PC_W64
 #define RK_PC_W64 4 // fp64
 #endif
+#ifndef RK_PC2_W
+#define RK_PC2_W 5 // fp32 kernels with two consumers: used for trees too small to fill the device, where registers
+                   // (no spills) matter more than the number of waves per SIMD
+#endif
+#ifndef RK_PC2_W64
+#define RK_PC2_W64 3 // the same for fp64
+#endif
 
 namespace rk
 {
@@ -48,7 +55,9 @@ struct pc_lds {
 };
 
 template <typename F, int Q, int MAC, int R, int ND, int KC>
-__global__ void __launch_bounds__(64 * (1 + KC), (sizeof(F) == 4 ? (R <= 2 ? RK_PC_W12 : RK_PC_W34) : RK_PC_W64))
+__global__ void __launch_bounds__(64 * (1 + KC),
+                                  (sizeof(F) == 4 ? (KC > 1 ? RK_PC2_W : (R <= 2 ? RK_PC_W12 : RK_PC_W34))
+                                                  : (KC > 1 ? RK_PC2_W64 : RK_PC_W64)))
     k_pc(const kparams<F> P, const uint32_t *__restrict__ list, int n_list)
 {
     using v4 = typename vt<F>::v4;
@@ -364,16 +373,25 @@ __global__ void __launch_bounds__(64 * (1 + KC), (sizeof(F) == 4 ? (R <= 2 ? RK_
         bt.rb = rec->b;
     };
     // Pop up to 8 sibling runs and issue the loads of their records. Returns the number of entries popped.
-    auto pop_and_load = [&](batch_t &bt) __attribute__((always_inline)) -> int {
+    // `pending` = number of entries a batch already in flight may still push (no batch is prefetched at present: two
+    // batches in flight were measured on trees of 30k-1M particles and changed nothing, tools/r02_job10.sh).
+    auto pop_and_load = [&](batch_t &bt, int pending) __attribute__((always_inline)) -> int {
         if (size == 0) {
             return 0;
         }
         int k = size < 8 ? size : 8;
         // Keep the stack within bounds even if every candidate is opened (8 pushes per popped entry);
-        // otherwise fall back to one entry at a time (depth-first), whose growth is bounded by LK_DFS_RESERVE.
-        const int room = (LK_STACK_CAP - LK_DFS_RESERVE - n_uq - size) / 7;
+        // otherwise fall back to one entry at a time (depth-first), whose growth is bounded by LK_DFS_RESERVE -- only when
+        // nothing else is in flight.
+        const int room = (LK_STACK_CAP - LK_DFS_RESERVE - pending - n_uq - size) / 7;
         if (room < k) {
-            k = room >= 1 ? room : 1;
+            if (room >= 1) {
+                k = room;
+            } else if (pending == 0) {
+                k = 1;
+            } else {
+                return 0;
+            }
         }
         const int e_idx = lane >> 3, e_sub = lane & 7;
         uint32_t entry = 0u;
@@ -525,43 +543,47 @@ __global__ void __launch_bounds__(64 * (1 + KC), (sizeof(F) == 4 ? (R <= 2 ? RK_
         return 1;
     };
     // ---- list building ----
-    bool done = false;
-    for (;;) {
-        // Room for the worst-case output of one pass (64 sources, 64 leaves); everything is settled at the end.
-        if (n_lq + 64 > LK_LQ_CAP || done) {
-            drain_leaves();
+    auto fetch = [&](batch_t &bt, int pending) __attribute__((always_inline)) -> bool {
+        if (pop_and_load(bt, pending) != 0) {
+            return true;
         }
-        if (done) {
-            break;
-        }
-        if (n_src + 64 > TILE_CAP) {
-            flush();
-        }
-        if (n_uq >= 64) {
-            process_exact();
-            continue;
-        }
-        // Near the stack bound the descent is one entry at a time, and LK_DFS_RESERVE only bounds a STRICT depth-first
-        // descent: settle the parked candidates first.
-        if (n_uq > 0 && LK_STACK_CAP - LK_DFS_RESERVE - n_uq - size < 7) {
-            process_exact();
-            continue;
-        }
-        batch_t A;
-        int k = pop_and_load(A);
-        if (k == 0) {
-            k = resid_load(A);
-        }
-        if (k == 0) {
-            // Stack and residual list exhausted: settle the undecided candidates (they may open new runs).
-            if (n_uq > 0) {
-                process_exact();
-            } else {
-                done = true;
+        return resid_load(bt) != 0;
+    };
+    {
+        bool done = false;
+        for (;;) {
+            // Room for the worst-case output of one pass (64 sources, 64 leaves); everything is settled at the end.
+            if (n_lq + 64 > LK_LQ_CAP || done) {
+                drain_leaves();
             }
-            continue;
+            if (done) {
+                break;
+            }
+            if (n_src + 64 > TILE_CAP) {
+                flush();
+            }
+            if (n_uq >= 64) {
+                process_exact();
+                continue;
+            }
+            // Near the stack bound the descent is one entry at a time, and LK_DFS_RESERVE only bounds a STRICT
+            // depth-first descent: settle the parked candidates first.
+            if (n_uq > 0 && LK_STACK_CAP - LK_DFS_RESERVE - n_uq - size < 7) {
+                process_exact();
+                continue;
+            }
+            batch_t A;
+            if (!fetch(A, 0)) {
+                // Stack and residual list exhausted: settle the undecided candidates (they may open new runs).
+                if (n_uq > 0) {
+                    process_exact();
+                } else {
+                    done = true;
+                }
+                continue;
+            }
+            process(A);
         }
-        process(A);
     }
     publish(true);
 }
