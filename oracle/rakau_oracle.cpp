@@ -11,16 +11,18 @@
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
 // library.  The product (rakau_amd/) never links, imports or calls it.
 //
-// Pinning status: the reference cannot be built in this image (TBB, xsimd and Boost are
-// absent and no stand-ins may be written), and it ships no golden vectors.  The oracle is
-// pinned (tests/test_oracle_*.py) against
+// Pinning status: PARITY UNPINNED. The reference cannot be built in this image (TBB, xsimd and Boost are absent and no
+// stand-ins may be written), and it ships no golden vectors, so no output of a run of the reference backs this file.
+// What constrains it instead (tests/test_oracle_*.py, tests/test_cpu_engine.py):
 //   (1) the reference's own known-answer tests restated on this oracle
 //       (test/accuracy_*.cpp, g_constant_*.cpp, zero_masses.cpp, softening_*.cpp,
 //        ordering_*.cpp: agreement with the direct sum to the tolerances those tests state,
-//        bit-exact G scaling, exact zeros), and
-//   (2) the checkpoints SURVEY.md section 8(c) recorded from the reference's arithmetic
-//       (node count, deduced box size and accs_u at Morton index 0 for the default-seeded
-//        benchmark Plummer sphere at N=1e5 and N=4e6).
+//        bit-exact G scaling, exact zeros);
+//   (2) bit-for-bit agreement with an independently structured second implementation (the scalar flavour of
+//       include/rakau_amd/cpu_engine.hpp) on trees built by an independent builder;
+//   (3) consistency with the figures SURVEY.md section 8(c) recorded (node count, deduced box size, accs_u at Morton
+//       index 0 for the default-seeded benchmark Plummer sphere) -- obtained there from a stand-in build, hence a
+//       consistency check, not a pin.
 //
 // Build: see oracle/Makefile  (g++ -O2 -ffp-contract=off -mfma; no -march=native: the .so
 // travels to the GPU box).
