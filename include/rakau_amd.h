@@ -261,10 +261,10 @@ RK_EXPORT int rk_count_interactions(rk_state *s, int64_t p_begin, int64_t p_end,
  * (the reference leaves the split vector to the user, tree.hpp:2853-2935). */
 RK_EXPORT int rk_group_work(rk_state *s, double mac_value, uint64_t *work);
 
-/* Select the traversal kernel: 0 = automatic (default), 1 = wave-per-group scalar DFS, 2 = LDS interaction-list kernel
- * (one wave per critical node), 3 = producer / consumer waves per critical node (results bit-identical to 2),
- * 4 = producer + two consumer waves (a different, equally deterministic summation order). A property of the STATE:
- * every call on it, whatever its range, uses the same kernel, so shards always reproduce the full-range result. */
+/* Select the traversal kernel: 0 = automatic (default: the producer / consumer kernel for calls over few critical nodes,
+ * the list kernel otherwise), 1 = wave-per-group scalar DFS, 2 = LDS interaction-list kernel (one wave per critical
+ * node), 3 = producer / consumer waves per critical node. 2 and 3 give bit-identical results (same interaction lists,
+ * same summation order); 1 sums in the CPU engine's order. For tests and benchmarks. */
 RK_EXPORT int rk_set_kernel_variant(rk_state *s, int variant);
 
 #ifdef __cplusplus

@@ -273,10 +273,10 @@ void launch_traversal(const rk_state &s, int q, const kparams<F> &p, const int64
                       const int64_t cls_end[n_classes], hipStream_t stream);
 template <typename F>
 void launch_list(const rk_state &s, int q, const kparams<F> &p, const int64_t cls_begin[n_classes],
-                 const int64_t cls_end[n_classes], hipStream_t const streams[n_list_R]);
+                 const int64_t cls_end[n_classes], hipStream_t const streams[n_list_R], unsigned class_mask = ~0u);
 template <typename F>
-void launch_pc(const rk_state &s, int q, int kc, const kparams<F> &p, const int64_t cls_begin[n_classes],
-               const int64_t cls_end[n_classes], hipStream_t const streams[n_list_R]);
+void launch_pc(const rk_state &s, int q, const kparams<F> &p, const int64_t cls_begin[n_classes],
+               const int64_t cls_end[n_classes], hipStream_t const streams[n_list_R], unsigned class_mask = ~0u);
 template <typename F>
 void launch_super(const rk_state &s, const kparams<F> &p, int64_t s_begin, int64_t s_end, hipStream_t stream);
 template <typename F>

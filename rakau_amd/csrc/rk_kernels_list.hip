@@ -700,13 +700,13 @@ template void launch_super<double>(const rk_state &, const kparams<double> &, in
 // ------------------------------------------------------------------------------------------------
 template <typename F, int Q, int MAC>
 static void launch_list_qm(const rk_state &s, const kparams<F> &p, const int64_t cb[n_classes],
-                           const int64_t ce[n_classes], hipStream_t const streams[n_list_R])
+                           const int64_t ce[n_classes], hipStream_t const streams[n_list_R], unsigned class_mask)
 {
     const auto *lists = s.cur_lists; // class lists of the state, or the launch plan of this call
     auto go = [&](auto Rtag, int c) {
         constexpr int R = decltype(Rtag)::value;
         const int64_t n = ce[c] - cb[c];
-        if (n <= 0) {
+        if (n <= 0 || !((class_mask >> c) & 1u)) {
             return;
         }
         const auto grid = static_cast<unsigned>((n + RK_WPB - 1) / RK_WPB);
@@ -731,23 +731,23 @@ static void launch_list_qm(const rk_state &s, const kparams<F> &p, const int64_t
 
 template <typename F>
 void launch_list(const rk_state &s, int q, const kparams<F> &p, const int64_t cb[n_classes],
-                 const int64_t ce[n_classes], hipStream_t const streams[n_list_R])
+                 const int64_t ce[n_classes], hipStream_t const streams[n_list_R], unsigned class_mask)
 {
     switch (q * 2 + s.mac) {
-        case 0: launch_list_qm<F, 0, 0>(s, p, cb, ce, streams); break;
-        case 1: launch_list_qm<F, 0, 1>(s, p, cb, ce, streams); break;
-        case 2: launch_list_qm<F, 1, 0>(s, p, cb, ce, streams); break;
-        case 3: launch_list_qm<F, 1, 1>(s, p, cb, ce, streams); break;
-        case 4: launch_list_qm<F, 2, 0>(s, p, cb, ce, streams); break;
-        case 5: launch_list_qm<F, 2, 1>(s, p, cb, ce, streams); break;
+        case 0: launch_list_qm<F, 0, 0>(s, p, cb, ce, streams, class_mask); break;
+        case 1: launch_list_qm<F, 0, 1>(s, p, cb, ce, streams, class_mask); break;
+        case 2: launch_list_qm<F, 1, 0>(s, p, cb, ce, streams, class_mask); break;
+        case 3: launch_list_qm<F, 1, 1>(s, p, cb, ce, streams, class_mask); break;
+        case 4: launch_list_qm<F, 2, 0>(s, p, cb, ce, streams, class_mask); break;
+        case 5: launch_list_qm<F, 2, 1>(s, p, cb, ce, streams, class_mask); break;
         default: throw error(RK_EINVAL, "invalid q / mac combination");
     }
     RK_HIP(hipGetLastError());
 }
 
 template void launch_list<float>(const rk_state &, int, const kparams<float> &, const int64_t[n_classes],
-                                 const int64_t[n_classes], hipStream_t const[n_list_R]);
+                                 const int64_t[n_classes], hipStream_t const[n_list_R], unsigned);
 template void launch_list<double>(const rk_state &, int, const kparams<double> &, const int64_t[n_classes],
-                                  const int64_t[n_classes], hipStream_t const[n_list_R]);
+                                  const int64_t[n_classes], hipStream_t const[n_list_R], unsigned);
 
 } // namespace rk

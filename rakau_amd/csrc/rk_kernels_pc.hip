@@ -1,41 +1,30 @@
 // Variant 3 of the traversal: producer / consumer wavefronts per target group.
 //
 // The list kernel (rk_kernels_list.hip) alternates list building and dense evaluation inside ONE wavefront per critical
-// node: the two phases serialise, the live registers of both are allocated together (spills), and a launch with few
-// critical nodes leaves the device half empty while every wave walks its long serial chain. Here a workgroup of
-// 1 + KC wavefronts serves one critical node:
+// node. That is the best use of the wave slots when the device is full; a launch with few critical nodes, however, ends
+// with the longest serial chains -- the dense phase of the largest groups, R targets per lane times all their sources --
+// running alone on their SIMDs. Here a workgroup of 1 + R wavefronts serves one critical node of lane-mapping class R:
 //
 //   * the PRODUCER wave builds the interaction list exactly as the list kernel does (same stack of sibling runs, same
 //     box / probe / exact MAC tests, same leaf gathering, same supergroup pre-pass inputs) into a double-buffered LDS tile;
-//   * the KC CONSUMER waves evaluate the published tile with the dense targets x sources loop while the producer fills
-//     the other buffer. One workgroup barrier per tile: the producer arrives when tile k is complete, the consumers when
-//     they have finished tile k - 1.
+//   * CONSUMER wave c (c < R) evaluates every published tile for the c-th target of each lane of the list kernel's
+//     mapping (targets c * TP .. c * TP + TP - 1), i.e. with ONE target per lane, while the producer fills the other
+//     buffer. One workgroup barrier per tile: the producer arrives when tile k is complete, the consumers when they have
+//     finished tile k - 1.
 //
-// With KC = 1 the sequence of tiles, their contents and the lane mapping of the dense phase are those of the list
-// kernel, so the results are bit-identical to it (tests assert this); the critical path of a group becomes
-// max(list building, dense) instead of their sum, the device holds twice as many waves for the same number of groups,
-// and neither role keeps the other's registers alive. KC = 2 splits every tile between two consumers (fixed shares,
-// partial sums added in a fixed order): a different, equally deterministic summation order -- selected per STATE
-// (rk_set_kernel_variant), never per call, so that shards and full-range calls of one state always agree bit for bit.
+// The sequence of tiles, their contents, the number of source splits NS and the order in which every target receives its
+// contributions are those of the list kernel, so the results are BIT-IDENTICAL to it (tests assert this) -- which kernel
+// serves a call is therefore a pure scheduling decision (rk_state.hip picks this one for calls over few critical nodes).
+// What it buys there: the critical path of a group is max(list building, dense / R) instead of list building + dense.
 //
 // The MAC decisions are those of the reference's CPU engine (include/rakau/tree.hpp:2662-2672 of the reference).
 #include "rk_list_common.hpp"
 
-#ifndef RK_PC_W12
-#define RK_PC_W12 8 // waves per SIMD the R <= 2 kernels are compiled for
-#endif
-#ifndef RK_PC_W34
-#define RK_PC_W34 6 // R = 3, 4
+#ifndef RK_PC_W
+#define RK_PC_W 5 // fp32: waves per SIMD the kernels are compiled for (96 VGPRs: at most 24 bytes of spills, in the producer)
 #endif
 #ifndef RK_PC_W64
 #define RK_PC_W64 4 // fp64
-#endif
-#ifndef RK_PC2_W
-#define RK_PC2_W 5 // fp32 kernels with two consumers: used for trees too small to fill the device, where registers
-                   // (no spills) matter more than the number of waves per SIMD
-#endif
-#ifndef RK_PC2_W64
-#define RK_PC2_W64 3 // the same for fp64
 #endif
 
 namespace rk
@@ -43,33 +32,32 @@ namespace rk
 
 constexpr uint32_t PC_LAST = 0x80000000u;
 
-// Workgroup LDS: producer-private stack and queues, two tiles of KC x src_cap sources, the published counts.
-// fp32, KC = 1: 2 + 1 + 0.5 + 4 KiB = 7.5 KiB per group.
-template <typename F, int KC>
+// Workgroup LDS: producer-private stack and queues, two tiles of src_cap sources, the published counts.
+// fp32: 2 + 1 + 0.5 + 4 KiB = 7.5 KiB per group.
+template <typename F>
 struct pc_lds {
     uint32_t stack[LK_STACK_CAP];
     uint2 lq[LK_LQ_CAP];
     uint32_t uq[LK_UQ_CAP];
     uint32_t tile_n[2];
-    typename vt<F>::v4 tile[2][lk_cfg<F>::src_cap * KC];
+    typename vt<F>::v4 tile[2][lk_cfg<F>::src_cap];
 };
 
-template <typename F, int Q, int MAC, int R, int ND, int KC>
-__global__ void __launch_bounds__(64 * (1 + KC),
-                                  (sizeof(F) == 4 ? (KC > 1 ? RK_PC2_W : (R <= 2 ? RK_PC_W12 : RK_PC_W34))
-                                                  : (KC > 1 ? RK_PC2_W64 : RK_PC_W64)))
+template <typename F, int Q, int MAC, int R, int ND>
+__global__ void __launch_bounds__(64 * (1 + R), (sizeof(F) == 4 ? RK_PC_W : RK_PC_W64))
     k_pc(const kparams<F> P, const uint32_t *__restrict__ list, int n_list)
 {
     using v4 = typename vt<F>::v4;
     using v2 = typename vt<F>::v2;
     constexpr int NR = nres_of(Q);
-    constexpr int SRC_CAP = lk_cfg<F>::src_cap; // sources one consumer takes from a tile
-    constexpr int TILE_CAP = SRC_CAP * KC;
-    static_assert(KC == 1 || KC == 2);
-    static_assert(sizeof(uint32_t) * LK_STACK_CAP >= 64 * 4 * sizeof(F) || KC == 1, "cross-consumer scratch does not fit");
-    __shared__ pc_lds<F, KC> L;
+    constexpr int SRC_CAP = lk_cfg<F>::src_cap;
+    constexpr int TILE_CAP = SRC_CAP;
+    static_assert(R >= 1 && R <= 4);
+    // The consumers' split-reduction scratch (64 * NR values each) lives in the two tiles.
+    static_assert(2 * lk_cfg<F>::src_cap * 4 * sizeof(F) >= size_t(R) * 64 * 4 * sizeof(F), "reduction scratch does not fit");
+    __shared__ pc_lds<F> L;
 
-    const int role = threadIdx.x >> 6; // 0 = producer, 1.. = consumers
+    const int role = threadIdx.x >> 6; // 0 = producer, 1 + c = consumer c
     const int lane = threadIdx.x & 63;
     const unsigned blk = xcd_map_block(blockIdx.x, gridDim.x, P.xcd_mode);
     if (static_cast<int>(blk) >= n_list) {
@@ -83,39 +71,33 @@ __global__ void __launch_bounds__(64 * (1 + KC),
     const unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
-    // Lane mapping of the dense phase (also used by the producer's lane = target exact test): TP target slots,
-    // NS source splits.
+    // Lane mapping of the list kernel's dense phase: TP target slots, NS source splits, R targets per slot.
     const int TP = (T + R - 1) / R;
     const int NS = 64 / TP;
     const int ts = lane % TP, sp_raw = lane / TP;
     const bool lane_on = sp_raw < NS;
     const int sp = lane_on ? sp_raw : 0; // idle lanes shadow split 0; their results are never stored
-
-    v4 tp[R];
-    int tidx[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        tidx[r] = ts + r * TP;
-        const bool valid = tidx[r] < T;
-        tp[r] = P.part4[tb + (valid ? tidx[r] : 0)];
-        if (!valid) {
-            tidx[r] = -1;
-        }
-    }
     const F eps2 = P.eps2;
 
     if (role != 0) {
         // =====================================================================================================
-        // Consumer: dense evaluation of the published tiles.
+        // Consumer c: dense evaluation of the published tiles for target c * TP + ts.
         // =====================================================================================================
         const int cons = role - 1;
-        F acc[R][NR];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-#pragma unroll
-            for (int k = 0; k < NR; ++k) {
-                acc[r][k] = F(0);
+        v4 tp[1];
+        int tidx[1];
+        tidx[0] = ts + cons * TP;
+        {
+            const bool valid = tidx[0] < T;
+            tp[0] = P.part4[tb + (valid ? tidx[0] : 0)];
+            if (!valid) {
+                tidx[0] = -1;
             }
+        }
+        F acc[1][NR];
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            acc[0][k] = F(0);
         }
         // n / NS for n <= SRC_CAP without a division per tile: exact for n * NS < 2^16.
         const int inv_ns = (65536 + NS - 1) / NS;
@@ -124,98 +106,71 @@ __global__ void __launch_bounds__(64 * (1 + KC),
         for (;;) {
             __syncthreads(); // tile `buf` is published; the producer now owns the other buffer
             const uint32_t word = L.tile_n[buf];
-            const int n_all = static_cast<int>(word & ~PC_LAST);
-            // Consumer c takes the sources [c * SRC_CAP, (c + 1) * SRC_CAP) of the tile.
-            int n = n_all - cons * SRC_CAP;
-            n = n < 0 ? 0 : (n > SRC_CAP ? SRC_CAP : n);
+            const int n = static_cast<int>(word & ~PC_LAST);
             if (n > 0) {
-                lk_eval_tile<F, Q, R, false, ND>(L.tile[buf] + cons * SRC_CAP, n, (n * inv_ns) >> 16, sp, NS, true, lane_on, tp,
-                                                 acc, eps2, tidx);
+                lk_eval_tile<F, Q, 1, false, ND>(L.tile[buf], n, (n * inv_ns) >> 16, sp, NS, true, lane_on, tp, acc, eps2, tidx);
             }
             if (word & PC_LAST) {
                 break;
             }
             buf ^= 1;
         }
-        // ---- interactions inside the group: its own particles as sources, self pair masked (consumer 0) ----
-        // The producer has published its last tile: the buffer it would fill next is free.
-        if (cons == 0) {
+        // ---- interactions inside the group: its own particles as sources, self pair masked ----
+        // The producer has published its last tile and left: the buffer it would fill next is free. Consumer 0 loads the
+        // group's particles, every consumer evaluates them for its own targets.
+        {
             v4 *self = L.tile[buf ^ 1];
             for (int b0 = 0; b0 < T; b0 += SRC_CAP) {
                 const int n = (T - b0) < SRC_CAP ? (T - b0) : SRC_CAP;
-                for (int j = lane; j < n; j += 64) {
-                    self[j] = P.part4[tb + static_cast<uint32_t>(b0 + j)];
+                if (cons == 0) {
+                    for (int j = lane; j < n; j += 64) {
+                        self[j] = P.part4[tb + static_cast<uint32_t>(b0 + j)];
+                    }
                 }
-                wave_sync();
-                int tloc[R];
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    tloc[r] = tidx[r] < 0 ? -1 : tidx[r] - b0;
+                if constexpr (R > 1) {
+                    __syncthreads();
+                } else {
+                    wave_sync();
                 }
-                lk_eval_tile<F, Q, R, true, ND>(self, n, (n * inv_ns) >> 16, sp, NS, true, lane_on, tp, acc, eps2, tloc);
-                wave_sync();
+                int tloc[1];
+                tloc[0] = tidx[0] < 0 ? -1 : tidx[0] - b0;
+                lk_eval_tile<F, Q, 1, true, ND>(self, n, (n * inv_ns) >> 16, sp, NS, true, lane_on, tp, acc, eps2, tloc);
+                if constexpr (R > 1) {
+                    __syncthreads();
+                } else {
+                    wave_sync();
+                }
             }
         }
-        // ---- sum the source splits in a fixed order ----
+        // ---- sum the source splits in a fixed order (scratch: this consumer's share of the two tiles) ----
         if (NS > 1) {
-            // Scratch: this consumer's share of the buffer it read last (nobody else touches it any more; 64 * NR values).
-            F *red = reinterpret_cast<F *>(L.tile[buf] + cons * SRC_CAP);
+            F *red = reinterpret_cast<F *>(&L.tile[0][0]) + cons * 64 * NR;
+            if (lane_on) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                if (lane_on) {
-#pragma unroll
-                    for (int k = 0; k < NR; ++k) {
-                        red[(sp_raw * TP + ts) * NR + k] = acc[r][k];
-                    }
+                for (int k = 0; k < NR; ++k) {
+                    red[(sp_raw * TP + ts) * NR + k] = acc[0][k];
                 }
-                wave_sync();
-                if (lane_on && sp_raw == 0) {
-#pragma unroll
-                    for (int k = 0; k < NR; ++k) {
-                        F sum = F(0);
-                        for (int s = 0; s < NS; ++s) {
-                            sum += red[(s * TP + ts) * NR + k];
-                        }
-                        acc[r][k] = sum;
-                    }
-                }
-                wave_sync();
             }
-        }
-        if constexpr (KC > 1) {
-            // ---- add the consumers' partial sums in consumer order (scratch: the producer's stack, idle by now) ----
-            F *xr = reinterpret_cast<F *>(L.stack);
+            wave_sync();
+            if (lane_on && sp_raw == 0) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                if (cons == 1 && lane_on && sp_raw == 0) {
-#pragma unroll
-                    for (int k = 0; k < NR; ++k) {
-                        xr[ts * NR + k] = acc[r][k];
+                for (int k = 0; k < NR; ++k) {
+                    F sum = F(0);
+                    for (int s = 0; s < NS; ++s) {
+                        sum += red[(s * TP + ts) * NR + k];
                     }
+                    acc[0][k] = sum;
                 }
-                __syncthreads();
-                if (cons == 0 && lane_on && sp_raw == 0) {
-#pragma unroll
-                    for (int k = 0; k < NR; ++k) {
-                        acc[r][k] += xr[ts * NR + k];
-                    }
-                }
-                __syncthreads();
             }
         }
         // ---- scale by G, write out ----
-        if (cons == 0 && lane_on && sp_raw == 0) {
+        if (lane_on && sp_raw == 0 && tidx[0] >= 0) {
             const F G = P.G;
+            const uint32_t o = out_index(P, tb + static_cast<uint32_t>(tidx[0]));
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                if (tidx[r] >= 0) {
-                    const uint32_t o = out_index(P, tb + static_cast<uint32_t>(tidx[r]));
-#pragma unroll
-                    for (int k = 0; k < NR; ++k) {
-                        if (ND == 3 || Q == 1 || k != 2) { // a quadtree has no z acceleration (and no array for it)
-                            P.out[k][o] = acc[r][k] * G;
-                        }
-                    }
+            for (int k = 0; k < NR; ++k) {
+                if (ND == 3 || Q == 1 || k != 2) { // a quadtree has no z acceleration (and no array for it)
+                    P.out[k][o] = acc[0][k] * G;
                 }
             }
         }
@@ -231,6 +186,13 @@ __global__ void __launch_bounds__(64 * (1 + KC),
         return;
     }
 
+    // The producer keeps all R targets of the list kernel's lane mapping for the lane = target exact MAC test.
+    v4 tp[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int ti = ts + r * TP;
+        tp[r] = P.part4[tb + (ti < T ? ti : 0)];
+    }
     // =========================================================================================================
     // Producer: list building (the code of the list kernel, with flush() replaced by publish()).
     // =========================================================================================================
@@ -277,7 +239,7 @@ __global__ void __launch_bounds__(64 * (1 + KC),
         n_src = 0;
     };
     // The list kernel evaluates a tile as soon as another batch (up to 64 sources) might not fit; so does this one
-    // (KC = 1: identical tile boundaries).
+    // (identical tile boundaries).
     auto flush = [&]() __attribute__((always_inline)) {
         if (n_src > 0) {
             publish(false);
@@ -591,66 +553,58 @@ __global__ void __launch_bounds__(64 * (1 + KC),
 // ------------------------------------------------------------------------------------------------
 // Launch.
 // ------------------------------------------------------------------------------------------------
-template <typename F, int Q, int MAC, int KC>
+template <typename F, int Q, int MAC>
 static void launch_pc_qm(const rk_state &s, const kparams<F> &p, const int64_t cb[n_classes], const int64_t ce[n_classes],
-                         hipStream_t const streams[n_list_R])
+                         hipStream_t const streams[n_list_R], unsigned class_mask)
 {
     const auto *lists = s.cur_lists; // class lists of the state, or the launch plan of this call
     auto go = [&](auto Rtag, int c) {
         constexpr int R = decltype(Rtag)::value;
         const int64_t n = ce[c] - cb[c];
-        if (n <= 0) {
+        if (n <= 0 || !((class_mask >> c) & 1u)) {
             return;
         }
         const auto grid = static_cast<unsigned>(n);
         if (s.ndim == 3 || !RK_QUAD_BODY) {
-            hipLaunchKernelGGL((k_pc<F, Q, MAC, R, 3, KC>), dim3(grid), dim3(64 * (1 + KC)), 0, streams[c], p,
+            hipLaunchKernelGGL((k_pc<F, Q, MAC, R, 3>), dim3(grid), dim3(64 * (1 + R)), 0, streams[c], p,
                                lists + s.cur_off[c] + cb[c], static_cast<int>(n));
         } else {
-            hipLaunchKernelGGL((k_pc<F, Q, MAC, R, 2, KC>), dim3(grid), dim3(64 * (1 + KC)), 0, streams[c], p,
+            hipLaunchKernelGGL((k_pc<F, Q, MAC, R, 2>), dim3(grid), dim3(64 * (1 + R)), 0, streams[c], p,
                                lists + s.cur_off[c] + cb[c], static_cast<int>(n));
         }
     };
     static_assert(RK_MAX_R == 4, "the producer / consumer kernel is instantiated for R = 1..4");
+    // The classes with the longest serial chains first.
+    go(std::integral_constant<int, 4>{}, 3);
+    go(std::integral_constant<int, 2>{}, 1);
     go(std::integral_constant<int, 3>{}, 2);
     go(std::integral_constant<int, 1>{}, 0);
-    go(std::integral_constant<int, 2>{}, 1);
-    go(std::integral_constant<int, 4>{}, 3);
 }
 
 template <typename F>
-void launch_pc(const rk_state &s, int q, int kc, const kparams<F> &p, const int64_t cb[n_classes],
-               const int64_t ce[n_classes], hipStream_t const streams[n_list_R])
+void launch_pc(const rk_state &s, int q, const kparams<F> &p, const int64_t cb[n_classes], const int64_t ce[n_classes],
+               hipStream_t const streams[n_list_R], unsigned class_mask)
 {
     for (int c = RK_MAX_R; c < big_class; ++c) {
         if (ce[c] != cb[c]) {
             throw error(RK_ERUNTIME, "internal error: target group in a lane-mapping class beyond RK_MAX_R");
         }
     }
-    if (kc != 1 && kc != 2) {
-        throw error(RK_EINVAL, "invalid number of consumer waves");
-    }
-    switch ((q * 2 + s.mac) * 2 + (kc - 1)) {
-        case 0: launch_pc_qm<F, 0, 0, 1>(s, p, cb, ce, streams); break;
-        case 1: launch_pc_qm<F, 0, 0, 2>(s, p, cb, ce, streams); break;
-        case 2: launch_pc_qm<F, 0, 1, 1>(s, p, cb, ce, streams); break;
-        case 3: launch_pc_qm<F, 0, 1, 2>(s, p, cb, ce, streams); break;
-        case 4: launch_pc_qm<F, 1, 0, 1>(s, p, cb, ce, streams); break;
-        case 5: launch_pc_qm<F, 1, 0, 2>(s, p, cb, ce, streams); break;
-        case 6: launch_pc_qm<F, 1, 1, 1>(s, p, cb, ce, streams); break;
-        case 7: launch_pc_qm<F, 1, 1, 2>(s, p, cb, ce, streams); break;
-        case 8: launch_pc_qm<F, 2, 0, 1>(s, p, cb, ce, streams); break;
-        case 9: launch_pc_qm<F, 2, 0, 2>(s, p, cb, ce, streams); break;
-        case 10: launch_pc_qm<F, 2, 1, 1>(s, p, cb, ce, streams); break;
-        case 11: launch_pc_qm<F, 2, 1, 2>(s, p, cb, ce, streams); break;
+    switch (q * 2 + s.mac) {
+        case 0: launch_pc_qm<F, 0, 0>(s, p, cb, ce, streams, class_mask); break;
+        case 1: launch_pc_qm<F, 0, 1>(s, p, cb, ce, streams, class_mask); break;
+        case 2: launch_pc_qm<F, 1, 0>(s, p, cb, ce, streams, class_mask); break;
+        case 3: launch_pc_qm<F, 1, 1>(s, p, cb, ce, streams, class_mask); break;
+        case 4: launch_pc_qm<F, 2, 0>(s, p, cb, ce, streams, class_mask); break;
+        case 5: launch_pc_qm<F, 2, 1>(s, p, cb, ce, streams, class_mask); break;
         default: throw error(RK_EINVAL, "invalid q / mac combination");
     }
     RK_HIP(hipGetLastError());
 }
 
-template void launch_pc<float>(const rk_state &, int, int, const kparams<float> &, const int64_t[n_classes],
-                               const int64_t[n_classes], hipStream_t const[n_list_R]);
-template void launch_pc<double>(const rk_state &, int, int, const kparams<double> &, const int64_t[n_classes],
-                                const int64_t[n_classes], hipStream_t const[n_list_R]);
+template void launch_pc<float>(const rk_state &, int, const kparams<float> &, const int64_t[n_classes],
+                               const int64_t[n_classes], hipStream_t const[n_list_R], unsigned);
+template void launch_pc<double>(const rk_state &, int, const kparams<double> &, const int64_t[n_classes],
+                                const int64_t[n_classes], hipStream_t const[n_list_R], unsigned);
 
 } // namespace rk

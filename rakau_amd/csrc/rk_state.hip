@@ -899,18 +899,35 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                     RK_HIP(hipStreamWaitEvent(s.aux_stream[i], s.ev_fork, 0));
                 }
             }
-            // Variant 0 (automatic): trees with few critical nodes cannot fill the device with one wave per node; they
-            // get the producer + two consumers kernel (three waves per node, shorter serial chain per node). The choice
-            // depends on the TREE only (never on the range of the call), so every call on a state sums in the same order.
-            static const int64_t pc_max_crit = [] {
-                const char *e = std::getenv("RK_PC_MAX_CRIT");
-                return e ? std::atoll(e) : int64_t(10000);
+            // Variant 0 (automatic): a call over few critical nodes cannot fill the device with one wave per node, and
+            // ends with its longest serial chains running alone. Such calls hand lane-mapping classes to the producer /
+            // consumer kernel (1 + R waves per node): all of them below 5 000 critical nodes, the class with the longest
+            // chains (R = 2: 64 < T <= 128 targets on one wave) below 20 000. Both kernels give the same bits, so this is
+            // a pure scheduling decision (measured: tools/r02_job11.sh, r02_job12.sh).
+            static const int64_t pc_all_below = [] {
+                const char *e = std::getenv("RK_PC_ALL_BELOW");
+                return e ? std::atoll(e) : int64_t(5000);
             }();
-            const int kc = s.variant == 3 ? 1 : ((s.variant == 4 || (s.variant == 0 && s.n_crit <= pc_max_crit)) ? 2 : 0);
-            if (kc) {
-                rk::launch_pc<F>(s, q, kc, p, cb, ce, streams); // producer / consumer waves per group
-            } else {
-                rk::launch_list<F>(s, q, p, cb, ce, streams);
+            static const int64_t pc_r2_below = [] {
+                const char *e = std::getenv("RK_PC_R2_BELOW");
+                return e ? std::atoll(e) : int64_t(20000);
+            }();
+            static const int pc_mask_env = [] {
+                const char *e = std::getenv("RK_PC_MASK"); // experiment knob: bit c = class R = c + 1 on the P/C kernel
+                return e ? std::atoi(e) : -1;
+            }();
+            unsigned pc_mask = 0u;
+            if (s.variant == 3) {
+                pc_mask = pc_mask_env >= 0 ? static_cast<unsigned>(pc_mask_env) & 0xfu : 0xfu;
+            } else if (s.variant == 0) {
+                const int64_t ng = g_hi - g_lo;
+                pc_mask = ng <= pc_all_below ? 0xfu : (ng <= pc_r2_below ? 0x2u : 0u);
+            }
+            if (pc_mask) {
+                rk::launch_pc<F>(s, q, p, cb, ce, streams, pc_mask);
+            }
+            if (pc_mask != 0xfu) {
+                rk::launch_list<F>(s, q, p, cb, ce, streams, ~pc_mask);
             }
             if (!serial) {
                 for (int i = 0; i < rk::n_list_R - 1; ++i) {
@@ -1820,7 +1837,7 @@ int rk_device_memcpy(void *dst, const void *src, int64_t bytes, int device)
 int rk_set_kernel_variant(rk_state *s, int variant)
 {
     return guard([&] {
-        if (!s || variant < 0 || variant > 4) {
+        if (!s || variant < 0 || variant > 3) {
             throw rk::error(RK_EINVAL, "invalid kernel variant");
         }
         s->variant = variant;

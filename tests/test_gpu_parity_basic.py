@@ -1,4 +1,5 @@
-"""GPU parity: HIP path (through the C ABI) vs the CPU oracle on identical trees, both kernel variants."""
+"""GPU parity: HIP path (through the C ABI) vs the CPU oracle on identical trees, every kernel variant (1 = depth-first
+wave kernel, 2 = list kernel, 3 = producer / consumer kernel; 0 = automatic mixes 2 and 3 by launch size)."""
 import numpy as np
 import pytest
 
@@ -13,7 +14,7 @@ pytestmark = pytest.mark.gpu
 # fp64 <= 2e-11 (test/ordering_acc.cpp:94); identical lists deliver far better, so a tighter regression
 # bound is asserted (~1e-7 median, < 1e-5 max in fp32).
 TIGHT = {np.float32: 2e-5, np.float64: 1e-12}
-VARIANTS = [1, 2]
+VARIANTS = [1, 2, 3]
 
 
 def check(got, ref, q, dtype, tol=None):
@@ -97,3 +98,32 @@ def test_variants_agree_and_deterministic(variant):
     z0 = st.acc_pot(2, mv, G=0.0)
     for v in z0:
         assert np.all(v == 0)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_list_and_producer_consumer_kernels_give_the_same_bits(dtype):
+    """The producer / consumer kernel reproduces the list kernel's tiles, lane mapping and summation order: identical
+    results bit for bit, for every Q, with and without softening, on sub-ranges, for octrees and quadtrees -- which is
+    what allows the automatic variant to pick a kernel per lane-mapping class and per call by launch size alone."""
+    for n, ndim in ((40000, 3), (9000, 3), (20000, 2)):
+        if ndim == 3:
+            m, x, y, z = oracle.plummer(n, dtype)
+            ot = oracle.Tree(x, y, z, m, mac="bh_geom" if n == 9000 else "bh")
+        else:
+            m, x, y = oracle.Rng(4).uniform_particles(n, 3.0, dtype, ndim=2)
+            ot = oracle.Tree(x, y, None, m, ndim=2)
+        st = state_from_oracle(ot)
+        mv = mac_value_of(0.6, ot.mac, dtype)
+        cr = st.crit_ranges()
+        b, e = int(cr[len(cr) // 5, 0]), int(cr[4 * len(cr) // 5, 0])
+        for q in (0, 1, 2):
+            for eps2 in (0.0, 1e-5):
+                res = {}
+                for v in (2, 3, 0):
+                    st.set_variant(v)
+                    res[v] = (st.acc_pot(q, mv, eps2=eps2, G=1.25), st.acc_pot(q, mv, eps2=eps2, p_begin=b, p_end=e, offset_output=False))
+                for v in (3, 0):
+                    for full_a, full_b in zip(res[2][0], res[v][0]):
+                        assert np.array_equal(full_a, full_b), (n, ndim, q, eps2, v)
+                    for part_a, part_b in zip(res[2][1], res[v][1]):
+                        assert np.array_equal(part_a, part_b), (n, ndim, q, eps2, v)
