@@ -433,7 +433,7 @@ def main():
 def cpu_baseline(tree, m, x, y, z, mac, theta, eps, q, n, threads, gpu_outs, p_begin):
     """CPU baseline on the host cores of the GPU box, same inputs, same tree parameters:
     * `value`: the CPU engine of the C++ header (include/rakau_amd/cpu_engine.hpp: critical-node tasks on std::threads,
-      AVX2 batches of targets, fp32 rsqrt + Newton step -- a re-implementation of the reference's TBB + xsimd engine,
+      AVX-512 (where the CPU has it) or AVX2 batches of targets, fp32 rsqrt + Newton step -- a re-implementation of the reference's TBB + xsimd engine,
       which cannot be built here; it is also what the host share of kwargs::split runs), whole workload, best of 2;
     * `oracle_scalar_port`: the CPU oracle (scalar restatement of the reference's engine) on a bounded sample of
       critical nodes (~5 s), which is also the checker: parity of the timed GPU result and of the CPU engine against it."""
@@ -448,9 +448,11 @@ def cpu_baseline(tree, m, x, y, z, mac, theta, eps, q, n, threads, gpu_outs, p_b
         if ts[-1] > 15.0:
             break
     dt = min(ts)
-    out = {"value": round(n / dt / 1e6, 3), "unit": "Mparticles/s", "cores": threads, "kind": "port-simd",
+    from rakau_amd import _capi
+    isa = "AVX-512" if _capi.lib().rk_cpu_engine_run(None) == 0 else "AVX2"
+    out = {"value": round(n / dt / 1e6, 3), "unit": "Mparticles/s", "cores": threads, "kind": "port-simd", "isa": isa,
            "sample": "whole workload (%d particles), best of %d calls, %.2f s" % (n, len(ts), dt),
-           "note": "rakau_amd's own CPU engine (std::thread + AVX2, the engine behind split = {cpu, ...}); a re-implementation, "
+           "note": "rakau_amd's own CPU engine (std::thread + AVX-512 / AVX2 batches, the engine behind split = {cpu, ...}); a re-implementation, "
                    "not the reference's TBB + xsimd build (not buildable here); published reference figure: 48.8 Mparticles/s "
                    "on 2 x Xeon Gold 6148 (README.md:42-49)"}
     ot = oracle.Tree(x, y, z, m, mac=mac)

@@ -29,6 +29,7 @@
  *                                and update_particles_u of tree.hpp:1330-1487, 3678-3765), rk_state_download,
  *                                rk_state_tree_info, rk_state_device_ptr, rk_state_set_perm, rk_set_build_exact,
  *                                rk_pool_trim
+ *   CPU share of kwargs::split   rk_cpu_engine_run (AVX-512 flavour of the header's CPU engine, chosen at run time)
  *   diagnostics                  rk_state_info, rk_state_ndim, rk_last_kernel_ms, rk_count_interactions,
  *                                rk_set_kernel_variant
  *
@@ -260,6 +261,30 @@ RK_EXPORT int rk_count_interactions(rk_state *s, int64_t p_begin, int64_t p_end,
  * critical nodes: callers use it to cut shards / `split` fractions of equal work rather than equal particle counts
  * (the reference leaves the split vector to the user, tree.hpp:2853-2935). */
 RK_EXPORT int rk_group_work(rk_state *s, double mac_value, uint64_t *work);
+
+/*
+ * CPU engine hand-off (used by include/rakau_amd/tree.hpp for the CPU share of kwargs::split, tree.hpp:3047-3113 of the
+ * reference): the header's CPU engine is a template compiled with the CALLER's instruction-set flags. On a CPU with
+ * AVX-512 the library can run the same engine compiled for AVX-512 (a separate shared object next to librakau_amd.so,
+ * loaded on first use). rk_cpu_engine_run() returns RK_OK if it did the job, a negative value if no wider flavour is
+ * available (the caller then runs its own instantiation), a positive status code on error. A NULL job probes:
+ * RK_OK if the AVX-512 flavour is available.
+ * tree / crit: arrays of rakau::tree_node_t<ndim, F, UInt, MAC> / tree_cnode_t<F, UInt> (code_bits = 32 or 64);
+ * critical nodes [c_begin, c_end); parts: ndim coordinate arrays + masses (Morton order); out: full-size Morton-order
+ * result arrays; flavour: 0 = automatic, 2 = SIMD with sqrt + divide; nthreads > 0.
+ */
+typedef struct rk_cpu_job {
+    int q, ndim, fp, code_bits, mac, flavour;
+    unsigned nthreads;
+    const void *tree;
+    uint64_t tree_size;
+    const void *crit;
+    uint64_t c_begin, c_end;
+    const void *parts[4];
+    void *out[4];
+    double mac_value, G, eps2;
+} rk_cpu_job;
+RK_EXPORT int rk_cpu_engine_run(const rk_cpu_job *job);
 
 /* Select the traversal kernel: 0 = automatic (default: the producer / consumer kernel for calls over few critical nodes,
  * the list kernel otherwise), 1 = wave-per-group scalar DFS, 2 = LDS interaction-list kernel (one wave per critical

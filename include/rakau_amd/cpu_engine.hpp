@@ -33,6 +33,19 @@
 #if defined(__AVX2__) && defined(__FMA__)
 #include <immintrin.h>
 #define RAKAU_AMD_CPU_AVX2 1
+#if defined(__AVX512F__) && defined(__AVX512DQ__)
+#define RAKAU_AMD_CPU_AVX512 1
+#endif
+#endif
+// The engine's templates live in an inline namespace named after the instruction set they were compiled for, so that
+// objects built with different -m flags (the AVX-512 flavour of librakau_amd is a separate shared object) never share
+// a symbol.
+#if defined(RAKAU_AMD_CPU_AVX512)
+#define RAKAU_AMD_CPU_ISA isa_avx512
+#elif defined(RAKAU_AMD_CPU_AVX2)
+#define RAKAU_AMD_CPU_ISA isa_avx2
+#else
+#define RAKAU_AMD_CPU_ISA isa_generic
 #endif
 #if defined(__linux__)
 #include <sched.h>
@@ -82,6 +95,8 @@ inline unsigned usable_hw_threads()
 enum class cpu_flavour : int { automatic = 0, scalar = 1, simd_exact = 2 };
 
 namespace cpu
+{
+inline namespace RAKAU_AMD_CPU_ISA
 {
 
 // ---- batches of W targets --------------------------------------------------------------------------------------
@@ -281,10 +296,140 @@ struct batch<double, 4> {
 };
 #endif
 
+#if defined(RAKAU_AMD_CPU_AVX512)
+template <>
+struct batch<float, 16> {
+    static constexpr int size = 16;
+    __m512 v;
+    static batch load(const float *p)
+    {
+        return {_mm512_loadu_ps(p)};
+    }
+    static batch set1(float x)
+    {
+        return {_mm512_set1_ps(x)};
+    }
+    void store(float *p) const
+    {
+        _mm512_storeu_ps(p, v);
+    }
+    friend batch operator+(batch a, batch b)
+    {
+        return {_mm512_add_ps(a.v, b.v)};
+    }
+    friend batch operator-(batch a, batch b)
+    {
+        return {_mm512_sub_ps(a.v, b.v)};
+    }
+    friend batch operator*(batch a, batch b)
+    {
+        return {_mm512_mul_ps(a.v, b.v)};
+    }
+    friend batch operator/(batch a, batch b)
+    {
+        return {_mm512_div_ps(a.v, b.v)};
+    }
+    static batch fma(batch a, batch b, batch c)
+    {
+        return {_mm512_fmadd_ps(a.v, b.v, c.v)};
+    }
+    static batch fnma(batch a, batch b, batch c)
+    {
+        return {_mm512_fnmadd_ps(a.v, b.v, c.v)};
+    }
+    static batch sqrt(batch a)
+    {
+        return {_mm512_sqrt_ps(a.v)};
+    }
+    // vrsqrt14ps (14 bits) + one Newton step: the reference's AVX-512 fast path (detail/simd.hpp:110-146).
+    static batch rsqrt(batch a)
+    {
+        const __m512 y = _mm512_rsqrt14_ps(a.v);
+        const __m512 hx = _mm512_mul_ps(a.v, _mm512_set1_ps(0.5f));
+        const __m512 t = _mm512_fnmadd_ps(_mm512_mul_ps(hx, y), y, _mm512_set1_ps(1.5f));
+        return {_mm512_mul_ps(y, t)};
+    }
+    static bool any_ge(batch a, batch b)
+    {
+        return _mm512_cmp_ps_mask(a.v, b.v, _CMP_GE_OQ) != 0;
+    }
+    static batch select_index(batch a, batch other, std::size_t first, std::size_t j)
+    {
+        if (j < first || j >= first + 16u) {
+            return a;
+        }
+        return {_mm512_mask_blend_ps(static_cast<__mmask16>(1u << (j - first)), a.v, other.v)};
+    }
+};
+
+template <>
+struct batch<double, 8> {
+    static constexpr int size = 8;
+    __m512d v;
+    static batch load(const double *p)
+    {
+        return {_mm512_loadu_pd(p)};
+    }
+    static batch set1(double x)
+    {
+        return {_mm512_set1_pd(x)};
+    }
+    void store(double *p) const
+    {
+        _mm512_storeu_pd(p, v);
+    }
+    friend batch operator+(batch a, batch b)
+    {
+        return {_mm512_add_pd(a.v, b.v)};
+    }
+    friend batch operator-(batch a, batch b)
+    {
+        return {_mm512_sub_pd(a.v, b.v)};
+    }
+    friend batch operator*(batch a, batch b)
+    {
+        return {_mm512_mul_pd(a.v, b.v)};
+    }
+    friend batch operator/(batch a, batch b)
+    {
+        return {_mm512_div_pd(a.v, b.v)};
+    }
+    static batch fma(batch a, batch b, batch c)
+    {
+        return {_mm512_fmadd_pd(a.v, b.v, c.v)};
+    }
+    static batch fnma(batch a, batch b, batch c)
+    {
+        return {_mm512_fnmadd_pd(a.v, b.v, c.v)};
+    }
+    static batch sqrt(batch a)
+    {
+        return {_mm512_sqrt_pd(a.v)};
+    }
+    static batch rsqrt(batch a)
+    {
+        return {_mm512_div_pd(_mm512_set1_pd(1.), _mm512_sqrt_pd(a.v))};
+    }
+    static bool any_ge(batch a, batch b)
+    {
+        return _mm512_cmp_pd_mask(a.v, b.v, _CMP_GE_OQ) != 0;
+    }
+    static batch select_index(batch a, batch other, std::size_t first, std::size_t j)
+    {
+        if (j < first || j >= first + 8u) {
+            return a;
+        }
+        return {_mm512_mask_blend_pd(static_cast<__mmask8>(1u << (j - first)), a.v, other.v)};
+    }
+};
+#endif
+
 // Widest batch compiled in for F.
 template <typename F>
 inline constexpr int native_width =
-#if defined(RAKAU_AMD_CPU_AVX2)
+#if defined(RAKAU_AMD_CPU_AVX512)
+    std::is_same_v<F, float> ? 16 : 8;
+#elif defined(RAKAU_AMD_CPU_AVX2)
     std::is_same_v<F, float> ? 8 : 4;
 #else
     1;
@@ -592,7 +737,7 @@ inline void run(const Node *tree, std::size_t tree_size, const CNode *crit, std:
     if (c_begin >= c_end) {
         return;
     }
-    nthreads = nthreads ? nthreads : usable_hw_threads();
+    nthreads = nthreads ? nthreads : 1u; // resolved by the caller (tree.hpp: usable_hw_threads())
     nthreads = static_cast<unsigned>(std::min<std::size_t>(nthreads, (c_end - c_begin + 7u) / 8u));
     std::atomic<std::size_t> next(c_begin);
     std::exception_ptr ep;
@@ -645,6 +790,7 @@ inline void run(const Node *tree, std::size_t tree_size, const CNode *crit, std:
     }
 }
 
+} // namespace RAKAU_AMD_CPU_ISA
 } // namespace cpu
 } // namespace detail
 } // namespace rakau_amd

@@ -1397,6 +1397,29 @@ private:
         for (std::size_t j = 0; j < nvecs_res<Q>; ++j) {
             out[j] = res[j];
         }
+        nthreads = nthreads ? nthreads : usable_hw_threads();
+        if (flavour != detail::cpu_flavour::scalar && detail::cpu::native_width<F> * sizeof(F) < 64u) {
+            // This translation unit was not compiled for AVX-512: let the library run the engine's AVX-512 build if
+            // the CPU has it (same algorithm, wider batches).
+            rk_cpu_job job{};
+            job.q = static_cast<int>(Q), job.ndim = static_cast<int>(NDim), job.fp = std::is_same_v<F, float> ? RK_F32 : RK_F64;
+            job.code_bits = static_cast<int>(sizeof(UInt) * 8u), job.mac = MAC == mac::bh ? RK_MAC_BH : RK_MAC_BH_GEOM;
+            job.flavour = static_cast<int>(flavour), job.nthreads = nthreads;
+            job.tree = m_tree.data(), job.tree_size = m_tree.size();
+            job.crit = m_crit_nodes.data(), job.c_begin = 0, job.c_end = c_end;
+            for (std::size_t j = 0; j < NDim + 1u; ++j) {
+                job.parts[j] = parts[j];
+                job.out[j] = out[j];
+            }
+            job.mac_value = static_cast<double>(mac_value), job.G = static_cast<double>(G), job.eps2 = static_cast<double>(eps2);
+            const int rc = rk_cpu_engine_run(&job);
+            if (rc == RK_OK) {
+                return;
+            }
+            if (rc > 0) {
+                throw_status(rc);
+            }
+        }
         detail::cpu::run<Q, NDim, MAC == mac::bh>(m_tree.data(), m_tree.size(), m_crit_nodes.data(), std::size_t(0), c_end,
                                                   parts, out, mac_value, G, eps2, flavour, nthreads);
     }

@@ -25,7 +25,7 @@ SYMBOLS = [
     "rk_state_info", "rk_state_crit_ranges", "rk_acc_pot", "rk_acc_pot_device", "rk_last_kernel_ms", "rk_state_export",
     "rk_state_import", "rk_state_clone", "rk_set_kernel_variant", "rk_device_memcpy", "rk_count_interactions", "rk_state_build",
     "rk_state_tree_info", "rk_state_download", "rk_state_build_device", "rk_state_set_perm", "rk_state_device_ptr",
-    "rk_state_rebuild_device", "rk_pool_trim", "rk_set_build_exact", "rk_group_work", "rk_state_create_nd", "rk_state_build_nd",
+    "rk_state_rebuild_device", "rk_pool_trim", "rk_set_build_exact", "rk_cpu_engine_run", "rk_group_work", "rk_state_create_nd", "rk_state_build_nd",
     "rk_state_ndim",
     # host-side tree builder (include/rakau_amd_tree.h)
     "rk_tree_create", "rk_tree_create_nd", "rk_tree_destroy", "rk_tree_info", "rk_tree_get", "rk_tree_nodes", "rk_tree_state",
@@ -96,6 +96,7 @@ def lib():
     L.rk_state_create_nd.argtypes = [C.POINTER(vp), ci, ci, ci, ci, C.POINTER(vp), vp, i64, vp, i64, i64, u64]
     L.rk_state_build_nd.argtypes = [C.POINTER(vp), ci, ci, ci, ci, C.POINTER(vp), ci, i64, dbl, u64, u64]
     L.rk_state_ndim.argtypes = [vp]
+    L.rk_cpu_engine_run.argtypes = [vp]
     L.rk_set_build_exact.argtypes = [ci]
     L.rk_set_build_exact.restype = None
     L.rk_pool_trim.argtypes = []

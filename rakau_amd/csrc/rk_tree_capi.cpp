@@ -2,6 +2,8 @@
 #include "../../include/rakau_amd/tree.hpp"
 #include "../../include/rakau_amd_tree.h"
 
+#include <dlfcn.h>
+
 #include <variant>
 
 namespace
@@ -311,6 +313,46 @@ int rk_tree_acc_pot(const rk_tree *t, int q, int ordered, void *const *out, doub
             },
             t->t);
     });
+}
+
+// The CPU engine compiled for AVX-512 lives in its own shared object next to this library (rk_cpu_engine.cpp); it is
+// loaded on first use, and only on CPUs that have AVX-512F + DQ + VL. RAKAU_AMD_CPU_ISA=avx2 keeps the caller's flavour.
+int rk_cpu_engine_run(const rk_cpu_job *job)
+{
+    using entry_t = int (*)(const rk_cpu_job *);
+    static const entry_t entry = []() -> entry_t {
+        const char *e = std::getenv("RAKAU_AMD_CPU_ISA");
+        if (e && std::string(e) != "avx512") {
+            return nullptr;
+        }
+        __builtin_cpu_init();
+        if (!__builtin_cpu_supports("avx512f") || !__builtin_cpu_supports("avx512dq") || !__builtin_cpu_supports("avx512vl")) {
+            return nullptr;
+        }
+        Dl_info info;
+        if (!dladdr(reinterpret_cast<const void *>(&rk_cpu_engine_run), &info) || !info.dli_fname) {
+            return nullptr;
+        }
+        std::string path(info.dli_fname);
+        const auto slash = path.find_last_of('/');
+        path = (slash == std::string::npos ? std::string() : path.substr(0, slash + 1)) + "librakau_amd_cpu512.so";
+        void *h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!h) {
+            return nullptr;
+        }
+        return reinterpret_cast<entry_t>(dlsym(h, "rk_cpu_engine_entry"));
+    }();
+    if (!entry) {
+        return -1;
+    }
+    if (!job) {
+        return RK_OK; // probe: the AVX-512 flavour is available
+    }
+    const int rc = entry(job);
+    if (rc != RK_OK) {
+        rk_set_last_error_("the AVX-512 flavour of the CPU engine failed");
+    }
+    return rc;
 }
 
 int rk_tree_cpu_acc_pot(const rk_tree *t, int q, void *const *out, double theta, double G, double eps, int flavour,

@@ -6,12 +6,17 @@ kwargs::split (tree.hpp:3047-3113 of the reference) and bench.py's cpu_baseline.
    or rsqrt + one Newton step for fp32 ('auto', the reference's AVX fast path, detail/simd.hpp:76-146) -> rounding level;
  * split = {1} (the reference's "CPU only") goes through the public acc/pot surface; the default split needs the GPU and
    fails loudly without one."""
+import os
+
 import numpy as np
 import pytest
 
 import oracle
 import rakau_amd
 from helpers import rel_err, rel_err_vec
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def no_gpu():
@@ -128,3 +133,24 @@ def test_public_surface_split_one_is_the_cpu_engine():
             t.accs_u(0.75)
         with pytest.raises((RuntimeError, ValueError)):
             t.accs_u(0.75, split=[0.5, 0.5])
+
+
+def test_avx512_flavour_equals_the_avx2_flavour_bit_for_bit():
+    """On a CPU with AVX-512 the library runs the engine's AVX-512 build (librakau_amd_cpu512.so, rk_cpu_engine_run). A
+    lane is a target whatever the batch width, so with sqrt + divide arithmetic the two builds must agree bit for bit;
+    with RAKAU_AMD_CPU_ISA=avx2 (read once per process, hence the subprocess) the hand-off is disabled."""
+    import subprocess
+    import sys
+    import tempfile
+    script = (
+        "import sys, numpy as np; sys.path.insert(0, %r); import oracle, rakau_amd\n"
+        "m, x, y, z = oracle.plummer(20000, np.float64)\n"
+        "t = rakau_amd.Octree(x, y, z, m)\n"
+        "np.save(sys.argv[1], np.stack(t.cpu_acc_pot_u(2, 0.6, eps=1e-3, flavour='simd_exact')))\n" % ROOT)
+    res = {}
+    for isa in ("avx512", "avx2"):
+        with tempfile.NamedTemporaryFile(suffix=".npy") as f:
+            env = dict(os.environ, RAKAU_AMD_CPU_ISA=isa)
+            subprocess.run([sys.executable, "-c", script, f.name], check=True, env=env, timeout=300)
+            res[isa] = np.load(f.name)
+    assert np.array_equal(res["avx512"], res["avx2"])
