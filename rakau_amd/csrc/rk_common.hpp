@@ -224,6 +224,7 @@ struct rk_state {
     // hipGraph of the launch sequence of the last call (replayed when a call repeats it).
     struct graph_key {
         int q, offset_output, super_k, variant;
+        int with_super, pad; // whether the captured sequence starts with the supergroup pre-pass
         int64_t p_begin, p_end;
         double mac_value, G, eps2;
         void *out[4];
@@ -255,6 +256,11 @@ struct rk_state {
     // Scratch of the supergroup pre-pass (allocated on first use).
     void *sup_common = nullptr, *sup_resid = nullptr, *sup_cnt = nullptr;
     int64_t sup_alloc = 0; // number of supergroups the scratch was sized for
+    // What the scratch currently holds: the pre-pass output depends on the tree and the MAC value only, so a call that
+    // repeats (or follows: accs_u then pots_u) another one on the same tree reuses it instead of running k_super again.
+    double sup_mac = 0.;
+    int64_t sup_b = 0, sup_e = 0; // supergroups [sup_b, sup_e) are valid for sup_mac (empty: nothing cached)
+    hipEvent_t sup_ev = nullptr;  // recorded after the last k_super
     int super_k = -1;      // -1 = not initialised (read RK_SUPER_K, default 8)
     // Filled by the device-side tree build (rk_state_build); null for states created from a host tree.
     void *bld_codes = nullptr;     // uint64 sorted Morton codes [nparts]

@@ -116,6 +116,7 @@ void release_tree(rk_state *s)
     }
     s->plan = rk_state::launch_plan{};
     s->work_cache.clear();
+    s->sup_b = s->sup_e = 0;
     if (s->graph_exec) {
         (void)hipGraphExecDestroy(s->graph_exec);
         s->graph_exec = nullptr;
@@ -146,6 +147,9 @@ void free_state(rk_state *s)
     }
     if (s->ev_fork) {
         (void)hipEventDestroy(s->ev_fork);
+    }
+    if (s->sup_ev) {
+        (void)hipEventDestroy(s->sup_ev);
     }
     if (s->cap_stream) {
         (void)hipStreamDestroy(s->cap_stream);
@@ -700,6 +704,11 @@ void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64
         RK_HIP(hipMemcpy(s.plan.d_lists, lists.data(), lists.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     s.plan.p_begin = p_begin, s.plan.p_end = p_end, s.plan.mac_value = mac_value;
+    // A captured launch sequence may hold the plan buffer with its previous contents.
+    if (s.graph_exec) {
+        (void)hipGraphExecDestroy(s.graph_exec);
+        s.graph_exec = nullptr;
+    }
 }
 
 template <typename F>
@@ -819,6 +828,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                     *b = nullptr;
                 }
                 s.sup_alloc = 0;
+                s.sup_b = s.sup_e = 0;
                 s.sup_common = rk::pool_alloc(static_cast<size_t>(n_super) * rk::SUP_CAPC * sizeof(typename rk::vt<F>::v4));
                 s.sup_resid = rk::pool_alloc(static_cast<size_t>(n_super) * rk::SUP_CAPR * sizeof(uint32_t));
                 s.sup_cnt = rk::pool_alloc(static_cast<size_t>(n_super) * sizeof(uint2));
@@ -885,9 +895,24 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
         // The launch sequence of one call: pre-pass, then the per-class kernels forked onto side streams (so that
         // the tail of one overlaps the others), joined back, then the big-group fallback. Stream-ordered work only,
         // so it can be recorded into a hipGraph.
+        // Supergroup pre-pass: skipped when the scratch already holds these supergroups for this MAC value.
+        const int64_t sb = (p.super_k && g_hi > g_lo) ? g_lo / s.super_k : 0,
+                      se = (p.super_k && g_hi > g_lo) ? (g_hi - 1) / s.super_k + 1 : 0;
+        static const bool sup_cache = [] {
+            const char *e = std::getenv("RK_SUPER_CACHE"); // 0 disables the reuse
+            return !(e && std::atoi(e) == 0);
+        }();
+        const bool need_super = se > sb && !(sup_cache && s.sup_mac == mac_value && s.sup_b <= sb && se <= s.sup_e);
+        if (!s.sup_ev) {
+            RK_HIP(hipEventCreateWithFlags(&s.sup_ev, hipEventDisableTiming));
+        }
+        if (se > sb && !need_super) {
+            // The pre-pass that produced the lists may have run on another stream.
+            RK_HIP(hipStreamWaitEvent(stream, s.sup_ev, 0));
+        }
         auto enqueue = [&](hipStream_t st) {
-            if (p.super_k && g_hi > g_lo) {
-                rk::launch_super<F>(s, p, g_lo / s.super_k, (g_hi - 1) / s.super_k + 1, st);
+            if (need_super) {
+                rk::launch_super<F>(s, p, sb, se, st);
             }
             hipStream_t streams[rk::n_list_R];
             for (int i = 0; i < rk::n_list_R; ++i) {
@@ -946,6 +971,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
             rk_state::graph_key key{};
             key.q = q, key.p_begin = p_begin, key.p_end = p_end, key.mac_value = mac_value, key.G = G, key.eps2 = eps2;
             key.offset_output = offset_output, key.super_k = s.super_k, key.variant = s.variant;
+            key.with_super = need_super ? 1 : 0;
             for (int k = 0; k < rk::nres_of(q); ++k) {
                 key.out[k] = d_out[k];
             }
@@ -988,6 +1014,15 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
         }
     } else {
         rk::launch_traversal<F>(s, q, p, cb, ce, stream);
+    }
+    if (v2 && p.super_k && g_hi > g_lo) {
+        const int64_t sb2 = g_lo / s.super_k, se2 = (g_hi - 1) / s.super_k + 1;
+        if (s.sup_mac == mac_value && s.sup_e > s.sup_b && sb2 <= s.sup_e && s.sup_b <= se2) {
+            s.sup_b = std::min(s.sup_b, sb2), s.sup_e = std::max(s.sup_e, se2); // overlapping or adjacent: the union
+        } else if (!(s.sup_mac == mac_value && s.sup_b <= sb2 && se2 <= s.sup_e)) {
+            s.sup_mac = mac_value, s.sup_b = sb2, s.sup_e = se2;
+        }
+        RK_HIP(hipEventRecord(s.sup_ev, stream));
     }
     RK_HIP(hipEventRecord(s.ev1, stream));
     s.timed = true;
