@@ -469,9 +469,9 @@ __global__ void k_up_sums(const uint4 *topo, const uint64_t *ncode, uint32_t n_n
 // starts at the node's first particle, so the node's running sum after the first child's particles IS the first
 // child's sum: a node continues from there over its remaining particles, one fused multiply-add per particle and
 // component, in order. Identical bits to the host builders, at the price of serial chains (the root's is N long).
-constexpr uint32_t EXACT_WAVE_MIN = 256; // remaining particles from which a node gets a wavefront of its own
+constexpr uint32_t EXACT_WAVE_MIN = 1024; // remaining particles from which a node gets a workgroup of its own
 
-// Nodes with few remaining particles: one thread per node.
+// Nodes with fewer remaining particles: one thread per node.
 template <typename F, int ND>
 __global__ void k_up_sums_exact(const uint4 *topo, const uint64_t *ncode, uint32_t n_nodes, unsigned lvl,
                                 const typename vt<F>::v4 *part4, typename vt<F>::v4 *sums)
@@ -507,20 +507,22 @@ __global__ void k_exact_big_list(const uint4 *topo, uint32_t n_nodes, uint32_t *
     }
 }
 
-// One wavefront per listed node of level lvl. Lane j < 4 carries component j of the sums {m x, m y, m z, m}: every
-// particle costs ONE dependent fused multiply-add per lane (the mass sum is fma(m, 1, sum) = m + sum exactly). The
-// particles travel through LDS in chunks of 256, stored component-major so that one 16-byte LDS read brings the next
-// four operands of a lane's chain; the next chunk's global loads are in flight while this one is consumed.
+// One workgroup (4 wavefronts) per listed node of level lvl. The chain itself is serial: lanes 0-3 of wave 0 carry the
+// four sums {m x, m y, m z, m}, one dependent fused multiply-add per particle and lane (the mass sum is fma(m, 1, sum) =
+// m + sum exactly). Everything else feeds it: all 256 threads load the NEXT super-chunk of 2048 particles (8 per
+// thread, coalesced) into registers while wave 0 consumes the current one from LDS (component-major rows, one 16-byte
+// LDS read per four operands), then the registers go to the other LDS buffer. The loads of 2048 particles are in
+// flight during the ~7 us the chain needs for 2048 particles, so the chain never waits for memory.
 template <typename F, int ND>
 __global__ void __launch_bounds__(256) k_up_sums_exact_wave(const uint4 *topo, const uint64_t *ncode, const uint32_t *list,
                                                             const uint32_t *count, unsigned lvl,
                                                             const typename vt<F>::v4 *part4, typename vt<F>::v4 *sums)
 {
     using v4 = typename vt<F>::v4;
-    constexpr uint32_t CH = 256;
-    __shared__ __attribute__((aligned(32))) F s_tile[4][5][CH]; // rows: m x, m y, m z operands (x, y, z), m, ones
-    const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t e = blockIdx.x * 4u + static_cast<uint32_t>(wib);
+    constexpr uint32_t SC = 2048; // particles per super-chunk
+    __shared__ __attribute__((aligned(32))) F s_tile[2][4][SC]; // per buffer: rows x, y, z, m
+    __shared__ __attribute__((aligned(32))) F s_ones[8];
+    const uint32_t e = blockIdx.x;
     if (e >= *count) {
         return;
     }
@@ -528,62 +530,69 @@ __global__ void __launch_bounds__(256) k_up_sums_exact_wave(const uint4 *topo, c
     if (level_of<ND>(ncode[k]) != lvl) {
         return;
     }
-    F(*tile)[CH] = s_tile[wib];
-    for (uint32_t j = static_cast<uint32_t>(lane); j < CH; j += 64u) {
-        tile[4][j] = F(1);
+    const int tid = static_cast<int>(threadIdx.x), lane = tid & 63;
+    if (tid < 8) {
+        s_ones[tid] = F(1);
     }
     const uint32_t start = topo[k + 1u].z, end = topo[k].z;
     const int comp = lane & 3;
-    const F *row_c = tile[comp == 3 ? 4 : comp], *row_m = tile[3];
     F sum = reinterpret_cast<const F *>(&sums[k + 1u])[comp];
-    v4 nxt[4];
+    v4 nxt[8];
     auto fetch = [&](uint32_t base) {
 #pragma unroll
-        for (uint32_t u = 0; u < 4u; ++u) {
-            const uint32_t i = base + u * 64u + static_cast<uint32_t>(lane);
+        for (uint32_t u = 0; u < 8u; ++u) {
+            const uint32_t i = base + u * 256u + static_cast<uint32_t>(tid);
             nxt[u] = part4[i < end ? i : end - 1u];
         }
     };
-    // LDS operations of one wavefront execute in order: what the lanes exchange through the tile only needs the compiler
-    // to keep the program order (and must NOT wait for the global loads of the next chunk, which a memory fence would).
-    const auto sync = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
-    fetch(start);
-    for (uint32_t base = start; base < end; base += CH) {
+    auto stash = [&](int buf) {
 #pragma unroll
-        for (uint32_t u = 0; u < 4u; ++u) {
-            const uint32_t j = u * 64u + static_cast<uint32_t>(lane);
-            tile[0][j] = nxt[u].x, tile[1][j] = nxt[u].y, tile[2][j] = nxt[u].z, tile[3][j] = nxt[u].w;
+        for (uint32_t u = 0; u < 8u; ++u) {
+            const uint32_t j = u * 256u + static_cast<uint32_t>(tid);
+            s_tile[buf][0][j] = nxt[u].x, s_tile[buf][1][j] = nxt[u].y, s_tile[buf][2][j] = nxt[u].z, s_tile[buf][3][j] = nxt[u].w;
         }
-        if (base + CH < end) {
-            fetch(base + CH);
+    };
+    fetch(start);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (uint32_t base = start; base < end; base += SC, buf ^= 1) {
+        const bool more = base + SC < end;
+        if (more) {
+            fetch(base + SC); // in flight while wave 0 walks the chain
         }
-        sync();
-        const uint32_t cnt = end - base < CH ? end - base : CH, cnt8 = cnt & ~7u;
-        // The operands of the next eight particles are read from LDS while the eight dependent multiply-adds of the
-        // current ones execute.
-        v4 m0 = *reinterpret_cast<const v4 *>(row_m), m1 = *reinterpret_cast<const v4 *>(row_m + 4u);
-        v4 c0 = *reinterpret_cast<const v4 *>(row_c), c1 = *reinterpret_cast<const v4 *>(row_c + 4u);
-        for (uint32_t i = 0; i < cnt8; i += 8u) {
-            const uint32_t nx = i + 8u < CH ? i + 8u : i; // stays inside the tile
-            const v4 nm0 = *reinterpret_cast<const v4 *>(row_m + nx), nm1 = *reinterpret_cast<const v4 *>(row_m + nx + 4u);
-            const v4 nc0 = *reinterpret_cast<const v4 *>(row_c + nx), nc1 = *reinterpret_cast<const v4 *>(row_c + nx + 4u);
-            sum = d_fma(m0.x, c0.x, sum);
-            sum = d_fma(m0.y, c0.y, sum);
-            sum = d_fma(m0.z, c0.z, sum);
-            sum = d_fma(m0.w, c0.w, sum);
-            sum = d_fma(m1.x, c1.x, sum);
-            sum = d_fma(m1.y, c1.y, sum);
-            sum = d_fma(m1.z, c1.z, sum);
-            sum = d_fma(m1.w, c1.w, sum);
-            m0 = nm0, m1 = nm1, c0 = nc0, c1 = nc1;
+        if (tid < 64) {
+            const uint32_t cnt = end - base < SC ? end - base : SC, cnt8 = cnt & ~7u;
+            const F *row_m = s_tile[buf][3];
+            // The mass chain multiplies by one: its "coordinate" row is a row of ones (re-read, never advanced).
+            const F *row_c = comp == 3 ? s_ones : s_tile[buf][comp];
+            const uint32_t cstep = comp == 3 ? 0u : 1u;
+            // (Reading the operands of the NEXT eight particles ahead into registers was measured twice and is slower:
+            // 98 ms instead of 58 ms for the 4M build.)
+            for (uint32_t i = 0; i < cnt8; i += 8u) {
+                const v4 m0 = *reinterpret_cast<const v4 *>(row_m + i), m1 = *reinterpret_cast<const v4 *>(row_m + i + 4u);
+                const v4 c0 = *reinterpret_cast<const v4 *>(row_c + cstep * i),
+                         c1 = *reinterpret_cast<const v4 *>(row_c + cstep * i + 4u);
+                sum = d_fma(m0.x, c0.x, sum);
+                sum = d_fma(m0.y, c0.y, sum);
+                sum = d_fma(m0.z, c0.z, sum);
+                sum = d_fma(m0.w, c0.w, sum);
+                sum = d_fma(m1.x, c1.x, sum);
+                sum = d_fma(m1.y, c1.y, sum);
+                sum = d_fma(m1.z, c1.z, sum);
+                sum = d_fma(m1.w, c1.w, sum);
+            }
+            for (uint32_t i = cnt8; i < cnt; ++i) {
+                sum = d_fma(row_m[i], comp == 3 ? F(1) : row_c[i], sum);
+            }
         }
-        for (uint32_t i = cnt8; i < cnt; ++i) {
-            sum = d_fma(row_m[i], row_c[i], sum);
+        if (more) {
+            stash(buf ^ 1); // the other buffer was consumed one iteration ago
         }
-        sync();
+        __syncthreads();
     }
-    if (lane < 4) {
-        reinterpret_cast<F *>(&sums[k])[lane] = sum;
+    if (tid < 4) {
+        reinterpret_cast<F *>(&sums[k])[tid] = sum;
     }
 }
 
@@ -1028,7 +1037,7 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
             hipLaunchKernelGGL((k_up_sums_exact<F, ND>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode,
                                static_cast<uint32_t>(nn), static_cast<unsigned>(lvl), static_cast<const v4 *>(p4), sums.get());
             // Per level the listed nodes are disjoint in particles: at most n / EXACT_WAVE_MIN of them exist.
-            hipLaunchKernelGGL((k_up_sums_exact_wave<F, ND>), dim3((std::min<unsigned>(max_big, static_cast<unsigned>(nn)) + 3u) / 4u),
+            hipLaunchKernelGGL((k_up_sums_exact_wave<F, ND>), dim3(std::min<unsigned>(max_big, static_cast<unsigned>(nn))),
                                dim3(256), 0, st, topo, ncode, big.get(), big.get() + nn, static_cast<unsigned>(lvl),
                                static_cast<const v4 *>(p4), sums.get());
         }
