@@ -56,3 +56,21 @@ def test_two_ranks_one_gpu(launcher, scaling):
         assert 1218.45 < d["interactions_per_particle"] < 1500
         assert "200k Plummer" in d["metric"] and "200k-particle" in d["config"]["workload"]
     assert "across 2 GPUs" in d["config"]["workload"]
+
+
+def test_shard_union_through_the_product():
+    """Two ranks (gloo, sharing the GPU): replicate the state as bench.py does, traverse one Morton shard each through
+    the C ABI, and compare the union of the shards with the full-range result on rank 0 -- bit for bit, compact host
+    outputs and ordered device outputs (tests/multirank_product_worker.py)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multirank_product_worker.py"), "300000"],
+                                      env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[1][-1500:] for o in outs)
+    assert "SHARD_UNION_EQUALS_FULL True ORDERED True" in outs[0][0], outs[0][0]
