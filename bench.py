@@ -416,9 +416,24 @@ def main():
                 state.acc_pot(q, mac_value, eps2=eps2, out=host_out)
                 ts.append(time.perf_counter() - t0)
             t_host = float(np.median(ts[2:]))
+            line["host"]["kernel_ms_host_outputs"] = round(state.last_kernel_ms(), 4)
             line["host"]["acc_pot_host_outputs_ms"] = round(t_host * 1e3, 3)
             line["value_host_outputs"] = round(n / t_host / 1e6, 2)
             line["ms_per_call_host_outputs"] = round(t_host * 1e3, 4)
+            # Same call, output arrays in pinned host memory (rk_host_alloc / rakau_amd::pinned_allocator): the kernels
+            # write the results into the caller's arrays themselves.
+            pin_out = [rakau_amd.pinned_empty(n, dtype) for _ in range(nres)]
+            ts = []
+            for _ in range(7):
+                t0 = time.perf_counter()
+                state.acc_pot(q, mac_value, eps2=eps2, out=pin_out)
+                ts.append(time.perf_counter() - t0)
+            t_pin = float(np.median(ts[2:]))
+            line["host"]["kernel_ms_pinned_outputs"] = round(state.last_kernel_ms(), 4)
+            line["value_host_outputs_pinned"] = round(n / t_pin / 1e6, 2)
+            line["ms_per_call_host_outputs_pinned"] = round(t_pin * 1e3, 4)
+            line["host"]["pinned_equals_pageable"] = bool(all(np.array_equal(a, b) for a, b in zip(host_out, pin_out)))
+            del pin_out
     except Exception as e:  # pragma: no cover
         line["host"]["acc_pot_host_outputs_error"] = str(e)
 

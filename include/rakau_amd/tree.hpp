@@ -52,6 +52,43 @@ namespace rakau_amd
 // Multipole acceptance criteria (tree_fwd.hpp:46).
 enum class mac { bh, bh_geom };
 
+// Allocator for output vectors in pinned host memory (rk_host_alloc): with
+//     std::array<std::vector<float, rakau_amd::pinned_allocator<float>>, 3> accs;  t.accs_u(accs, theta);
+// -- the `std::vector<F, Allocator>` overloads of the reference's API, tree.hpp:3406-3497 -- the kernels write the
+// results into the vectors themselves instead of a staging buffer that host threads then copy (rakau_amd.h).
+template <typename T>
+struct pinned_allocator {
+    using value_type = T;
+    pinned_allocator() = default;
+    template <typename U>
+    pinned_allocator(const pinned_allocator<U> &) noexcept
+    {
+    }
+    T *allocate(std::size_t n)
+    {
+        void *p = nullptr;
+        if (n > static_cast<std::size_t>(std::numeric_limits<std::int64_t>::max()) / sizeof(T)
+            || rk_host_alloc(&p, static_cast<std::int64_t>(n * sizeof(T))) != RK_OK || (n && !p)) {
+            throw std::bad_alloc();
+        }
+        return static_cast<T *>(p);
+    }
+    void deallocate(T *p, std::size_t) noexcept
+    {
+        (void)rk_host_free(p);
+    }
+    template <typename U>
+    bool operator==(const pinned_allocator<U> &) const noexcept
+    {
+        return true;
+    }
+    template <typename U>
+    bool operator!=(const pinned_allocator<U> &) const noexcept
+    {
+        return false;
+    }
+};
+
 inline namespace detail
 {
 

@@ -4,9 +4,8 @@ The package holds only what the hot path needs: ``csrc/`` (hand-written HIP kern
 C ABI of ``include/rakau_amd.h``), ``lib/`` (the built ``librakau_amd.so``) and thin ctypes plumbing.
 """
 from . import _capi
-from .state import State, node_dtype, mac_value_of, NRES, nres
+from .state import State, node_dtype, mac_value_of, NRES, nres, pinned_empty
 from .tree import Octree, Quadtree
-
 
 
 def set_build_exact(on=True):
@@ -14,4 +13,4 @@ def set_build_exact(on=True):
     _capi.lib().rk_set_build_exact(int(bool(on)))
 
 
-__all__ = ["set_build_exact", "State", "Octree", "Quadtree", "node_dtype", "mac_value_of", "NRES", "nres"]
+__all__ = ["set_build_exact", "pinned_empty", "State", "Octree", "Quadtree", "node_dtype", "mac_value_of", "NRES", "nres"]

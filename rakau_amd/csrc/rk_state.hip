@@ -1208,6 +1208,57 @@ int rk_state_crit_ranges(const rk_state *s, int64_t *begin_end)
     });
 }
 
+namespace
+{
+
+// Device-side address of [p, p + bytes) if the whole range is host memory the device can write to (hipHostMalloc /
+// hipHostRegister: rk_host_alloc(), a pinned torch tensor, a user's registered vector), nullptr for pageable memory.
+void *device_view_of_host_range(void *p, size_t bytes)
+{
+    if (!p || !bytes) {
+        return nullptr;
+    }
+    hipPointerAttribute_t a0{}, a1{};
+    if (hipPointerGetAttributes(&a0, p) != hipSuccess
+        || hipPointerGetAttributes(&a1, static_cast<unsigned char *>(p) + bytes - 1u) != hipSuccess) {
+        (void)hipGetLastError(); // pageable memory is reported as an error: clear it
+        return nullptr;
+    }
+    if (a0.type != hipMemoryTypeHost || a1.type != hipMemoryTypeHost || !a0.devicePointer || !a1.devicePointer) {
+        return nullptr;
+    }
+    // One registration: the device view is contiguous over the range.
+    if (static_cast<unsigned char *>(a1.devicePointer) - static_cast<unsigned char *>(a0.devicePointer)
+        != static_cast<ptrdiff_t>(bytes - 1u)) {
+        return nullptr;
+    }
+    return a0.devicePointer;
+}
+
+} // namespace
+
+int rk_host_alloc(void **ptr, int64_t bytes)
+{
+    return guard([&] {
+        if (!ptr || bytes < 0) {
+            throw rk::error(RK_EINVAL, "rk_host_alloc: null pointer or negative size");
+        }
+        *ptr = nullptr;
+        if (bytes) {
+            RK_HIP(hipHostMalloc(ptr, static_cast<size_t>(bytes), hipHostMallocPortable));
+        }
+    });
+}
+
+int rk_host_free(void *ptr)
+{
+    return guard([&] {
+        if (ptr) {
+            RK_HIP(hipHostFree(ptr));
+        }
+    });
+}
+
 int rk_acc_pot_device(rk_state *s, int q, int64_t p_begin, int64_t p_end, void *const *d_out, double mac_value,
                       double G, double eps2, int offset_output, void *hip_stream)
 {
@@ -1262,6 +1313,29 @@ int rk_acc_pot(rk_state *s, int q, int64_t p_begin, int64_t p_end, void *const *
         unsigned char *dst[4] = {};
         for (int k = 0; k < nres; ++k) {
             dst[k] = static_cast<unsigned char *>(out[k]) + (offset_output ? static_cast<size_t>(p_begin) * fsz : 0);
+        }
+        // Output arrays in pinned host memory (rk_host_alloc(), rakau_amd::pinned_allocator, hipHostRegister): the kernels
+        // write the results where the caller wants them, nothing is staged or copied.
+        {
+            static const bool direct = [] {
+                const char *e = std::getenv("RK_HOST_DIRECT"); // 0: treat pinned arrays like pageable ones
+                return !(e && std::atoi(e) == 0);
+            }();
+            void *v_ptrs[4] = {};
+            bool all = direct;
+            for (int k = 0; all && k < nres; ++k) {
+                v_ptrs[k] = device_view_of_host_range(dst[k], count * fsz);
+                all = v_ptrs[k] != nullptr;
+            }
+            if (all) {
+                if (s->fp == RK_F32) {
+                    run_impl<float>(*s, q, p_begin, p_end, v_ptrs, mac_value, G, eps2, 0, nullptr, false);
+                } else {
+                    run_impl<double>(*s, q, p_begin, p_end, v_ptrs, mac_value, G, eps2, 0, nullptr, false);
+                }
+                RK_HIP(hipEventSynchronize(s->ev1));
+                return;
+            }
         }
         if (need < (size_t(1) << 20)) {
             if (s->fp == RK_F32) {

@@ -39,6 +39,33 @@ def mac_value_of(theta, mac, dtype):
     return float(one / (t * t)) if mac == "bh" else float(one / t)
 
 
+class _PinnedBlock:
+    """Owner of one rk_host_alloc() block (freed when the last numpy view of it dies)."""
+
+    def __init__(self, nbytes):
+        p = C.c_void_p()
+        _capi.check(_capi.lib().rk_host_alloc(C.byref(p), nbytes))
+        self.ptr, self.nbytes = p.value, nbytes
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                _capi.lib().rk_host_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def pinned_empty(n, dtype):
+    """A numpy array of n elements in pinned host memory (rk_host_alloc): as an output of State.acc_pot() / rk_acc_pot()
+    it receives the results straight from the kernels (no staging copy)."""
+    dtype = np.dtype(dtype)
+    blk = _PinnedBlock(max(int(n), 1) * dtype.itemsize)
+    buf = (C.c_char * blk.nbytes).from_address(blk.ptr)
+    buf._rk_owner = blk  # the ctypes object is the array's base: keeps the block alive
+    return np.frombuffer(buf, dtype=dtype, count=int(n))
+
+
 class State:
     """z = None selects the 2-dimensional (quadtree) variant everywhere: coordinates are then x, y."""
 
@@ -181,7 +208,8 @@ class State:
         _capi.check(_capi.lib().rk_set_kernel_variant(self._h, v))
 
     def acc_pot(self, q, mac_value, G=1.0, eps2=0.0, p_begin=0, p_end=None, out=None, offset_output=True):
-        """rocm_state::acc_pot<Q>: host outputs (numpy). Returns the list of output arrays."""
+        """rocm_state::acc_pot<Q>: host outputs (numpy). Returns the list of output arrays. Arrays in pinned memory
+        (pinned_empty()) are written by the kernels directly."""
         p_end = self.nparts if p_end is None else p_end
         if out is None:
             n = self.nparts if offset_output else p_end - p_begin

@@ -452,6 +452,44 @@ static void narrow_code_checks(bool gpu)
     }
 }
 
+// Output vectors with rakau_amd::pinned_allocator (the `std::vector<F, Allocator>` overloads, tree.hpp:3406-3497 of the
+// reference): the kernels write into them directly; the results are the bits of the pageable path.
+template <typename F>
+static void pinned_output_checks()
+{
+    std::mt19937 rng(11);
+    const std::size_t s = 300000;
+    std::vector<F> m(s), x(s), y(s), z(s);
+    std::uniform_real_distribution<F> md(F(0.1), F(1)), rd(F(-0.5), F(0.5));
+    for (std::size_t i = 0; i < s; ++i) m[i] = md(rng), x[i] = rd(rng), y[i] = rd(rng), z[i] = rd(rng);
+    octree<F, mac::bh> t{x_coords = x, y_coords = y, z_coords = z, masses = m, box_size = F(1)};
+    using pvec = std::vector<F, pinned_allocator<F>>;
+    std::array<std::vector<F>, 3> a0;
+    std::array<pvec, 3> a1;
+    t.accs_u(a0, F(0.75));
+    t.accs_u(a1, F(0.75));
+    bool same = a1[0].size() == s;
+    for (std::size_t k = 0; same && k < 3; ++k) same = std::memcmp(a0[k].data(), a1[k].data(), s * sizeof(F)) == 0;
+    CHECK(same);
+    std::array<std::vector<F>, 4> b0;
+    std::array<pvec, 4> b1;
+    t.accs_pots_o(b0, F(0.75), eps = F(0.01), G = F(3));
+    t.accs_pots_o(b1, F(0.75), eps = F(0.01), G = F(3));
+    same = true;
+    for (std::size_t k = 0; same && k < 4; ++k) same = std::memcmp(b0[k].data(), b1[k].data(), s * sizeof(F)) == 0;
+    CHECK(same);
+    // A CPU share next to the device: both engines write into the same pinned vectors.
+    pvec p0, p1;
+    std::vector<F> q0;
+    t.pots_u(q0, F(0.75), split = std::vector<double>{0.25, 0.75});
+    t.pots_u(p0, F(0.75), split = std::vector<double>{0.25, 0.75});
+    t.pots_u(p1, F(0.75));
+    CHECK(std::memcmp(q0.data(), p0.data(), s * sizeof(F)) == 0);
+    double worst = 0;
+    for (std::size_t i = 0; i < s; ++i) worst = std::max(worst, std::abs(double(p0[i] - p1[i]) / double(p1[i])));
+    CHECK(worst < (std::is_same_v<F, double> ? 1e-12 : 1e-4));
+}
+
 int main(int argc, char **argv)
 {
     const bool gpu = argc > 1 && std::strcmp(argv[1], "gpu") == 0;
@@ -476,6 +514,8 @@ int main(int argc, char **argv)
         gpu_checks<float, mac::bh>();
         gpu_checks<double, mac::bh>();
         gpu_checks<double, mac::bh_geom>();
+        pinned_output_checks<float>();
+        pinned_output_checks<double>();
     }
     std::printf("%s: %d failure(s)\n", gpu ? "gpu+host checks" : "host checks", failures);
     return failures ? 1 : 0;
