@@ -465,7 +465,7 @@ def cpu_baseline(tree, m, x, y, z, mac, theta, eps, q, n, threads, gpu_outs, p_b
     dt = min(ts)
     from rakau_amd import _capi
     isa = "AVX-512" if _capi.lib().rk_cpu_engine_run(None) == 0 else "AVX2"
-    out = {"value": round(n / dt / 1e6, 3), "unit": "Mparticles/s", "cores": threads, "kind": "port-simd", "isa": isa,
+    out = {"value": round(n / dt / 1e6, 3), "unit": "Mparticles/s", "cores": threads, "kind": "port", "flavour": "simd", "isa": isa,
            "sample": "whole workload (%d particles), best of %d calls, %.2f s" % (n, len(ts), dt),
            "note": "rakau_amd's own CPU engine (std::thread + AVX-512 / AVX2 batches, the engine behind split = {cpu, ...}); a re-implementation, "
                    "not the reference's TBB + xsimd build (not buildable here); published reference figure: 48.8 Mparticles/s "
