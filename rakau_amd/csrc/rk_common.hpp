@@ -281,6 +281,8 @@ template <typename F>
 void launch_list(const rk_state &s, int q, const kparams<F> &p, const int64_t cls_begin[n_classes],
                  const int64_t cls_end[n_classes], hipStream_t const streams[n_list_R], unsigned class_mask = ~0u);
 template <typename F>
+void launch_list_big(const rk_state &s, int q, const kparams<F> &p, const uint32_t *list, int64_t n, hipStream_t stream);
+template <typename F>
 void launch_pc(const rk_state &s, int q, const kparams<F> &p, const int64_t cls_begin[n_classes],
                const int64_t cls_end[n_classes], hipStream_t const streams[n_list_R], unsigned class_mask = ~0u);
 template <typename F>

@@ -24,20 +24,25 @@
 namespace rk
 {
 
-template <typename F, int Q, int MAC, int R, int ND>
-__global__ void __launch_bounds__(64 * RK_WPB, (sizeof(F) == 4 ? (R <= 2 ? RK_W12 : (R == 3 ? RK_W3 : (R == 4 ? RK_W4 : (R == 5 ? RK_W5 : RK_W6)))) : RK_W64)) k_list(const kparams<F> P, const uint32_t *__restrict__ list, int n_list)
+template <typename F, int Q, int MAC, int R, int ND, bool BIG = false>
+__global__ void __launch_bounds__(64 * (BIG ? LK_BIG_WPB : RK_WPB), (sizeof(F) == 4 ? (R <= 2 ? RK_W12 : (R == 3 ? RK_W3 : (R == 4 ? RK_W4 : (R == 5 ? RK_W5 : RK_W6)))) : RK_W64)) k_list(const kparams<F> P, const uint32_t *__restrict__ list, int n_list)
 {
     using v4 = typename vt<F>::v4;
     using v2 = typename vt<F>::v2;
     constexpr int NR = nres_of(Q);
     constexpr int SRC_CAP = lk_cfg<F>::src_cap;
     static_assert(sizeof(lk_wave_lds<F>) >= 64 * 4 * sizeof(F), "reduction scratch does not fit");
-    __shared__ lk_wave_lds<F> s_lds[RK_WPB];
+    __shared__ lk_wave_lds<F> s_lds[BIG ? LK_BIG_WPB : RK_WPB];
 
     const int wib = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
-    const unsigned blk = xcd_map_block(blockIdx.x, gridDim.x, P.xcd_mode);
-    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(blk * unsigned(RK_WPB)) + wib);
+    // BIG: one workgroup per critical node too large for one wavefront (more than 64 * RK_MAX_R particles: ncrit or
+    // max_leaf_n above 256, or a tree that ran out of levels). Its targets are cut into chunks of at most
+    // LK_BIG_CHUNK, every wavefront of the workgroup serves chunks wib, wib + LK_BIG_WPB, ... exactly like a group of
+    // its own -- except that every MAC decision is taken for ALL particles of the critical node (bounding box, probes
+    // and the exact test range over the node, not the chunk), so the interaction set is the reference's.
+    const unsigned blk = BIG ? blockIdx.x : xcd_map_block(blockIdx.x, gridDim.x, P.xcd_mode);
+    const int wave = __builtin_amdgcn_readfirstlane(BIG ? static_cast<int>(blk) : static_cast<int>(blk * unsigned(RK_WPB)) + wib);
     if (wave >= n_list) {
         return;
     }
@@ -45,7 +50,13 @@ __global__ void __launch_bounds__(64 * RK_WPB, (sizeof(F) == 4 ? (R <= 2 ? RK_W1
 
     const uint32_t g = __builtin_amdgcn_readfirstlane(list[wave]);
     const uint4 c = P.crit[g];
-    const uint32_t tb = c.x, te = c.y, cnode = c.z;
+    const uint32_t gb = c.x, ge = c.y, cnode = c.z;
+    const int TG = static_cast<int>(ge - gb);
+    const int n_chunks = BIG ? (TG + LK_BIG_CHUNK - 1) / LK_BIG_CHUNK : 1;
+    const int chunk_len = BIG ? (TG + n_chunks - 1) / n_chunks : TG;
+    for (int chunk = BIG ? wib : 0; chunk < n_chunks; chunk += BIG ? LK_BIG_WPB : 1) {
+    const uint32_t tb = gb + static_cast<uint32_t>(chunk * chunk_len);
+    const uint32_t te = (BIG && tb + static_cast<uint32_t>(chunk_len) < ge) ? tb + static_cast<uint32_t>(chunk_len) : ge;
     const int T = static_cast<int>(te - tb);
 
     // Lane mapping of the dense phase: TP target slots, NS source splits.
@@ -75,7 +86,7 @@ __global__ void __launch_bounds__(64 * RK_WPB, (sizeof(F) == 4 ? (R <= 2 ? RK_W1
     const F mac_value = P.mac_value, eps2 = P.eps2;
     // Bounding box of the group's particles and two probe targets (first and last): wave-uniform.
     const v4 blo = P.crit_box[2u * g], bhi = P.crit_box[2u * g + 1u];
-    const v4 pr0 = P.part4[tb], pr1 = P.part4[te - 1u];
+    const v4 pr0 = P.part4[gb], pr1 = P.part4[ge - 1u];
     RK_STAMP_DECL
 #ifdef RK_TRACE
     // Diagnostic build: wall-clock interval (100 MHz counter) and placement of every wave, for occupancy timelines.
@@ -349,7 +360,7 @@ __global__ void __launch_bounds__(64 * RK_WPB, (sizeof(F) == 4 ? (R <= 2 ? RK_W1
         const F mac_lh = mac_lhs<F>(MAC, bt.mp, mac_value);
         bool fail;
 #if RK_EXACT_TRANSPOSED
-        if (k * (7 * R + 3) < T * 7) {
+        if (!BIG && k * (7 * R + 3) < T * 7) {
             // Few candidates: lane = target. Every lane already keeps R targets of the group in registers (unused
             // slots repeat target 0), so a candidate costs one broadcast LDS read and 7 R + 3 instructions instead of
             // a share of the 7 T of the loop below. Same formula, same operands: same decision.
@@ -382,11 +393,11 @@ __global__ void __launch_bounds__(64 * RK_WPB, (sizeof(F) == 4 ? (R <= 2 ? RK_W1
             // min over the targets of the unsoftened squared distance to the node's centre of mass. The target
             // coordinates are wave-uniform: they arrive through scalar loads as SGPR operands.
             F mind2 = std::numeric_limits<F>::infinity();
-            for (int t = 0; t < T; t += 4) {
+            for (int t = 0; t < TG; t += 4) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int ti = (t + u < T) ? t + u : T - 1;
-                    const v4 tg = P.part4[tb + static_cast<uint32_t>(ti)];
+                    const int ti = (t + u < TG) ? t + u : TG - 1;
+                    const v4 tg = P.part4[gb + static_cast<uint32_t>(ti)];
                     const F dx = com.x - tg.x, dy = com.y - tg.y, dz = com.z - tg.z;
                     const F d2 = rk_fma(dz, dz, rk_fma(dy, dy, dx * dx));
                     mind2 = rk_min(mind2, d2);
@@ -483,16 +494,16 @@ __global__ void __launch_bounds__(64 * RK_WPB, (sizeof(F) == 4 ? (R <= 2 ? RK_W1
 
     RK_STAMP(7)
     // ---- interactions inside the group: its own particles as sources, self-pair masked ----
-    for (int b0 = 0; b0 < T; b0 += SRC_CAP) {
-        const int n = (T - b0) < SRC_CAP ? (T - b0) : SRC_CAP;
+    for (int b0 = 0; b0 < TG; b0 += SRC_CAP) {
+        const int n = (TG - b0) < SRC_CAP ? (TG - b0) : SRC_CAP;
         for (int j = lane; j < n; j += 64) {
-            L.src[j] = P.part4[tb + static_cast<uint32_t>(b0 + j)];
+            L.src[j] = P.part4[gb + static_cast<uint32_t>(b0 + j)];
         }
         wave_sync();
         int tloc[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            tloc[r] = tidx[r] < 0 ? -1 : tidx[r] - b0;
+            tloc[r] = tidx[r] < 0 ? -1 : static_cast<int>(tb - gb) + tidx[r] - b0;
         }
         lk_eval_tile<F, Q, R, true, ND>(L.src, n, (n * inv_ns) >> 16, sp, NS, true, lane_on, tp, acc, eps2, tloc);
         wave_sync();
@@ -544,7 +555,7 @@ __global__ void __launch_bounds__(64 * RK_WPB, (sizeof(F) == 4 ? (R <= 2 ? RK_W1
     RK_STAMP(7)
     RK_STAMP_FLUSH
 #ifdef RK_TRACE
-    if (lane == 0 && P.dbg) {
+    if (!BIG && lane == 0 && P.dbg) {
         const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
         P.dbg[4u * g] = tr_t0;
         P.dbg[4u * g + 1u] = __builtin_amdgcn_s_memrealtime();
@@ -552,6 +563,10 @@ __global__ void __launch_bounds__(64 * RK_WPB, (sizeof(F) == 4 ? (R <= 2 ? RK_W1
         P.dbg[4u * g + 3u] = (static_cast<unsigned long long>(R) << 32) | static_cast<unsigned>(T);
     }
 #endif
+    if (BIG) {
+        wave_sync(); // the next chunk reuses this wave's LDS region
+    }
+    } // chunk loop
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -744,6 +759,40 @@ void launch_list(const rk_state &s, int q, const kparams<F> &p, const int64_t cb
     }
     RK_HIP(hipGetLastError());
 }
+
+// Critical nodes of more than 64 * RK_MAX_R particles: k_list<..., BIG> (one workgroup per node).
+template <typename F>
+void launch_list_big(const rk_state &s, int q, const kparams<F> &p, const uint32_t *list, int64_t n, hipStream_t stream)
+{
+    if (n <= 0) {
+        return;
+    }
+    const dim3 grid(static_cast<unsigned>(n)), block(64 * LK_BIG_WPB);
+    const int cnt = static_cast<int>(n);
+    auto go = [&](auto Qt, auto Mt) {
+        constexpr int Q = decltype(Qt)::value, M = decltype(Mt)::value;
+        if (s.ndim == 3 || !RK_QUAD_BODY) {
+            hipLaunchKernelGGL((k_list<F, Q, M, 2, 3, true>), grid, block, 0, stream, p, list, cnt);
+        } else {
+            hipLaunchKernelGGL((k_list<F, Q, M, 2, 2, true>), grid, block, 0, stream, p, list, cnt);
+        }
+    };
+    using i0 = std::integral_constant<int, 0>;
+    using i1 = std::integral_constant<int, 1>;
+    using i2 = std::integral_constant<int, 2>;
+    switch (q * 2 + s.mac) {
+        case 0: go(i0{}, i0{}); break;
+        case 1: go(i0{}, i1{}); break;
+        case 2: go(i1{}, i0{}); break;
+        case 3: go(i1{}, i1{}); break;
+        case 4: go(i2{}, i0{}); break;
+        case 5: go(i2{}, i1{}); break;
+        default: throw error(RK_EINVAL, "invalid q / mac combination");
+    }
+    RK_HIP(hipGetLastError());
+}
+template void launch_list_big<float>(const rk_state &, int, const kparams<float> &, const uint32_t *, int64_t, hipStream_t);
+template void launch_list_big<double>(const rk_state &, int, const kparams<double> &, const uint32_t *, int64_t, hipStream_t);
 
 template void launch_list<float>(const rk_state &, int, const kparams<float> &, const int64_t[n_classes],
                                  const int64_t[n_classes], hipStream_t const[n_list_R], unsigned);

@@ -90,6 +90,9 @@ constexpr int LK_DFS_RESERVE = 7 * 21;
 constexpr int LK_LQ_CAP = 128;
 // Queue of candidates left undecided by the bounding-box / probe tests.
 constexpr int LK_UQ_CAP = 128;
+// Critical nodes too large for one wavefront (k_list<..., BIG>): wavefronts per workgroup, targets per chunk.
+constexpr int LK_BIG_WPB = 4;
+constexpr int LK_BIG_CHUNK = 128;
 
 template <typename F>
 struct lk_cfg {

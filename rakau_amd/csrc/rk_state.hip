@@ -945,10 +945,18 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                     RK_HIP(hipStreamWaitEvent(st, s.ev_join[i], 0));
                 }
             }
-            // Groups too large for the wave kernels are served by the block-per-group kernel.
-            rk::launch_block<F>(s, q, p,
-                                static_cast<const uint32_t *>(s.buf[RK_BUF_CLASS]) + s.class2_off[rk::big_class] + big_b,
-                                big_e - big_b, st);
+            // Critical nodes too large for one wavefront: a workgroup each, cut into chunks of targets (k_list<BIG>).
+            // RK_BIG_DFS=1 selects the scalar block-per-node walk of variant 1 instead (cross-check).
+            static const bool big_dfs = [] {
+                const char *e = std::getenv("RK_BIG_DFS");
+                return e && std::atoi(e) != 0;
+            }();
+            const auto *big_list = static_cast<const uint32_t *>(s.buf[RK_BUF_CLASS]) + s.class2_off[rk::big_class] + big_b;
+            if (big_dfs) {
+                rk::launch_block<F>(s, q, p, big_list, big_e - big_b, st);
+            } else {
+                rk::launch_list_big<F>(s, q, p, big_list, big_e - big_b, st);
+            }
         };
         if (use_graph && allow_graph) {
             // A call that repeats the previous one (same range, outputs, parameters) replays a captured graph:

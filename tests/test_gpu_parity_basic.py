@@ -17,12 +17,12 @@ TIGHT = {np.float32: 2e-5, np.float64: 1e-12}
 VARIANTS = [1, 2, 3]
 
 
-def check(got, ref, q, dtype, tol=None):
+def check(got, ref, q, dtype, tol=None, ndim=3):
     tol = TIGHT[dtype] if tol is None else tol
     for g in got:
         assert np.all(np.isfinite(g))
     if q in (0, 2):
-        e = rel_err_vec(got, ref)
+        e = rel_err_vec(got, ref, ndim=ndim)
         assert e.max() <= tol, ("acc", e.max(), int(e.argmax()))
     if q in (1, 2):
         e = rel_err(got[-1], ref[-1])
@@ -78,6 +78,39 @@ def test_big_groups_and_huge_leaves(variant):
         ref = ot.acc_pot(2, 0.6, eps=0.01, nthreads=8)
         got = st.acc_pot(2, mac_value_of(0.6, "bh", dtype), eps2=float(dtype(0.01) ** 2))
         check(got, ref, 2, dtype, tol=1e-4)
+
+
+@pytest.mark.parametrize("dtype,ndim,mac", [(np.float64, 3, "bh"), (np.float32, 3, "bh_geom"), (np.float64, 2, "bh"),
+                                            (np.float32, 2, "bh_geom")])
+def test_chunked_big_groups_all_flavours(dtype, ndim, mac):
+    """Critical nodes of more than 256 particles are cut into chunks of targets that share the node's MAC decisions
+    (k_list<BIG>): every flavour against the oracle, Q = 0, 1, 2; the union of two sub-ranges equals the full-range
+    result bit for bit; repeated calls give the same bits."""
+    rng = oracle.Rng(21)
+    n = 7000
+    if ndim == 3:
+        m, x, y, z = rng.uniform_particles(n, 1.0, dtype)
+        x[:900], y[:900], z[:900] = 0.2, 0.1, -0.3  # 900 coincident particles: one deepest-level leaf
+        ot = oracle.Tree(x, y, z, m, box_size=1.0, max_leaf_n=300, ncrit=1300, mac=mac)
+    else:
+        m, x, y = rng.uniform_particles(n, 1.0, dtype, ndim=2)
+        x[:900], y[:900] = 0.2, 0.1
+        ot = oracle.Tree(x, y, None, m, box_size=1.0, max_leaf_n=300, ncrit=1300, mac=mac, ndim=2)
+    st = state_from_oracle(ot)
+    cr = st.crit_ranges()
+    assert (cr[:, 1] - cr[:, 0]).max() > 600
+    mv = mac_value_of(0.6, mac, dtype)
+    cut = int(cr[len(cr) // 2, 0])
+    for q in (0, 1, 2):
+        ref = ot.acc_pot(q, 0.6, eps=0.01, nthreads=8)
+        got = st.acc_pot(q, mv, eps2=float(dtype(0.01) ** 2))
+        check(got, ref, q, dtype, tol=1e-4 if dtype == np.float32 else 1e-11, ndim=ndim)
+        again = st.acc_pot(q, mv, eps2=float(dtype(0.01) ** 2))
+        lo = st.acc_pot(q, mv, eps2=float(dtype(0.01) ** 2), p_begin=0, p_end=cut, offset_output=False)
+        hi = st.acc_pot(q, mv, eps2=float(dtype(0.01) ** 2), p_begin=cut, p_end=n, offset_output=False)
+        for a, b, l, h in zip(got, again, lo, hi):
+            assert np.array_equal(a, b)
+            assert np.array_equal(a, np.concatenate([l, h]))
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
