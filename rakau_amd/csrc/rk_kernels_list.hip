@@ -25,7 +25,7 @@ namespace rk
 {
 
 template <typename F, int Q, int MAC, int R, int ND, bool BIG = false>
-__global__ void __launch_bounds__(64 * (BIG ? LK_BIG_WPB : RK_WPB), (sizeof(F) == 4 ? (R <= 2 ? RK_W12 : (R == 3 ? RK_W3 : (R == 4 ? RK_W4 : (R == 5 ? RK_W5 : RK_W6)))) : RK_W64)) k_list(const kparams<F> P, const uint32_t *__restrict__ list, int n_list)
+__global__ void __launch_bounds__(64 * (BIG ? LK_BIG_WPB : RK_WPB), BIG ? (sizeof(F) == 4 ? RK_WBIG : RK_W64) : (sizeof(F) == 4 ? (R <= 2 ? RK_W12 : (R == 3 ? RK_W3 : (R == 4 ? RK_W4 : (R == 5 ? RK_W5 : RK_W6)))) : RK_W64)) k_list(const kparams<F> P, const uint32_t *__restrict__ list, int n_list)
 {
     using v4 = typename vt<F>::v4;
     using v2 = typename vt<F>::v2;
