@@ -52,11 +52,8 @@ __global__ void __launch_bounds__(64 * (BIG ? LK_BIG_WPB : RK_WPB), BIG ? (sizeo
     const uint4 c = P.crit[g];
     const uint32_t gb = c.x, ge = c.y, cnode = c.z;
     const int TG = static_cast<int>(ge - gb);
-    const int n_chunks = BIG ? (TG + LK_BIG_CHUNK - 1) / LK_BIG_CHUNK : 1;
-    const int chunk_len = BIG ? (TG + n_chunks - 1) / n_chunks : TG;
-    for (int chunk = BIG ? wib : 0; chunk < n_chunks; chunk += BIG ? LK_BIG_WPB : 1) {
-    const uint32_t tb = gb + static_cast<uint32_t>(chunk * chunk_len);
-    const uint32_t te = (BIG && tb + static_cast<uint32_t>(chunk_len) < ge) ? tb + static_cast<uint32_t>(chunk_len) : ge;
+    // The targets [tb, te) of this wavefront: the whole critical node, or one chunk of an oversized one.
+    auto run_targets = [&](const uint32_t tb, const uint32_t te) __attribute__((always_inline)) {
     const int T = static_cast<int>(te - tb);
 
     // Lane mapping of the dense phase: TP target slots, NS source splits.
@@ -563,10 +560,18 @@ __global__ void __launch_bounds__(64 * (BIG ? LK_BIG_WPB : RK_WPB), BIG ? (sizeo
         P.dbg[4u * g + 3u] = (static_cast<unsigned long long>(R) << 32) | static_cast<unsigned>(T);
     }
 #endif
-    if (BIG) {
-        wave_sync(); // the next chunk reuses this wave's LDS region
+    }; // run_targets
+    if constexpr (BIG) {
+        const int n_chunks = (TG + LK_BIG_CHUNK - 1) / LK_BIG_CHUNK;
+        const int chunk_len = (TG + n_chunks - 1) / n_chunks;
+        for (int chunk = wib; chunk < n_chunks; chunk += LK_BIG_WPB) {
+            const uint32_t tb = gb + static_cast<uint32_t>(chunk * chunk_len);
+            run_targets(tb, tb + static_cast<uint32_t>(chunk_len) < ge ? tb + static_cast<uint32_t>(chunk_len) : ge);
+            wave_sync(); // the next chunk reuses this wave's LDS region
+        }
+    } else {
+        run_targets(gb, ge);
     }
-    } // chunk loop
 }
 
 // ------------------------------------------------------------------------------------------------
