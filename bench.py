@@ -303,6 +303,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Order of the measurements: the interaction census of this rank's range (what the roofline divides by), then the
+    # kernel-only time of a step (HIP events recorded by the library on the launch stream, one synchronised call at a
+    # time), then the W warmup steps and the K timed steps. The first two also take the GPU out of the idle power state the
+    # host-side tree construction left it in: after idling a 4M step needs 50-80 ms of load before its duration settles
+    # (2.80, 2.71, 2.65, 2.60, 2.53, 2.49, 2.45, 2.43, 2.43, 2.38, ... 2.33 ms; RK_BENCH_DEBUG=1 prints the series), more
+    # than W = 3-5 steps provide. Hence at least 12 calls and 80 ms of kernel time here; the median of the last 10 is
+    # `kernel_ms`.
+    census = state.count_interactions(mac_value, p_begin, p_end)
+    inter_local = census["com"] + census["pp"] + census["self"]
+    kms, busy_ms = [], 0.0
+    while len(kms) < 12 or (busy_ms < 80.0 and len(kms) < 1000):
+        step()
+        kms.append(state.last_kernel_ms())
+        busy_ms += kms[-1] if len(kms) > 2 else 0.0  # the first calls carry one-off initialisation
+    kernel_ms = float(np.median(kms[-10:]))
+    if os.environ.get("RK_BENCH_DEBUG"):
+        print("kernel ms of the pre-loop:", " ".join("%.3f" % v for v in kms), file=sys.stderr)
+    # One burst of K calls without synchronisation in between: the first time K launches are in flight the HIP runtime
+    # grows its signal / command pools (+0.05 ms per step on the first burst of 20, none afterwards).
+    for _ in range(args.steps):
+        step()
+    barrier()
+
     for _ in range(args.warmup):
         step()
     barrier()
@@ -311,16 +334,19 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-
-    # Kernel-only time of one step, HIP events recorded by the library on the launch stream.
-    kms = []
-    for _ in range(min(args.steps, 10)):
-        step()
-        kms.append(state.last_kernel_ms())
-    kernel_ms = float(np.median(kms))
-
-    census = state.count_interactions(mac_value, p_begin, p_end)
-    inter_local = census["com"] + census["pp"] + census["self"]
+    if os.environ.get("RK_BENCH_DEBUG"):
+        post = []
+        for _ in range(10):
+            step()
+            post.append(state.last_kernel_ms())
+        print("kernel ms after the timed loop:", " ".join("%.3f" % v for v in post), file=sys.stderr)
+        for _ in range(4):
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            barrier()
+            print("another %d steps: %.4f ms per step" % (args.steps, (time.perf_counter() - t1) / args.steps * 1e3), file=sys.stderr)
 
     if dist is not None:
         rdev = "cuda" if backend == "nccl" else "cpu"
