@@ -54,511 +54,511 @@ __global__ void __launch_bounds__(64 * (BIG ? LK_BIG_WPB : RK_WPB), BIG ? (sizeo
     const int TG = static_cast<int>(ge - gb);
     // The targets [tb, te) of this wavefront: the whole critical node, or one chunk of an oversized one.
     auto run_targets = [&](const uint32_t tb, const uint32_t te) __attribute__((always_inline)) {
-    const int T = static_cast<int>(te - tb);
+        const int T = static_cast<int>(te - tb);
 
-    // Lane mapping of the dense phase: TP target slots, NS source splits.
-    const int TP = (T + R - 1) / R;
-    const int NS = 64 / TP;
-    const int ts = lane % TP, sp_raw = lane / TP;
-    const bool lane_on = sp_raw < NS;
-    const int sp = lane_on ? sp_raw : 0; // idle lanes shadow split 0; their results are never stored
+        // Lane mapping of the dense phase: TP target slots, NS source splits.
+        const int TP = (T + R - 1) / R;
+        const int NS = 64 / TP;
+        const int ts = lane % TP, sp_raw = lane / TP;
+        const bool lane_on = sp_raw < NS;
+        const int sp = lane_on ? sp_raw : 0; // idle lanes shadow split 0; their results are never stored
 
-    v4 tp[R];
-    int tidx[R];
-    F acc[R][NR];
+        v4 tp[R];
+        int tidx[R];
+        F acc[R][NR];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        tidx[r] = ts + r * TP;
-        const bool valid = tidx[r] < T;
-        tp[r] = P.part4[tb + (valid ? tidx[r] : 0)];
-        if (!valid) {
-            tidx[r] = -1;
-        }
+        for (int r = 0; r < R; ++r) {
+            tidx[r] = ts + r * TP;
+            const bool valid = tidx[r] < T;
+            tp[r] = P.part4[tb + (valid ? tidx[r] : 0)];
+            if (!valid) {
+                tidx[r] = -1;
+            }
 #pragma unroll
-        for (int k = 0; k < NR; ++k) {
-            acc[r][k] = F(0);
+            for (int k = 0; k < NR; ++k) {
+                acc[r][k] = F(0);
+            }
         }
-    }
 
-    const F mac_value = P.mac_value, eps2 = P.eps2;
-    // Bounding box of the group's particles and two probe targets (first and last): wave-uniform.
-    const v4 blo = P.crit_box[2u * g], bhi = P.crit_box[2u * g + 1u];
-    const v4 pr0 = P.part4[gb], pr1 = P.part4[ge - 1u];
-    RK_STAMP_DECL
+        const F mac_value = P.mac_value, eps2 = P.eps2;
+        // Bounding box of the group's particles and two probe targets (first and last): wave-uniform.
+        const v4 blo = P.crit_box[2u * g], bhi = P.crit_box[2u * g + 1u];
+        const v4 pr0 = P.part4[gb], pr1 = P.part4[ge - 1u];
+        RK_STAMP_DECL
 #ifdef RK_TRACE
-    // Diagnostic build: wall-clock interval (100 MHz counter) and placement of every wave, for occupancy timelines.
-    const unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime();
+        // Diagnostic build: wall-clock interval (100 MHz counter) and placement of every wave, for occupancy timelines.
+        const unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    int size = 0, n_src = 0, n_lq = 0, n_uq = 0;
-    // Supergroup pre-pass results for this group's supergroup (if enabled and not overflowed).
-    uint32_t sup_S = 0, sup_ncommon = 0, sup_nresid = 0, sup_rpos = 0;
-    bool from_root = true;
-    if (P.super_k != 0u) {
-        sup_S = g / P.super_k;
-        const uint2 cnt = P.sup_cnt[sup_S];
-        if ((cnt.y >> 31) == 0u) {
-            from_root = false;
-            sup_ncommon = cnt.x;
-            sup_nresid = cnt.y;
-        }
-    }
-    if (from_root) {
-        // The root is an ancestor of every group (or the group itself): start from its children.
-        const node_rec<F> *root = P.node_rec;
-        const uint32_t r_nch = root->nch, r_a = root->a, r_b = root->b;
-        if (cnode != 0u && r_nch != 0u) {
-            if (lane == 0) {
-                L.stack[0] = (r_a << 3) | (r_b - 1u);
+        int size = 0, n_src = 0, n_lq = 0, n_uq = 0;
+        // Supergroup pre-pass results for this group's supergroup (if enabled and not overflowed).
+        uint32_t sup_S = 0, sup_ncommon = 0, sup_nresid = 0, sup_rpos = 0;
+        bool from_root = true;
+        if (P.super_k != 0u) {
+            sup_S = g / P.super_k;
+            const uint2 cnt = P.sup_cnt[sup_S];
+            if ((cnt.y >> 31) == 0u) {
+                from_root = false;
+                sup_ncommon = cnt.x;
+                sup_nresid = cnt.y;
             }
-            size = 1;
         }
-    }
-    wave_sync();
+        if (from_root) {
+            // The root is an ancestor of every group (or the group itself): start from its children.
+            const node_rec<F> *root = P.node_rec;
+            const uint32_t r_nch = root->nch, r_a = root->a, r_b = root->b;
+            if (cnode != 0u && r_nch != 0u) {
+                if (lane == 0) {
+                    L.stack[0] = (r_a << 3) | (r_b - 1u);
+                }
+                size = 1;
+            }
+        }
+        wave_sync();
 
-    // n / NS for n <= SRC_CAP without a division per tile: exact for n * NS < 2^16.
-    const int inv_ns = (65536 + NS - 1) / NS;
-    static_assert(SRC_CAP * 64 < 65536);
-    // Evaluate the tile. Unless `final`, only whole rounds of NS sources are consumed and the (< NS) sources left
-    // over move to the front of the tile, so that no masked remainder step is paid per tile.
-    auto flush = [&](bool final) __attribute__((always_inline)) {
-        if (n_src > 0) {
-            RK_STAMP(7)
-            const int full = (n_src * inv_ns) >> 16;
-            lk_eval_tile<F, Q, R, false, ND>(L.src, n_src, full, sp, NS, final || !RK_CARRY_REMAINDER, lane_on, tp, acc, eps2,
-                                         tidx);
+        // n / NS for n <= SRC_CAP without a division per tile: exact for n * NS < 2^16.
+        const int inv_ns = (65536 + NS - 1) / NS;
+        static_assert(SRC_CAP * 64 < 65536);
+        // Evaluate the tile. Unless `final`, only whole rounds of NS sources are consumed and the (< NS) sources left
+        // over move to the front of the tile, so that no masked remainder step is paid per tile.
+        auto flush = [&](bool final) __attribute__((always_inline)) {
+            if (n_src > 0) {
+                RK_STAMP(7)
+                const int full = (n_src * inv_ns) >> 16;
+                lk_eval_tile<F, Q, R, false, ND>(L.src, n_src, full, sp, NS, final || !RK_CARRY_REMAINDER, lane_on, tp, acc, eps2,
+                                             tidx);
 #if RK_CARRY_REMAINDER
-            const int left = final ? 0 : n_src - full * NS;
-            v4 keep;
-            if (lane < left) {
-                keep = L.src[full * NS + lane];
-            }
-            wave_sync();
-            if (lane < left) {
-                L.src[lane] = keep;
-            }
-            n_src = left;
+                const int left = final ? 0 : n_src - full * NS;
+                v4 keep;
+                if (lane < left) {
+                    keep = L.src[full * NS + lane];
+                }
+                wave_sync();
+                if (lane < left) {
+                    L.src[lane] = keep;
+                }
+                n_src = left;
 #else
-            n_src = 0;
+                n_src = 0;
 #endif
-            wave_sync();
-            RK_STAMP(4)
-        }
-    };
-
-    // Gather the particles of the queued leaves into the source tile, evaluating the tile when it fills.
-    auto drain_leaves = [&]() __attribute__((always_inline)) {
-#ifdef RK_ABLATE_LEAVES
-        n_lq = 0; // diagnostic build: opened leaves are dropped
-#endif
-        while (n_lq > 0) {
-            RK_STAMP(7)
-            const int free_slots = SRC_CAP - n_src;
-            uint2 lf = make_uint2(0u, 0u);
-            if (lane < n_lq) {
-                lf = L.lq[lane];
+                wave_sync();
+                RK_STAMP(4)
             }
-            const unsigned cnt = lane < n_lq ? lf.y - lf.x : 0u;
-            const unsigned incl = wave_incl_scan(cnt);
-            const bool fits = lane < n_lq && incl <= static_cast<unsigned>(free_slots);
-            const unsigned long long m_fit = __builtin_amdgcn_ballot_w64(fits);
-            const int m = __builtin_popcountll(m_fit); // leaves [0, m) fit (prefix property)
-            if (m == 0) {
-                if (n_src > 0) {
-                    flush(true); // everything, so that the tile really is empty afterwards
+        };
+
+        // Gather the particles of the queued leaves into the source tile, evaluating the tile when it fills.
+        auto drain_leaves = [&]() __attribute__((always_inline)) {
+#ifdef RK_ABLATE_LEAVES
+            n_lq = 0; // diagnostic build: opened leaves are dropped
+#endif
+            while (n_lq > 0) {
+                RK_STAMP(7)
+                const int free_slots = SRC_CAP - n_src;
+                uint2 lf = make_uint2(0u, 0u);
+                if (lane < n_lq) {
+                    lf = L.lq[lane];
+                }
+                const unsigned cnt = lane < n_lq ? lf.y - lf.x : 0u;
+                const unsigned incl = wave_incl_scan(cnt);
+                const bool fits = lane < n_lq && incl <= static_cast<unsigned>(free_slots);
+                const unsigned long long m_fit = __builtin_amdgcn_ballot_w64(fits);
+                const int m = __builtin_popcountll(m_fit); // leaves [0, m) fit (prefix property)
+                if (m == 0) {
+                    if (n_src > 0) {
+                        flush(true); // everything, so that the tile really is empty afterwards
+                        continue;
+                    }
+                    // A single leaf larger than the whole tile: take SRC_CAP of its particles.
+                    const uint32_t b0 = __builtin_amdgcn_readfirstlane(lf.x);
+                    for (int j = lane; j < SRC_CAP; j += 64) {
+                        L.src[j] = P.part4[b0 + static_cast<uint32_t>(j)];
+                    }
+                    if (lane == 0) {
+                        L.lq[0] = make_uint2(b0 + static_cast<uint32_t>(SRC_CAP), lf.y);
+                    }
+                    n_src = SRC_CAP;
+                    wave_sync();
+                    flush(true);
                     continue;
                 }
-                // A single leaf larger than the whole tile: take SRC_CAP of its particles.
-                const uint32_t b0 = __builtin_amdgcn_readfirstlane(lf.x);
-                for (int j = lane; j < SRC_CAP; j += 64) {
-                    L.src[j] = P.part4[b0 + static_cast<uint32_t>(j)];
-                }
-                if (lane == 0) {
-                    L.lq[0] = make_uint2(b0 + static_cast<uint32_t>(SRC_CAP), lf.y);
-                }
-                n_src = SRC_CAP;
-                wave_sync();
-                flush(true);
-                continue;
-            }
-            // Lane l copies the particles of leaf l, eight loads in flight at a time.
-            const unsigned mycnt = fits ? cnt : 0u;
-            const int dst = n_src + static_cast<int>(incl - cnt);
-            for (unsigned j0 = 0; __builtin_amdgcn_ballot_w64(j0 < mycnt) != 0ull; j0 += 8u) {
-                v4 tmp[8];
-                // Unconditional loads (index clamped into the leaf; particle 0 for idle lanes).
-                const uint32_t lbase = mycnt ? lf.x : 0u, llast = mycnt ? mycnt - 1u : 0u;
+                // Lane l copies the particles of leaf l, eight loads in flight at a time.
+                const unsigned mycnt = fits ? cnt : 0u;
+                const int dst = n_src + static_cast<int>(incl - cnt);
+                for (unsigned j0 = 0; __builtin_amdgcn_ballot_w64(j0 < mycnt) != 0ull; j0 += 8u) {
+                    v4 tmp[8];
+                    // Unconditional loads (index clamped into the leaf; particle 0 for idle lanes).
+                    const uint32_t lbase = mycnt ? lf.x : 0u, llast = mycnt ? mycnt - 1u : 0u;
 #pragma unroll
-                for (unsigned u = 0; u < 8u; ++u) {
-                    const uint32_t jj = j0 + u < llast ? j0 + u : llast;
-                    tmp[u] = P.part4[lbase + jj];
-                }
+                    for (unsigned u = 0; u < 8u; ++u) {
+                        const uint32_t jj = j0 + u < llast ? j0 + u : llast;
+                        tmp[u] = P.part4[lbase + jj];
+                    }
 #pragma unroll
-                for (unsigned u = 0; u < 8u; ++u) {
-                    if (j0 + u < mycnt) {
-                        L.src[dst + static_cast<int>(j0 + u)] = tmp[u];
+                    for (unsigned u = 0; u < 8u; ++u) {
+                        if (j0 + u < mycnt) {
+                            L.src[dst + static_cast<int>(j0 + u)] = tmp[u];
+                        }
                     }
                 }
-            }
-            n_src += __builtin_amdgcn_readlane(static_cast<int>(incl), m - 1);
-            // Drop the consumed leaves from the queue (move the rest down, 64 entries at a time).
-            const int tail = n_lq - m;
-            wave_sync();
-            for (int j0 = 0; j0 < tail; j0 += 64) {
-                const int j = j0 + lane;
-                uint2 mv = make_uint2(0u, 0u);
-                if (j < tail) {
-                    mv = L.lq[j + m];
-                }
+                n_src += __builtin_amdgcn_readlane(static_cast<int>(incl), m - 1);
+                // Drop the consumed leaves from the queue (move the rest down, 64 entries at a time).
+                const int tail = n_lq - m;
                 wave_sync();
-                if (j < tail) {
-                    L.lq[j] = mv;
+                for (int j0 = 0; j0 < tail; j0 += 64) {
+                    const int j = j0 + lane;
+                    uint2 mv = make_uint2(0u, 0u);
+                    if (j < tail) {
+                        mv = L.lq[j + m];
+                    }
+                    wave_sync();
+                    if (j < tail) {
+                        L.lq[j] = mv;
+                    }
+                    wave_sync();
                 }
-                wave_sync();
+                n_lq = tail;
+                RK_STAMP(3)
+                if (n_src + 64 > SRC_CAP) {
+                    flush(false);
+                }
             }
-            n_lq = tail;
-            RK_STAMP(3)
-            if (n_src + 64 > SRC_CAP) {
-                flush(false);
-            }
-        }
-    };
+        };
 
-    // A batch of up to 64 candidate nodes held in registers (lane = candidate).
-    struct batch_t {
-        bool active;
-        v4 com;
-        v2 mp;
-        uint32_t node, nch, ra, rb, rec;
-    };
-    // Pop up to 8 sibling runs and issue the loads of their records. `pending` = number of entries that
-    // batches already in flight may still push. Returns the number of entries popped.
-    auto pop_and_load = [&](batch_t &bt, int pending, bool allow_dfs) __attribute__((always_inline)) -> int {
-        if (size == 0) {
-            return 0;
-        }
-        int k = size < 8 ? size : 8;
-        // Keep the stack within bounds even if every candidate is opened (8 pushes per popped entry);
-        // otherwise fall back to one entry at a time (depth-first), whose growth is bounded by
-        // LK_DFS_RESERVE -- only when nothing else is in flight.
-        const int room = (LK_STACK_CAP - LK_DFS_RESERVE - pending - n_uq - size) / 7;
-        if (room < k) {
-            if (room >= 1) {
-                k = room;
-            } else if (allow_dfs) {
-                k = 1;
-            } else {
+        // A batch of up to 64 candidate nodes held in registers (lane = candidate).
+        struct batch_t {
+            bool active;
+            v4 com;
+            v2 mp;
+            uint32_t node, nch, ra, rb, rec;
+        };
+        // Pop up to 8 sibling runs and issue the loads of their records. `pending` = number of entries that
+        // batches already in flight may still push. Returns the number of entries popped.
+        auto pop_and_load = [&](batch_t &bt, int pending, bool allow_dfs) __attribute__((always_inline)) -> int {
+            if (size == 0) {
                 return 0;
             }
-        }
-        const int e_idx = lane >> 3, e_sub = lane & 7;
-        uint32_t entry = 0u;
-        if (e_idx < k) {
-            entry = L.stack[size - 1 - e_idx];
-        }
-        size -= k;
-        bt.active = e_idx < k && static_cast<uint32_t>(e_sub) <= (entry & 7u);
-        // Everything about the candidate in three independent 16-byte loads (record 0 for idle lanes).
-        bt.rec = bt.active ? (entry >> 3) + static_cast<uint32_t>(e_sub) : 0u;
-        const node_rec<F> *rec = P.node_rec + bt.rec;
-        bt.com = rec->com;
-        bt.mp = rec->mac;
-        bt.node = rec->dfs;
-        bt.nch = rec->nch;
-        bt.ra = rec->a;
-        bt.rb = rec->b;
-        return k;
-    };
+            int k = size < 8 ? size : 8;
+            // Keep the stack within bounds even if every candidate is opened (8 pushes per popped entry);
+            // otherwise fall back to one entry at a time (depth-first), whose growth is bounded by
+            // LK_DFS_RESERVE -- only when nothing else is in flight.
+            const int room = (LK_STACK_CAP - LK_DFS_RESERVE - pending - n_uq - size) / 7;
+            if (room < k) {
+                if (room >= 1) {
+                    k = room;
+                } else if (allow_dfs) {
+                    k = 1;
+                } else {
+                    return 0;
+                }
+            }
+            const int e_idx = lane >> 3, e_sub = lane & 7;
+            uint32_t entry = 0u;
+            if (e_idx < k) {
+                entry = L.stack[size - 1 - e_idx];
+            }
+            size -= k;
+            bt.active = e_idx < k && static_cast<uint32_t>(e_sub) <= (entry & 7u);
+            // Everything about the candidate in three independent 16-byte loads (record 0 for idle lanes).
+            bt.rec = bt.active ? (entry >> 3) + static_cast<uint32_t>(e_sub) : 0u;
+            const node_rec<F> *rec = P.node_rec + bt.rec;
+            bt.com = rec->com;
+            bt.mp = rec->mac;
+            bt.node = rec->dfs;
+            bt.nch = rec->nch;
+            bt.ra = rec->a;
+            bt.rb = rec->b;
+            return k;
+        };
 
-    // Route classified candidates: accepted nodes go to the source tile, opened leaves to the leaf queue,
-    // opened internal nodes push their run of children, undecided ones go to the exact-test queue.
-    auto route = [&](bool accept, bool open, bool undecided, const batch_t &bt) __attribute__((always_inline)) {
-        const bool leaf = open && bt.nch == 0u;
-        const bool expand = open && bt.nch != 0u;
-        const unsigned long long m_acc = __builtin_amdgcn_ballot_w64(accept);
-        if (accept) {
-            L.src[n_src + static_cast<int>(wave_prefix_count(m_acc))] = bt.com;
-        }
-        n_src += __builtin_popcountll(m_acc);
-        const unsigned long long m_leaf = __builtin_amdgcn_ballot_w64(leaf);
-        if (leaf) {
-            L.lq[n_lq + static_cast<int>(wave_prefix_count(m_leaf))] = make_uint2(bt.ra, bt.rb);
-        }
-        n_lq += __builtin_popcountll(m_leaf);
-        const unsigned long long m_exp = __builtin_amdgcn_ballot_w64(expand);
-        if (expand) {
-            L.stack[size + static_cast<int>(wave_prefix_count(m_exp))] = (bt.ra << 3) | (bt.rb - 1u);
-        }
-        size += __builtin_popcountll(m_exp);
-        const unsigned long long m_und = __builtin_amdgcn_ballot_w64(undecided);
-        if (undecided) {
-            L.uq[n_uq + static_cast<int>(wave_prefix_count(m_und))] = bt.rec;
-        }
-        n_uq += __builtin_popcountll(m_und);
-        wave_sync();
-    };
+        // Route classified candidates: accepted nodes go to the source tile, opened leaves to the leaf queue,
+        // opened internal nodes push their run of children, undecided ones go to the exact-test queue.
+        auto route = [&](bool accept, bool open, bool undecided, const batch_t &bt) __attribute__((always_inline)) {
+            const bool leaf = open && bt.nch == 0u;
+            const bool expand = open && bt.nch != 0u;
+            const unsigned long long m_acc = __builtin_amdgcn_ballot_w64(accept);
+            if (accept) {
+                L.src[n_src + static_cast<int>(wave_prefix_count(m_acc))] = bt.com;
+            }
+            n_src += __builtin_popcountll(m_acc);
+            const unsigned long long m_leaf = __builtin_amdgcn_ballot_w64(leaf);
+            if (leaf) {
+                L.lq[n_lq + static_cast<int>(wave_prefix_count(m_leaf))] = make_uint2(bt.ra, bt.rb);
+            }
+            n_lq += __builtin_popcountll(m_leaf);
+            const unsigned long long m_exp = __builtin_amdgcn_ballot_w64(expand);
+            if (expand) {
+                L.stack[size + static_cast<int>(wave_prefix_count(m_exp))] = (bt.ra << 3) | (bt.rb - 1u);
+            }
+            size += __builtin_popcountll(m_exp);
+            const unsigned long long m_und = __builtin_amdgcn_ballot_w64(undecided);
+            if (undecided) {
+                L.uq[n_uq + static_cast<int>(wave_prefix_count(m_und))] = bt.rec;
+            }
+            n_uq += __builtin_popcountll(m_und);
+            wave_sync();
+        };
 
-    // First-stage MAC test of one batch. The reference's criterion is "every target t of the group has
-    // d2(t) > mac_lh" with d2(t) the squared distance from target t to the node's centre of mass
-    // (tree.hpp:2662-2672). Two cheap tests reproduce that decision for most candidates:
-    //  * accept if the squared distance from the centre of mass to the group's bounding box exceeds mac_lh
-    //    by a margin (1e-5 relative, far above the ~1e-6 rounding of either quantity): every d2(t) is larger;
-    //  * open if one of two probe targets already violates the criterion (same formula as the exact test).
-    // The rest is queued for the exact all-targets loop, so every decision equals the reference's.
-    auto process = [&](const batch_t &bt) __attribute__((always_inline)) {
-        const v4 com = bt.com;
-        // Ancestor-or-self of the target group (tree.hpp:2828-2838 of the reference) on the depth-first
-        // index interval of the subtree.
-        const bool anc = bt.active && bt.node <= cnode && cnode <= bt.node + bt.nch;
-        const bool self = anc && bt.node == cnode;
-        const bool test = bt.active && !anc;
-        const F mac_lh = mac_lhs<F>(MAC, bt.mp, mac_value);
+        // First-stage MAC test of one batch. The reference's criterion is "every target t of the group has
+        // d2(t) > mac_lh" with d2(t) the squared distance from target t to the node's centre of mass
+        // (tree.hpp:2662-2672). Two cheap tests reproduce that decision for most candidates:
+        //  * accept if the squared distance from the centre of mass to the group's bounding box exceeds mac_lh
+        //    by a margin (1e-5 relative, far above the ~1e-6 rounding of either quantity): every d2(t) is larger;
+        //  * open if one of two probe targets already violates the criterion (same formula as the exact test).
+        // The rest is queued for the exact all-targets loop, so every decision equals the reference's.
+        auto process = [&](const batch_t &bt) __attribute__((always_inline)) {
+            const v4 com = bt.com;
+            // Ancestor-or-self of the target group (tree.hpp:2828-2838 of the reference) on the depth-first
+            // index interval of the subtree.
+            const bool anc = bt.active && bt.node <= cnode && cnode <= bt.node + bt.nch;
+            const bool self = anc && bt.node == cnode;
+            const bool test = bt.active && !anc;
+            const F mac_lh = mac_lhs<F>(MAC, bt.mp, mac_value);
 #ifdef RK_STAMPS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        st_acc[6] += 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            st_acc[6] += 1;
 #endif
-        RK_STAMP(0)
-        const F bx = rk_max3(blo.x - com.x, com.x - bhi.x, F(0)), by = rk_max3(blo.y - com.y, com.y - bhi.y, F(0)),
-                bz = rk_max3(blo.z - com.z, com.z - bhi.z, F(0));
-        const F dbox2 = rk_fma(bz, bz, rk_fma(by, by, bx * bx));
-        const bool box_accept = dbox2 > mac_lh * F(1.00001);
-        const F p0x = com.x - pr0.x, p0y = com.y - pr0.y, p0z = com.z - pr0.z;
-        const F p1x = com.x - pr1.x, p1y = com.y - pr1.y, p1z = com.z - pr1.z;
-        const F d2p0 = rk_fma(p0z, p0z, rk_fma(p0y, p0y, p0x * p0x)), d2p1 = rk_fma(p1z, p1z, rk_fma(p1y, p1y, p1x * p1x));
-        const bool probe_open = mac_lh >= rk_min(d2p0, d2p1);
-        RK_STAMP(1)
+            RK_STAMP(0)
+            const F bx = rk_max3(blo.x - com.x, com.x - bhi.x, F(0)), by = rk_max3(blo.y - com.y, com.y - bhi.y, F(0)),
+                    bz = rk_max3(blo.z - com.z, com.z - bhi.z, F(0));
+            const F dbox2 = rk_fma(bz, bz, rk_fma(by, by, bx * bx));
+            const bool box_accept = dbox2 > mac_lh * F(1.00001);
+            const F p0x = com.x - pr0.x, p0y = com.y - pr0.y, p0z = com.z - pr0.z;
+            const F p1x = com.x - pr1.x, p1y = com.y - pr1.y, p1z = com.z - pr1.z;
+            const F d2p0 = rk_fma(p0z, p0z, rk_fma(p0y, p0y, p0x * p0x)), d2p1 = rk_fma(p1z, p1z, rk_fma(p1y, p1y, p1x * p1x));
+            const bool probe_open = mac_lh >= rk_min(d2p0, d2p1);
+            RK_STAMP(1)
 #ifdef RK_ABLATE_EXACT
-        const bool accept = test && (box_accept || !probe_open); // diagnostic build: no exact all-targets test
-        const bool open = (test && !box_accept && probe_open) || (anc && !self);
-        const bool undecided = false;
+            const bool accept = test && (box_accept || !probe_open); // diagnostic build: no exact all-targets test
+            const bool open = (test && !box_accept && probe_open) || (anc && !self);
+            const bool undecided = false;
 #else
-        const bool accept = test && box_accept;
-        const bool open = (test && !box_accept && probe_open) || (anc && !self);
-        const bool undecided = test && !box_accept && !probe_open;
+            const bool accept = test && box_accept;
+            const bool open = (test && !box_accept && probe_open) || (anc && !self);
+            const bool undecided = test && !box_accept && !probe_open;
 #endif
-        route(accept, open, undecided, bt);
-        RK_STAMP(2)
-    };
+            route(accept, open, undecided, bt);
+            RK_STAMP(2)
+        };
 
-    // Exact MAC test (all targets) of up to 64 queued candidates.
-    auto process_exact = [&]() __attribute__((always_inline)) {
-        const int k = n_uq < 64 ? n_uq : 64;
-        batch_t bt;
-        bt.active = lane < k;
-        bt.rec = bt.active ? L.uq[n_uq - 1 - lane] : 0u;
-        n_uq -= k;
-        const node_rec<F> *rec = P.node_rec + bt.rec;
-        bt.com = rec->com;
-        bt.mp = rec->mac;
-        bt.node = rec->dfs;
-        bt.nch = rec->nch;
-        bt.ra = rec->a;
-        bt.rb = rec->b;
-        const v4 com = bt.com;
-        const F mac_lh = mac_lhs<F>(MAC, bt.mp, mac_value);
-        bool fail;
+        // Exact MAC test (all targets) of up to 64 queued candidates.
+        auto process_exact = [&]() __attribute__((always_inline)) {
+            const int k = n_uq < 64 ? n_uq : 64;
+            batch_t bt;
+            bt.active = lane < k;
+            bt.rec = bt.active ? L.uq[n_uq - 1 - lane] : 0u;
+            n_uq -= k;
+            const node_rec<F> *rec = P.node_rec + bt.rec;
+            bt.com = rec->com;
+            bt.mp = rec->mac;
+            bt.node = rec->dfs;
+            bt.nch = rec->nch;
+            bt.ra = rec->a;
+            bt.rb = rec->b;
+            const v4 com = bt.com;
+            const F mac_lh = mac_lhs<F>(MAC, bt.mp, mac_value);
+            bool fail;
 #if RK_EXACT_TRANSPOSED
-        if (!BIG && k * (7 * R + 3) < T * 7) {
-            // Few candidates: lane = target. Every lane already keeps R targets of the group in registers (unused
-            // slots repeat target 0), so a candidate costs one broadcast LDS read and 7 R + 3 instructions instead of
-            // a share of the 7 T of the loop below. Same formula, same operands: same decision.
-            // The main loop keeps 64 free slots behind n_src in the source tile; the candidates are staged there.
-            v4 cd;
-            cd.x = com.x, cd.y = com.y, cd.z = com.z, cd.w = mac_lh;
-            if (bt.active) {
-                L.src[n_src + lane] = cd;
-            }
-            wave_sync();
-            unsigned long long fail_mask = 0ull;
-            for (int c = 0; c < k; ++c) {
-                const v4 cand = L.src[n_src + c];
-                bool f = false;
+            if (!BIG && k * (7 * R + 3) < T * 7) {
+                // Few candidates: lane = target. Every lane already keeps R targets of the group in registers (unused
+                // slots repeat target 0), so a candidate costs one broadcast LDS read and 7 R + 3 instructions instead of
+                // a share of the 7 T of the loop below. Same formula, same operands: same decision.
+                // The main loop keeps 64 free slots behind n_src in the source tile; the candidates are staged there.
+                v4 cd;
+                cd.x = com.x, cd.y = com.y, cd.z = com.z, cd.w = mac_lh;
+                if (bt.active) {
+                    L.src[n_src + lane] = cd;
+                }
+                wave_sync();
+                unsigned long long fail_mask = 0ull;
+                for (int c = 0; c < k; ++c) {
+                    const v4 cand = L.src[n_src + c];
+                    bool f = false;
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const F dx = cand.x - tp[r].x, dy = cand.y - tp[r].y, dz = cand.z - tp[r].z;
-                    const F d2 = rk_fma(dz, dz, rk_fma(dy, dy, dx * dx));
-                    f |= cand.w >= d2;
+                    for (int r = 0; r < R; ++r) {
+                        const F dx = cand.x - tp[r].x, dy = cand.y - tp[r].y, dz = cand.z - tp[r].z;
+                        const F d2 = rk_fma(dz, dz, rk_fma(dy, dy, dx * dx));
+                        f |= cand.w >= d2;
+                    }
+                    if (__builtin_amdgcn_ballot_w64(f) != 0ull) {
+                        fail_mask |= 1ull << c;
+                    }
                 }
-                if (__builtin_amdgcn_ballot_w64(f) != 0ull) {
-                    fail_mask |= 1ull << c;
-                }
-            }
-            fail = ((fail_mask >> lane) & 1ull) != 0ull;
-            wave_sync();
-        } else
+                fail = ((fail_mask >> lane) & 1ull) != 0ull;
+                wave_sync();
+            } else
 #endif
-        {
-            // min over the targets of the unsoftened squared distance to the node's centre of mass. The target
-            // coordinates are wave-uniform: they arrive through scalar loads as SGPR operands.
-            F mind2 = std::numeric_limits<F>::infinity();
-            for (int t = 0; t < TG; t += 4) {
+            {
+                // min over the targets of the unsoftened squared distance to the node's centre of mass. The target
+                // coordinates are wave-uniform: they arrive through scalar loads as SGPR operands.
+                F mind2 = std::numeric_limits<F>::infinity();
+                for (int t = 0; t < TG; t += 4) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int ti = (t + u < TG) ? t + u : TG - 1;
-                    const v4 tg = P.part4[gb + static_cast<uint32_t>(ti)];
-                    const F dx = com.x - tg.x, dy = com.y - tg.y, dz = com.z - tg.z;
-                    const F d2 = rk_fma(dz, dz, rk_fma(dy, dy, dx * dx));
-                    mind2 = rk_min(mind2, d2);
+                    for (int u = 0; u < 4; ++u) {
+                        const int ti = (t + u < TG) ? t + u : TG - 1;
+                        const v4 tg = P.part4[gb + static_cast<uint32_t>(ti)];
+                        const F dx = com.x - tg.x, dy = com.y - tg.y, dz = com.z - tg.z;
+                        const F d2 = rk_fma(dz, dz, rk_fma(dy, dy, dx * dx));
+                        mind2 = rk_min(mind2, d2);
+                    }
                 }
+                fail = mac_lh >= mind2;
             }
-            fail = mac_lh >= mind2;
-        }
-        route(bt.active && !fail, bt.active && fail, false, bt);
-        RK_STAMP(3)
-    };
+            route(bt.active && !fail, bt.active && fail, false, bt);
+            RK_STAMP(3)
+        };
 
-    // ---- list building ----
-    // Sources accepted for the whole supergroup: stream them from the pre-pass list through the tile.
-    {
-        const v4 *common = P.sup_common + static_cast<size_t>(sup_S) * SUP_CAPC;
+        // ---- list building ----
+        // Sources accepted for the whole supergroup: stream them from the pre-pass list through the tile.
+        {
+            const v4 *common = P.sup_common + static_cast<size_t>(sup_S) * SUP_CAPC;
 #ifdef RK_ABLATE_COMMON
-        sup_ncommon = 0; // diagnostic build: the supergroup's common sources are dropped
+            sup_ncommon = 0; // diagnostic build: the supergroup's common sources are dropped
 #endif
-        for (uint32_t base = 0; base < sup_ncommon;) {
-            const uint32_t room = static_cast<uint32_t>(SRC_CAP - n_src), left = sup_ncommon - base;
-            const uint32_t take = left < room ? left : room;
-            for (uint32_t j = lane; j < take; j += 64u) {
-                L.src[n_src + static_cast<int>(j)] = common[base + j];
+            for (uint32_t base = 0; base < sup_ncommon;) {
+                const uint32_t room = static_cast<uint32_t>(SRC_CAP - n_src), left = sup_ncommon - base;
+                const uint32_t take = left < room ? left : room;
+                for (uint32_t j = lane; j < take; j += 64u) {
+                    L.src[n_src + static_cast<int>(j)] = common[base + j];
+                }
+                n_src += static_cast<int>(take);
+                base += take;
+                wave_sync();
+                if (n_src == SRC_CAP) {
+                    flush(false);
+                }
             }
-            n_src += static_cast<int>(take);
-            base += take;
+        }
+        // Candidates the pre-pass left to the member groups: taken 64 at a time whenever the stack runs empty.
+        auto resid_load = [&](batch_t &bt) __attribute__((always_inline)) -> int {
+            if (sup_rpos >= sup_nresid) {
+                return 0;
+            }
+            const uint32_t left = sup_nresid - sup_rpos, k = left < 64u ? left : 64u;
+            bt.active = static_cast<uint32_t>(lane) < k;
+            bt.rec = bt.active ? P.sup_resid[static_cast<size_t>(sup_S) * SUP_CAPR + sup_rpos + static_cast<uint32_t>(lane)] : 0u;
+            sup_rpos += k;
+            const node_rec<F> *rec = P.node_rec + bt.rec;
+            bt.com = rec->com;
+            bt.mp = rec->mac;
+            bt.node = rec->dfs;
+            bt.nch = rec->nch;
+            bt.ra = rec->a;
+            bt.rb = rec->b;
+            return 1;
+        };
+        auto next_batch = [&](batch_t &bt) __attribute__((always_inline)) -> int {
+            const int k = pop_and_load(bt, 0, true);
+            return k ? k : resid_load(bt);
+        };
+        // ---- list building ----
+        // Queues are settled BEFORE the next batch of records is fetched, so that no candidate registers are live
+        // across the dense phase (register pressure decides the occupancy of this kernel).
+        bool done = false;
+        for (;;) {
+            // Room for the worst-case output of one pass (64 sources, 64 leaves); everything is settled at the end.
+            if (n_lq + 64 > LK_LQ_CAP || done) {
+                drain_leaves();
+            }
+            if (n_src + 64 > SRC_CAP || done) {
+                flush(done);
+            }
+            if (done) {
+                break;
+            }
+            if (n_uq >= 64) {
+                process_exact();
+                continue;
+            }
+            // Near the stack bound pop_and_load() descends one entry at a time, and LK_DFS_RESERVE (7 pending entries per
+            // level) only bounds a STRICT depth-first descent: settle the parked candidates first, so that everything an
+            // entry can push is on the stack before the next entry is popped.
+            if (n_uq > 0 && LK_STACK_CAP - LK_DFS_RESERVE - n_uq - size < 7) {
+                process_exact();
+                continue;
+            }
+            RK_STAMP(7)
+            batch_t A;
+            if (next_batch(A) == 0) {
+                // Stack and residual list exhausted: settle the undecided candidates (they may open new runs).
+                if (n_uq > 0) {
+                    process_exact();
+                } else {
+                    done = true;
+                }
+                continue;
+            }
+            process(A);
+        }
+
+        RK_STAMP(7)
+        // ---- interactions inside the group: its own particles as sources, self-pair masked ----
+        for (int b0 = 0; b0 < TG; b0 += SRC_CAP) {
+            const int n = (TG - b0) < SRC_CAP ? (TG - b0) : SRC_CAP;
+            for (int j = lane; j < n; j += 64) {
+                L.src[j] = P.part4[gb + static_cast<uint32_t>(b0 + j)];
+            }
             wave_sync();
-            if (n_src == SRC_CAP) {
-                flush(false);
+            int tloc[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                tloc[r] = tidx[r] < 0 ? -1 : static_cast<int>(tb - gb) + tidx[r] - b0;
+            }
+            lk_eval_tile<F, Q, R, true, ND>(L.src, n, (n * inv_ns) >> 16, sp, NS, true, lane_on, tp, acc, eps2, tloc);
+            wave_sync();
+        }
+
+        RK_STAMP(5)
+        // ---- sum the source splits in a fixed order, scale by G, write out ----
+        const F G = P.G;
+        if (NS > 1) {
+            // One target slot r at a time: the scratch then needs 64 * NR values (<= 2 KiB), well inside
+            // this wave's LDS region for every F, Q and R.
+            F *red = reinterpret_cast<F *>(&L);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (lane_on) {
+#pragma unroll
+                    for (int k = 0; k < NR; ++k) {
+                        red[(sp_raw * TP + ts) * NR + k] = acc[r][k];
+                    }
+                }
+                wave_sync();
+                if (lane_on && sp_raw == 0) {
+#pragma unroll
+                    for (int k = 0; k < NR; ++k) {
+                        F sum = F(0);
+                        for (int s = 0; s < NS; ++s) {
+                            sum += red[(s * TP + ts) * NR + k];
+                        }
+                        acc[r][k] = sum;
+                    }
+                }
+                wave_sync();
             }
         }
-    }
-    // Candidates the pre-pass left to the member groups: taken 64 at a time whenever the stack runs empty.
-    auto resid_load = [&](batch_t &bt) __attribute__((always_inline)) -> int {
-        if (sup_rpos >= sup_nresid) {
-            return 0;
-        }
-        const uint32_t left = sup_nresid - sup_rpos, k = left < 64u ? left : 64u;
-        bt.active = static_cast<uint32_t>(lane) < k;
-        bt.rec = bt.active ? P.sup_resid[static_cast<size_t>(sup_S) * SUP_CAPR + sup_rpos + static_cast<uint32_t>(lane)] : 0u;
-        sup_rpos += k;
-        const node_rec<F> *rec = P.node_rec + bt.rec;
-        bt.com = rec->com;
-        bt.mp = rec->mac;
-        bt.node = rec->dfs;
-        bt.nch = rec->nch;
-        bt.ra = rec->a;
-        bt.rb = rec->b;
-        return 1;
-    };
-    auto next_batch = [&](batch_t &bt) __attribute__((always_inline)) -> int {
-        const int k = pop_and_load(bt, 0, true);
-        return k ? k : resid_load(bt);
-    };
-    // ---- list building ----
-    // Queues are settled BEFORE the next batch of records is fetched, so that no candidate registers are live
-    // across the dense phase (register pressure decides the occupancy of this kernel).
-    bool done = false;
-    for (;;) {
-        // Room for the worst-case output of one pass (64 sources, 64 leaves); everything is settled at the end.
-        if (n_lq + 64 > LK_LQ_CAP || done) {
-            drain_leaves();
-        }
-        if (n_src + 64 > SRC_CAP || done) {
-            flush(done);
-        }
-        if (done) {
-            break;
-        }
-        if (n_uq >= 64) {
-            process_exact();
-            continue;
-        }
-        // Near the stack bound pop_and_load() descends one entry at a time, and LK_DFS_RESERVE (7 pending entries per
-        // level) only bounds a STRICT depth-first descent: settle the parked candidates first, so that everything an
-        // entry can push is on the stack before the next entry is popped.
-        if (n_uq > 0 && LK_STACK_CAP - LK_DFS_RESERVE - n_uq - size < 7) {
-            process_exact();
-            continue;
+        if (lane_on && sp_raw == 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (tidx[r] >= 0) {
+                    const uint32_t o = out_index(P, tb + static_cast<uint32_t>(tidx[r]));
+#pragma unroll
+                    for (int k = 0; k < NR; ++k) {
+                        if (ND == 3 || Q == 1 || k != 2) { // a quadtree has no z acceleration (and no array for it)
+                            P.out[k][o] = acc[r][k] * G;
+                        }
+                    }
+                }
+            }
         }
         RK_STAMP(7)
-        batch_t A;
-        if (next_batch(A) == 0) {
-            // Stack and residual list exhausted: settle the undecided candidates (they may open new runs).
-            if (n_uq > 0) {
-                process_exact();
-            } else {
-                done = true;
-            }
-            continue;
-        }
-        process(A);
-    }
-
-    RK_STAMP(7)
-    // ---- interactions inside the group: its own particles as sources, self-pair masked ----
-    for (int b0 = 0; b0 < TG; b0 += SRC_CAP) {
-        const int n = (TG - b0) < SRC_CAP ? (TG - b0) : SRC_CAP;
-        for (int j = lane; j < n; j += 64) {
-            L.src[j] = P.part4[gb + static_cast<uint32_t>(b0 + j)];
-        }
-        wave_sync();
-        int tloc[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            tloc[r] = tidx[r] < 0 ? -1 : static_cast<int>(tb - gb) + tidx[r] - b0;
-        }
-        lk_eval_tile<F, Q, R, true, ND>(L.src, n, (n * inv_ns) >> 16, sp, NS, true, lane_on, tp, acc, eps2, tloc);
-        wave_sync();
-    }
-
-    RK_STAMP(5)
-    // ---- sum the source splits in a fixed order, scale by G, write out ----
-    const F G = P.G;
-    if (NS > 1) {
-        // One target slot r at a time: the scratch then needs 64 * NR values (<= 2 KiB), well inside
-        // this wave's LDS region for every F, Q and R.
-        F *red = reinterpret_cast<F *>(&L);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if (lane_on) {
-#pragma unroll
-                for (int k = 0; k < NR; ++k) {
-                    red[(sp_raw * TP + ts) * NR + k] = acc[r][k];
-                }
-            }
-            wave_sync();
-            if (lane_on && sp_raw == 0) {
-#pragma unroll
-                for (int k = 0; k < NR; ++k) {
-                    F sum = F(0);
-                    for (int s = 0; s < NS; ++s) {
-                        sum += red[(s * TP + ts) * NR + k];
-                    }
-                    acc[r][k] = sum;
-                }
-            }
-            wave_sync();
-        }
-    }
-    if (lane_on && sp_raw == 0) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if (tidx[r] >= 0) {
-                const uint32_t o = out_index(P, tb + static_cast<uint32_t>(tidx[r]));
-#pragma unroll
-                for (int k = 0; k < NR; ++k) {
-                    if (ND == 3 || Q == 1 || k != 2) { // a quadtree has no z acceleration (and no array for it)
-                        P.out[k][o] = acc[r][k] * G;
-                    }
-                }
-            }
-        }
-    }
-    RK_STAMP(7)
-    RK_STAMP_FLUSH
+        RK_STAMP_FLUSH
 #ifdef RK_TRACE
-    if (!BIG && lane == 0 && P.dbg) {
-        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
-        P.dbg[4u * g] = tr_t0;
-        P.dbg[4u * g + 1u] = __builtin_amdgcn_s_memrealtime();
-        P.dbg[4u * g + 2u] = (static_cast<unsigned long long>(xcc) << 32) | hw;
-        P.dbg[4u * g + 3u] = (static_cast<unsigned long long>(R) << 32) | static_cast<unsigned>(T);
-    }
+        if (!BIG && lane == 0 && P.dbg) {
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+            P.dbg[4u * g] = tr_t0;
+            P.dbg[4u * g + 1u] = __builtin_amdgcn_s_memrealtime();
+            P.dbg[4u * g + 2u] = (static_cast<unsigned long long>(xcc) << 32) | hw;
+            P.dbg[4u * g + 3u] = (static_cast<unsigned long long>(R) << 32) | static_cast<unsigned>(T);
+        }
 #endif
     }; // run_targets
     if constexpr (BIG) {
