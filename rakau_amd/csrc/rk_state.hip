@@ -644,13 +644,17 @@ void census_impl(rk_state &s, int64_t p_begin, int64_t p_end, double mac_value, 
     }
 }
 
-// Launch plan for the critical nodes [g_lo, g_hi): per class, the nodes of the range sorted by decreasing traversal work
-// (longest processing time first), so that a launch of only a few rounds of waves ends with its lightest nodes. The work
-// is the integer census of rk_group_work(), computed once per tree and MAC value. (Sorting whole supergroups by their
-// mean work instead -- spatially compact runs that share the pre-pass lists -- measured 3-7 % slower from 100k
-// particles to the 0.5M-particle shards of the 4M tree: tools/r02_job27.sh.)
+// Launch plan for the critical nodes [g_lo, g_hi): the dispatch order of a repeated call, per class. The work of a node
+// is the integer census of rk_group_work(), computed once per tree and MAC value.
+//  * lpt (calls of at most RK_PLAN_MAX_GROUPS nodes): sorted by decreasing work (longest processing time first), so
+//    that a launch of only a few rounds of waves ends with its lightest nodes. (Sorting whole supergroups by their mean
+//    work instead -- spatially compact runs that share the pre-pass lists -- measured 3-7 % slower from 100k particles
+//    to the 0.5M-particle shards of the 4M tree: tools/r02_job27.sh.)
+//  * otherwise: Morton order (neighbouring nodes share tree nodes and leaves in the L2), but the lightest quarter of the
+//    nodes goes last: the device then drains over the duration of short waves instead of average ones (4M: 2.32-2.33
+//    -> 2.28 ms; a full LPT order costs 60 % there: tools/r02_job41.sh).
 template <typename F>
-void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64_t g_hi, double mac_value)
+void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64_t g_hi, double mac_value, bool lpt)
 {
     ensure_mirrors(s);
     if (s.work_cache.empty() || s.work_mac_value != mac_value) {
@@ -671,8 +675,26 @@ void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64
         const auto e = std::lower_bound(l.begin(), l.end(), static_cast<uint32_t>(g_hi));
         const auto first = static_cast<std::ptrdiff_t>(lists.size());
         lists.insert(lists.end(), b, e);
-        std::stable_sort(lists.begin() + first, lists.end(),
-                         [&](uint32_t a, uint32_t b2) { return s.work_cache[a] > s.work_cache[b2]; });
+        if (lpt) {
+            std::stable_sort(lists.begin() + first, lists.end(),
+                             [&](uint32_t a, uint32_t b2) { return s.work_cache[a] > s.work_cache[b2]; });
+        } else if (lists.size() - static_cast<size_t>(first) > 1u) {
+            // Morton order, the lightest quarter of the nodes moved to the end (in Morton order among themselves).
+            static const double tail_frac = [] {
+                const char *e = std::getenv("RK_PLAN_TAIL"); // fraction of the nodes dispatched last (0 = none)
+                const double v = e ? std::atof(e) : 0.25;
+                return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+            }();
+            std::vector<uint64_t> w;
+            w.reserve(lists.size() - static_cast<size_t>(first));
+            for (auto it = lists.begin() + first; it != lists.end(); ++it) {
+                w.push_back(s.work_cache[*it]);
+            }
+            const size_t k = std::min(w.size() - 1u, static_cast<size_t>(static_cast<double>(w.size()) * tail_frac));
+            std::nth_element(w.begin(), w.begin() + static_cast<std::ptrdiff_t>(k), w.end());
+            const uint64_t thr = w[k];
+            std::stable_partition(lists.begin() + first, lists.end(), [&](uint32_t a) { return s.work_cache[a] >= thr; });
+        }
     }
     s.plan.off[rk::n_classes] = static_cast<int64_t>(lists.size());
     if (s.plan.alloc < static_cast<int64_t>(lists.size())) {
@@ -848,7 +870,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
         std::copy(s.class2_off, s.class2_off + rk::n_classes + 1, s.cur_off);
         const int64_t big_b = cb[rk::big_class], big_e = ce[rk::big_class];
         {
-            // RK_PLAN: 0 = never reorder, 1 = reorder repeated calls with few critical nodes (default), 2 = always.
+            // RK_PLAN: 0 = never reorder, 1 = reorder repeated calls (default), 2 = reorder every call.
             static const int plan_mode = [] {
                 const char *e = std::getenv("RK_PLAN");
                 return e ? std::atoi(e) : 1;
@@ -861,11 +883,18 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                                 && s.plan.mac_value == mac_value;
             const bool repeats = s.have_last_key && s.last_key.p_begin == p_begin && s.last_key.p_end == p_end
                                  && s.last_key.mac_value == mac_value;
+            // Beyond this many nodes the launch is so many rounds of waves deep that its tail no longer matters, and the
+            // contiguous slice of the Morton order per XCD (xcd_mode 1) wins: 16M fp64 +0.6 %, 64M +1.5 % with a plan.
+            static const int64_t plan_tail_max_groups = [] {
+                const char *e = std::getenv("RK_PLAN_TAIL_MAX_GROUPS");
+                return e ? std::atoll(e) : int64_t(250000);
+            }();
             const bool want = g_hi > g_lo
-                              && (plan_mode == 2 || (plan_mode == 1 && g_hi - g_lo <= plan_max_groups && (cached || repeats)));
+                              && (plan_mode == 2
+                                  || (plan_mode == 1 && g_hi - g_lo <= plan_tail_max_groups && (cached || repeats)));
             if (want) {
                 if (!cached) {
-                    build_plan<F>(s, p_begin, p_end, g_lo, g_hi, mac_value);
+                    build_plan<F>(s, p_begin, p_end, g_lo, g_hi, mac_value, g_hi - g_lo <= plan_max_groups);
                 }
                 s.cur_lists = static_cast<const uint32_t *>(s.plan.d_lists);
                 std::copy(s.plan.off, s.plan.off + rk::n_classes + 1, s.cur_off);
