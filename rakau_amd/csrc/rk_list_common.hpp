@@ -144,6 +144,13 @@ __device__ __forceinline__ unsigned xcd_map_block(unsigned b, unsigned nb, int m
     if (mode == 1) {
         return xcd_chunked_block(b, nb);
     }
+    if (mode == 5) {
+        // Launch plan with a light tail (rk_state.hip): the first three quarters of the list are Morton-ordered nodes, a
+        // contiguous slice of them per XCD as in mode 1; the last quarter -- the light nodes, dispatched last -- is dealt
+        // to the XCDs in chunks as in mode 0.
+        const unsigned nt = nb >> 2, nbulk = nb - nt;
+        return b < nbulk ? xcd_chunked_block(b, nbulk) : nbulk + xcd_map_block(b - nbulk, nt, 0);
+    }
     // Blocks beyond the last full round of 8 chunks keep their identity mapping.
     const unsigned span = 8u * XCD_CHUNK, full = nb - nb % span;
     if (b >= full) {
