@@ -37,6 +37,7 @@ __host__ __device__ constexpr int nres_of(int q)
 
 // Target groups (critical nodes) are binned by the number of targets each lane of a wave holds:
 // class c holds groups with size <= 64 * R(c); the last class is served by the block-per-group kernel.
+constexpr uint32_t RK_PLAN_PAD_VALUE = 0xffffffffu; // launch-plan list entry without a critical node (skipped)
 constexpr int n_classes = 7;  // classes 0..5 are served by wave kernels, the last one by the block-per-group kernel
 constexpr int big_class = n_classes - 1;
 constexpr int n_list_R = 6;   // variant 2: class c keeps R = c + 1 targets per lane

@@ -49,6 +49,9 @@ __global__ void __launch_bounds__(64 * (BIG ? LK_BIG_WPB : RK_WPB), BIG ? (sizeo
     lk_wave_lds<F> &L = s_lds[wib];
 
     const uint32_t g = __builtin_amdgcn_readfirstlane(list[wave]);
+    if (g == RK_PLAN_PAD_VALUE) {
+        return; // padding of a launch plan
+    }
     const uint4 c = P.crit[g];
     const uint32_t gb = c.x, ge = c.y, cnode = c.z;
     const int TG = static_cast<int>(ge - gb);

@@ -64,6 +64,9 @@ __global__ void __launch_bounds__(64 * (1 + R), (sizeof(F) == 4 ? RK_PC_W : RK_P
         return;
     }
     const uint32_t g = __builtin_amdgcn_readfirstlane(list[blk]);
+    if (g == RK_PLAN_PAD_VALUE) {
+        return; // padding of a launch plan
+    }
     const uint4 c = P.crit[g];
     const uint32_t tb = c.x, te = c.y, cnode = c.z;
     const int T = static_cast<int>(te - tb);

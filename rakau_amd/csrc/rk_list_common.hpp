@@ -126,7 +126,8 @@ __device__ __forceinline__ unsigned xcd_chunked_block(unsigned b, unsigned nb)
 
 // mode 0: XCD x walks chunks x, x + 8, x + 16, ... of XCD_CHUNK consecutive blocks (L2 locality inside a
 // chunk, work spread evenly over the XCDs whatever the spatial variation of the group costs);
-// mode 1: one contiguous slice per XCD; mode 2: identity (hardware round-robin);
+// mode 1: one contiguous slice per XCD; mode 2: identity (hardware round-robin: block i on XCD i % 8; the light-tail launch
+// plan of rk_state.hip lays its list out for this);
 // modes 3, 4: mode 1 with the slice walked from both ends alternately (3) or backwards (4) -- experiments on where
 // the expensive groups of a centrally condensed system end up in the dispatch order.
 constexpr unsigned XCD_CHUNK = 16;
@@ -143,13 +144,6 @@ __device__ __forceinline__ unsigned xcd_map_block(unsigned b, unsigned nb, int m
     }
     if (mode == 1) {
         return xcd_chunked_block(b, nb);
-    }
-    if (mode == 5) {
-        // Launch plan with a light tail (rk_state.hip): the first three quarters of the list are Morton-ordered nodes, a
-        // contiguous slice of them per XCD as in mode 1; the last quarter -- the light nodes, dispatched last -- is dealt
-        // to the XCDs in chunks as in mode 0.
-        const unsigned nt = nb >> 2, nbulk = nb - nt;
-        return b < nbulk ? xcd_chunked_block(b, nbulk) : nbulk + xcd_map_block(b - nbulk, nt, 0);
     }
     // Blocks beyond the last full round of 8 chunks keep their identity mapping.
     const unsigned span = 8u * XCD_CHUNK, full = nb - nb % span;

@@ -652,7 +652,17 @@ void census_impl(rk_state &s, int64_t p_begin, int64_t p_end, double mac_value, 
 //    to the 0.5M-particle shards of the 4M tree: tools/r02_job27.sh.)
 //  * otherwise: Morton order (neighbouring nodes share tree nodes and leaves in the L2), but the lightest quarter of the
 //    nodes goes last: the device then drains over the duration of short waves instead of average ones (4M: 2.32-2.33
-//    -> 2.28 ms; a full LPT order costs 60 % there: tools/r02_job41.sh).
+//    -> 2.27-2.28 ms; a full LPT order costs 60 % there: tools/r02_job41.sh), and every XCD works through one spatial
+//    region of the range in ALL class kernels (same time, 8.5 % fewer bytes fetched past the L2: tools/r02_job46.sh).
+bool plan_regions_enabled()
+{
+    static const bool on = [] {
+        const char *e = std::getenv("RK_PLAN_REGIONS"); // 0: one Morton-ordered list per class, dealt to the XCDs in chunks
+        return !(e && std::atoi(e) == 0);
+    }();
+    return on;
+}
+
 template <typename F>
 void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64_t g_hi, double mac_value, bool lpt)
 {
@@ -665,6 +675,7 @@ void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64
     }
     std::vector<uint32_t> lists;
     lists.reserve(static_cast<size_t>(g_hi - g_lo));
+    std::vector<uint32_t> region_bound; // light-tail plans: first node of each of the 8 per-XCD regions (+ g_hi)
     for (int c = 0; c < rk::n_classes; ++c) {
         s.plan.off[c] = static_cast<int64_t>(lists.size());
         if (c == rk::big_class) {
@@ -693,7 +704,53 @@ void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64
             const size_t k = std::min(w.size() - 1u, static_cast<size_t>(static_cast<double>(w.size()) * tail_frac));
             std::nth_element(w.begin(), w.begin() + static_cast<std::ptrdiff_t>(k), w.end());
             const uint64_t thr = w[k];
-            std::stable_partition(lists.begin() + first, lists.end(), [&](uint32_t a) { return s.work_cache[a] >= thr; });
+            if (plan_regions_enabled()) {
+                // One spatial region of the range per XCD, the SAME regions for every class kernel: the members of a
+                // supergroup (and neighbouring nodes generally) then run on one XCD whatever their class, and the
+                // pre-pass lists, tree nodes and leaves they share are fetched into one L2 instead of several.
+                // Regions are cut at equal census work. Entry i of the list is served by block i, i.e. by XCD i % 8:
+                // the per-XCD queues (bulk in Morton order, then the light nodes) are interleaved and padded with
+                // padding entries, which the kernels skip.
+                if (region_bound.empty()) {
+                    region_bound.assign(9, static_cast<uint32_t>(g_hi));
+                    region_bound[0] = static_cast<uint32_t>(g_lo);
+                    double total = 0., run = 0.;
+                    for (int64_t g = g_lo; g < g_hi; ++g) {
+                        total += static_cast<double>(s.work_cache[static_cast<size_t>(g)]);
+                    }
+                    int x = 1;
+                    for (int64_t g = g_lo; g < g_hi && x < 8; ++g) {
+                        run += static_cast<double>(s.work_cache[static_cast<size_t>(g)]);
+                        while (x < 8 && run >= total * x / 8.) {
+                            region_bound[static_cast<size_t>(x++)] = static_cast<uint32_t>(g + 1);
+                        }
+                    }
+                }
+                std::vector<uint32_t> q[8];
+                for (int pass = 0; pass < 2; ++pass) { // bulk, then light
+                    int x = 0;
+                    for (auto it = lists.begin() + first; it != lists.end(); ++it) {
+                        while (x < 7 && *it >= region_bound[static_cast<size_t>(x) + 1u]) {
+                            ++x;
+                        }
+                        if ((s.work_cache[*it] >= thr) == (pass == 0)) {
+                            q[x].push_back(*it);
+                        }
+                    }
+                }
+                size_t longest = 0;
+                for (const auto &v : q) {
+                    longest = std::max(longest, v.size());
+                }
+                lists.resize(static_cast<size_t>(first));
+                for (size_t pos = 0; pos < longest; ++pos) {
+                    for (const auto &v : q) {
+                        lists.push_back(pos < v.size() ? v[pos] : rk::RK_PLAN_PAD_VALUE);
+                    }
+                }
+            } else {
+                std::stable_partition(lists.begin() + first, lists.end(), [&](uint32_t a) { return s.work_cache[a] >= thr; });
+            }
         }
     }
     s.plan.off[rk::n_classes] = static_cast<int64_t>(lists.size());
@@ -904,14 +961,9 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                 }
                 // Heavy-first order: deal chunks of consecutive list entries round-robin to the XCDs.
                 p.xcd_mode = 0;
-                // Light-tail order: a contiguous slice of the Morton-ordered three quarters per XCD, the light quarter in
-                // chunks (xcd_map_block mode 5; 0 = chunks throughout: +0.7 % at 4M).
-                static const int plan_tail_xcd = [] {
-                    const char *e = std::getenv("RK_PLAN_TAIL_XCD");
-                    return e ? std::atoi(e) : 5;
-                }();
-                if (g_hi - g_lo > plan_max_groups) {
-                    p.xcd_mode = plan_tail_xcd;
+                // Light-tail order: the plan list interleaves the per-XCD queues itself (block i serves entry i).
+                if (g_hi - g_lo > plan_max_groups && plan_regions_enabled()) {
+                    p.xcd_mode = 2;
                 }
             }
         }

@@ -26,9 +26,14 @@ def time_range(b, e, reps=12):
         ms.append(st.last_kernel_ms())
     return float(np.median(ms[2:]))
 
+# Leave the idle power state first (a 4M call needs ~15 calls after idling before its duration settles).
+for _ in range(40):
+    st.acc_pot_device(0, mv, ptrs, p_begin=0, p_end=n, offset_output=False)
+torch.cuda.synchronize()
+
 for variant in variants:
     st.set_variant(variant)
-    full = time_range(0, n)
+    full = time_range(0, n, reps=24)
     print("variant %d full range: %.3f ms" % (variant, full))
     for world in (2, 4, 8):
         for name, w in (("work", work),) if len(variants) > 1 else (("particles", None), ("work", work)):
