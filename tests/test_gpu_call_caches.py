@@ -50,3 +50,51 @@ def test_call_sequences_with_history_equal_fresh_calls(n):
             fresh.close()
             for g, r in zip(got, ref):
                 assert np.array_equal(g, r), (i, q, theta, rng, ordered)
+
+
+def test_light_tail_plan_equals_plain_order(tmp_path):
+    """The launch plan of calls above RK_PLAN_MAX_GROUPS critical nodes (Morton order per XCD region, light nodes last,
+    padded queues) only permutes the dispatch: with the limit lowered so that a 60k-particle tree takes that path, full
+    range, sub-ranges, Q = 0 / 2, ordered outputs and both list kernels give the bits of RK_PLAN=0."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import sys, numpy as np, torch, oracle, rakau_amd
+from helpers import state_from_oracle
+n = 60000
+m, x, y, z = oracle.plummer(n, np.float32)
+ot = oracle.Tree(x, y, z, m)
+st = state_from_oracle(ot)
+st.set_perm(ot.codes_perms()["perm"])
+cr = st.crit_ranges()
+cuts = [0, int(cr[len(cr) // 3, 0]), n]
+mv = rakau_amd.mac_value_of(0.75, "bh", np.float32)
+res = {}
+for variant in (0, 2, 3):
+    st.set_variant(variant)
+    for q in (0, 2):
+        for b, e in ((0, n), (cuts[0], cuts[1]), (cuts[1], cuts[2])):
+            for ordered in (False, True):
+                outs = [torch.zeros(n, dtype=torch.float32, device="cuda") for _ in range(rakau_amd.NRES[q])]
+                for rep in range(3):  # direct call, plan + capture, replay
+                    st.acc_pot_device(q, mv, [o.data_ptr() for o in outs], eps2=1e-6, p_begin=b, p_end=e, ordered=ordered)
+                torch.cuda.synchronize()
+                res["v%d_q%d_%d_%d_%d" % (variant, q, b, e, ordered)] = np.stack([o.cpu().numpy() for o in outs])
+np.savez(sys.argv[1], **res)
+"""
+    files = []
+    for name, extra in (("plain", {"RK_PLAN": "0"}), ("tail", {"RK_PLAN_MAX_GROUPS": "64"}),
+                        ("tail_chunks", {"RK_PLAN_MAX_GROUPS": "64", "RK_PLAN_REGIONS": "0"})):
+        env = dict(os.environ, **extra)
+        env["PYTHONPATH"] = os.pathsep.join([root, os.path.join(root, "tests"), env.get("PYTHONPATH", "")])
+        f = str(tmp_path / (name + ".npz"))
+        out = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+        assert out.returncode == 0, out.stderr[-2000:]
+        files.append(np.load(f))
+    assert len(files[0].files) == 36
+    for k in files[0].files:
+        assert np.isfinite(files[0][k]).all()
+        assert np.array_equal(files[0][k], files[1][k]), k
+        assert np.array_equal(files[0][k], files[2][k]), k
