@@ -30,7 +30,7 @@
  *                                rk_state_tree_info, rk_state_device_ptr, rk_state_set_perm, rk_set_build_exact,
  *                                rk_pool_trim
  *   CPU share of kwargs::split   rk_cpu_engine_run (AVX-512 flavour of the header's CPU engine, chosen at run time)
- *   diagnostics                  rk_state_info, rk_state_ndim, rk_last_kernel_ms, rk_count_interactions,
+ *   diagnostics                  rk_state_info, rk_state_ndim, rk_last_kernel_ms, rk_state_set_timing, rk_count_interactions,
  *                                rk_set_kernel_variant
  *
  * Plain C: pointers and sizes only. All functions are blocking and may be called from any thread;
@@ -170,6 +170,13 @@ RK_EXPORT int rk_acc_pot_device(rk_state *s, int q, int64_t p_begin, int64_t p_e
  * ms[0] = elapsed milliseconds, first launch start -> last launch end.
  */
 RK_EXPORT int rk_last_kernel_ms(rk_state *s, float *ms);
+
+/*
+ * Kernel timing of rk_acc_pot_device() calls on or off (default: on). Each of the two timing events is a barrier packet
+ * between consecutive calls on a stream; a caller that issues calls back to back and never asks for rk_last_kernel_ms()
+ * saves them (4M particles: 2.27 -> 2.25 ms per call, 500k: 0.38 -> 0.36, 100k: 0.19 -> 0.17). rk_last_kernel_ms() fails while timing is off.
+ */
+RK_EXPORT int rk_state_set_timing(rk_state *s, int on);
 
 /*
  * Replication across GPUs. rk_state_export() lists the device buffers that make up a state

@@ -26,7 +26,7 @@ SYMBOLS = [
     "rk_state_import", "rk_state_clone", "rk_set_kernel_variant", "rk_device_memcpy", "rk_count_interactions", "rk_state_build",
     "rk_state_tree_info", "rk_state_download", "rk_state_build_device", "rk_state_set_perm", "rk_state_device_ptr",
     "rk_state_rebuild_device", "rk_pool_trim", "rk_set_build_exact", "rk_cpu_engine_run", "rk_group_work", "rk_state_create_nd", "rk_state_build_nd",
-    "rk_state_ndim", "rk_host_alloc", "rk_host_free",
+    "rk_state_ndim", "rk_host_alloc", "rk_host_free", "rk_state_set_timing",
     # host-side tree builder (include/rakau_amd_tree.h)
     "rk_tree_create", "rk_tree_create_nd", "rk_tree_destroy", "rk_tree_info", "rk_tree_get", "rk_tree_nodes", "rk_tree_state",
     "rk_tree_acc_pot", "rk_tree_exact", "rk_tree_update_particles", "rk_tree_cpu_acc_pot",
@@ -81,6 +81,7 @@ def lib():
     L.rk_acc_pot_device.argtypes = [vp, ci, i64, i64, C.POINTER(vp), dbl, dbl, dbl, ci, vp]
     L.rk_host_alloc.argtypes = [C.POINTER(vp), i64]
     L.rk_host_free.argtypes = [vp]
+    L.rk_state_set_timing.argtypes = [vp, ci]
     L.rk_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.rk_state_export.argtypes = [vp, C.POINTER(ci), C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)]
     L.rk_state_import.argtypes = [C.POINTER(vp), ci, ci, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)]

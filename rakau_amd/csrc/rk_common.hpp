@@ -236,7 +236,8 @@ struct rk_state {
     bool have_last_key = false;
     hipGraphExec_t graph_exec = nullptr;
     hipStream_t cap_stream = nullptr;
-    bool timed = false;
+    bool timed = false;  // the last call recorded ev0 / ev1
+    bool timing = true;  // rk_state_set_timing
     int variant = 0;
     // Group lists the class kernels of the current call read: the state's lists (ascending critical nodes per class,
     // RK_BUF_CLASS + class2_off) or a launch plan.

@@ -775,6 +775,15 @@ void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64
     }
 }
 
+bool super_cache_enabled()
+{
+    static const bool on = [] {
+        const char *e = std::getenv("RK_SUPER_CACHE"); // 0 disables the reuse of the pre-pass lists across calls
+        return !(e && std::atoi(e) == 0);
+    }();
+    return on;
+}
+
 template <typename F>
 void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d_out, double mac_value, double G,
               double eps2, int offset_output, hipStream_t stream, bool allow_graph = true)
@@ -868,7 +877,12 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
         RK_HIP(hipEventCreate(&s.ev0));
         RK_HIP(hipEventCreate(&s.ev1));
     }
-    RK_HIP(hipEventRecord(s.ev0, stream));
+    // allow_graph is false on the host-output path, which waits on ev1 for completion.
+    const bool need_done_event = !allow_graph;
+    if (s.timing) {
+        RK_HIP(hipEventRecord(s.ev0, stream));
+    }
+    bool ran_super = false;
     p.super_k = 0;
     p.n_crit = static_cast<uint32_t>(s.n_crit);
     p.sup_common = nullptr;
@@ -973,11 +987,9 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
         // Supergroup pre-pass: skipped when the scratch already holds these supergroups for this MAC value.
         const int64_t sb = (p.super_k && g_hi > g_lo) ? g_lo / s.super_k : 0,
                       se = (p.super_k && g_hi > g_lo) ? (g_hi - 1) / s.super_k + 1 : 0;
-        static const bool sup_cache = [] {
-            const char *e = std::getenv("RK_SUPER_CACHE"); // 0 disables the reuse
-            return !(e && std::atoi(e) == 0);
-        }();
+        const bool sup_cache = super_cache_enabled();
         const bool need_super = se > sb && !(sup_cache && s.sup_mac == mac_value && s.sup_b <= sb && se <= s.sup_e);
+        ran_super = need_super;
         if (!s.sup_ev) {
             RK_HIP(hipEventCreateWithFlags(&s.sup_ev, hipEventDisableTiming));
         }
@@ -1105,10 +1117,17 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
         } else if (!(s.sup_mac == mac_value && s.sup_b <= sb2 && se2 <= s.sup_e)) {
             s.sup_mac = mac_value, s.sup_b = sb2, s.sup_e = se2;
         }
-        RK_HIP(hipEventRecord(s.sup_ev, stream));
+        // Marks the completion of the pre-pass whose lists later calls (possibly on other streams) may reuse.
+        if (ran_super && super_cache_enabled()) {
+            RK_HIP(hipEventRecord(s.sup_ev, stream));
+        }
     }
-    RK_HIP(hipEventRecord(s.ev1, stream));
-    s.timed = true;
+    // Every event record is a barrier packet between this call and the next one on the stream (~10 us each on the GPU):
+    // timing events only if wanted (rk_state_set_timing), the completion event only where something waits on it.
+    if (s.timing || need_done_event) {
+        RK_HIP(hipEventRecord(s.ev1, stream));
+    }
+    s.timed = s.timing;
 }
 
 void check_call(const rk_state *s, int q, void *const *out, double mac_value, double G, double eps2)
@@ -1496,6 +1515,16 @@ int rk_acc_pot(rk_state *s, int q, int64_t p_begin, int64_t p_end, void *const *
     });
 }
 
+int rk_state_set_timing(rk_state *s, int on)
+{
+    return guard([&] {
+        if (!s) {
+            throw rk::error(RK_EINVAL, "null state");
+        }
+        s->timing = on != 0;
+    });
+}
+
 int rk_last_kernel_ms(rk_state *s, float *ms)
 {
     return guard([&] {
@@ -1503,7 +1532,7 @@ int rk_last_kernel_ms(rk_state *s, float *ms)
             throw rk::error(RK_EINVAL, "null argument");
         }
         if (!s->timed) {
-            throw rk::error(RK_EINVAL, "no traversal has been run on this state");
+            throw rk::error(RK_EINVAL, "no timed traversal has been run on this state (rk_state_set_timing)");
         }
         device_guard dg(s->device);
         RK_HIP(hipEventSynchronize(s->ev1));

@@ -241,6 +241,10 @@ class State:
         _capi.check(_capi.lib().rk_group_work(self._h, mac_value, out.ctypes.data))
         return out
 
+    def set_timing(self, on):
+        """rk_state_set_timing: record (or not) the HIP events behind last_kernel_ms() around every device-output call."""
+        _capi.check(_capi.lib().rk_state_set_timing(self._h, int(bool(on))))
+
     def last_kernel_ms(self):
         ms = C.c_float()
         _capi.check(_capi.lib().rk_last_kernel_ms(self._h, C.byref(ms)))
