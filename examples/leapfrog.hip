@@ -175,6 +175,7 @@ static int run(const options &o)
     rk_state *st = nullptr;
     RK_OK_OR_DIE(rk_state_build_nd(&st, 3, o.f64 ? RK_F64 : RK_F32, o.geom ? RK_MAC_BH_GEOM : RK_MAC_BH, 0, parts, 1, n,
                                    0., 16, 128));
+    RK_OK_OR_DIE(rk_state_set_timing(st, 0)); // this loop never asks for rk_last_kernel_ms()
     auto accs = [&] { RK_OK_OR_DIE(rk_acc_pot_device(st, q, 0, n, outs, mac_value, 1., eps2, RK_OUT_ORDERED, nullptr)); };
     auto energy = [&](double &kin, double &pot) {
         hipLaunchKernelGGL((k_energy<F>), dim3(256), dim3(256), 0, nullptr, vel[0], vel[1], vel[2], mass, out[3], n, d_partial);
