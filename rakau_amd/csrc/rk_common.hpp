@@ -253,8 +253,7 @@ struct rk_state {
         int64_t alloc = 0; // entries allocated
         int64_t off[rk::n_classes + 1] = {};
     } plan;
-    std::vector<uint64_t> work_cache; // rk_group_work() of the whole tree at work_mac_value (empty: not computed)
-    double work_mac_value = 0.;
+    std::vector<uint64_t> work_cache; // launch-plan weight of every critical node (its size; empty: not computed)
     // Scratch of the supergroup pre-pass (allocated on first use).
     void *sup_common = nullptr, *sup_resid = nullptr, *sup_cnt = nullptr;
     int64_t sup_alloc = 0; // number of supergroups the scratch was sized for

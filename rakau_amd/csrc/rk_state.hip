@@ -644,8 +644,8 @@ void census_impl(rk_state &s, int64_t p_begin, int64_t p_end, double mac_value, 
     }
 }
 
-// Launch plan for the critical nodes [g_lo, g_hi): the dispatch order of a repeated call, per class. The work of a node
-// is the integer census of rk_group_work(), computed once per tree and MAC value.
+// Launch plan for the critical nodes [g_lo, g_hi): the dispatch order of a repeated call, per class. The weight ("work")
+// of a node is its number of particles.
 //  * lpt (calls of at most RK_PLAN_MAX_GROUPS nodes): sorted by decreasing work (longest processing time first), so
 //    that a launch of only a few rounds of waves ends with its lightest nodes. (Sorting whole supergroups by their mean
 //    work instead -- spatially compact runs that share the pre-pass lists -- measured 3-7 % slower from 100k particles
@@ -667,11 +667,14 @@ template <typename F>
 void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64_t g_hi, double mac_value, bool lpt)
 {
     ensure_mirrors(s);
-    if (s.work_cache.empty() || s.work_mac_value != mac_value) {
-        s.work_cache.assign(static_cast<size_t>(s.n_crit), 0);
-        uint64_t counts[4];
-        census_impl<F>(s, 0, s.nparts, mac_value, counts, s.work_cache.data());
-        s.work_mac_value = mac_value;
+    // Weight of a node = its number of particles: as good a predictor of a wave's duration as the interaction census
+    // (4M: 2.24-2.26 ms either way; tools/r02_job54.sh) and free, where the census is a traversal of its own (13 ms at 4M).
+    if (s.work_cache.size() != static_cast<size_t>(s.n_crit)) {
+        s.work_cache.resize(static_cast<size_t>(s.n_crit));
+        for (int64_t g = 0; g < s.n_crit; ++g) {
+            s.work_cache[static_cast<size_t>(g)]
+                = static_cast<uint64_t>(s.crit_end[static_cast<size_t>(g)] - s.crit_begin[static_cast<size_t>(g)]);
+        }
     }
     std::vector<uint32_t> lists;
     lists.reserve(static_cast<size_t>(g_hi - g_lo));
@@ -708,7 +711,7 @@ void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64
                 // One spatial region of the range per XCD, the SAME regions for every class kernel: the members of a
                 // supergroup (and neighbouring nodes generally) then run on one XCD whatever their class, and the
                 // pre-pass lists, tree nodes and leaves they share are fetched into one L2 instead of several.
-                // Regions are cut at equal census work. Entry i of the list is served by block i, i.e. by XCD i % 8:
+                // Regions are cut at equal weight. Entry i of the list is served by block i, i.e. by XCD i % 8:
                 // the per-XCD queues (bulk in Morton order, then the light nodes) are interleaved and padded with
                 // padding entries, which the kernels skip.
                 if (region_bound.empty()) {
