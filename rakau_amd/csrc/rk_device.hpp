@@ -77,20 +77,28 @@ template <typename F, int Q, int ND = 3>
 __device__ __forceinline__ void interact(F (&acc)[nres_of(Q)], F dx, F dy, F dz, F d2, F m_src, F m_tgt)
 {
 #if RK_RSQ64_STEPS == 1
-    if constexpr (sizeof(F) == 8 && Q == 0) {
-        // fp64 accelerations: the Newton correction of v_rsq_f64 applied to m / r^3 directly. With y0 = rsq(d2) and
-        // e = 1 - d2 y0^2 (|e| < 2^-25), r^-3 = y0^3 (1 - e)^(-3/2) = y0^3 (1 + 3/2 e + O(e^2)): six operations after the
-        // rsq instead of the seven of "refine y, then cube" (4 % of the 16M fp64 step), same order of error (the
-        // dropped term is 15/8 e^2 <= 8 ulp worst case against 9/8 e^2; parity with the oracle unchanged: 3e-13).
+    if constexpr (sizeof(F) == 8) {
+        // fp64: the Newton correction of v_rsq_f64 applied to the results directly. With y0 = rsq(d2) and
+        // e = 1 - d2 y0^2 (|e| < 2^-25): 1/r = y0 (1 + e/2 + O(e^2)), 1/r^3 = y0^3 (1 + 3/2 e + O(e^2)). Accelerations
+        // take six operations after the rsq instead of the seven of "refine y, then cube" (4-5 % of the 16M fp64 step),
+        // potentials five either way; same order of error (dropped: 15/8 e^2 <= 8 ulp worst case against 9/8 e^2;
+        // parity with the oracle unchanged: 3e-13). The same expressions serve Q = 0, 1 and 2, so that accs_u(), pots_u()
+        // and accs_pots_u() keep agreeing bit for bit.
         const double y0 = __builtin_amdgcn_rsq(d2);
         const double s = y0 * y0;
         const double e = rk_fma(-d2, s, 1.0);
-        const double c = rk_fma(1.5, e, 1.0);
-        const double mr3 = ((m_src * y0) * s) * c;
-        acc[0] = rk_fma(dx, mr3, acc[0]);
-        acc[1] = rk_fma(dy, mr3, acc[1]);
-        if constexpr (ND == 3) {
-            acc[2] = rk_fma(dz, mr3, acc[2]);
+        const double my = m_src * y0;
+        if constexpr (Q == 0 || Q == 2) {
+            const double mr3 = (my * s) * rk_fma(1.5, e, 1.0);
+            acc[0] = rk_fma(dx, mr3, acc[0]);
+            acc[1] = rk_fma(dy, mr3, acc[1]);
+            if constexpr (ND == 3) {
+                acc[2] = rk_fma(dz, mr3, acc[2]);
+            }
+        }
+        if constexpr (Q == 1 || Q == 2) {
+            const double mr = my * rk_fma(0.5, e, 1.0);
+            acc[Q == 1 ? 0 : 3] = rk_fma(-m_tgt, mr, acc[Q == 1 ? 0 : 3]);
         }
         return;
     }
