@@ -160,3 +160,20 @@ def test_list_and_producer_consumer_kernels_give_the_same_bits(dtype):
                         assert np.array_equal(full_a, full_b), (n, ndim, q, eps2, v)
                     for part_a, part_b in zip(res[2][1], res[v][1]):
                         assert np.array_equal(part_a, part_b), (n, ndim, q, eps2, v)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_accs_pots_equal_accs_and_pots(dtype, variant):
+    """accs_u(), pots_u() and accs_pots_u() evaluate the same expressions (as the reference's batch_batch_3d_* do,
+    tree.hpp:2008-2068): the accelerations of Q = 0 and the potentials of Q = 1 are those of Q = 2, bit for bit."""
+    m, x, y, z = oracle.plummer(30000, dtype)
+    st = state_from_oracle(oracle.Tree(x, y, z, m))
+    st.set_variant(variant)
+    mv = mac_value_of(0.7, "bh", dtype)
+    both = st.acc_pot(2, mv, eps2=1e-5, G=0.75)
+    accs = st.acc_pot(0, mv, eps2=1e-5, G=0.75)
+    pots = st.acc_pot(1, mv, eps2=1e-5, G=0.75)
+    for k in range(3):
+        assert np.array_equal(accs[k], both[k])
+    assert np.array_equal(pots[0], both[3])
