@@ -82,8 +82,8 @@ __device__ __forceinline__ void interact(F (&acc)[nres_of(Q)], F dx, F dy, F dz,
         // e = 1 - d2 y0^2 (|e| < 2^-25): 1/r = y0 (1 + e/2 + O(e^2)), 1/r^3 = y0^3 (1 + 3/2 e + O(e^2)). Accelerations
         // take six operations after the rsq instead of the seven of "refine y, then cube" (4-5 % of the 16M fp64 step),
         // potentials five either way; same order of error (dropped: 15/8 e^2 <= 8 ulp worst case against 9/8 e^2;
-        // parity with the oracle unchanged: 3e-13). The same expressions serve Q = 0, 1 and 2, so that accs_u(), pots_u()
-        // and accs_pots_u() keep agreeing bit for bit.
+        // agreement with the CPU checker of the test suite unchanged: 3e-13). The same expressions serve Q = 0, 1 and 2, so
+        // that accs_u(), pots_u() and accs_pots_u() keep agreeing bit for bit.
         const double y0 = __builtin_amdgcn_rsq(d2);
         const double s = y0 * y0;
         const double e = rk_fma(-d2, s, 1.0);
