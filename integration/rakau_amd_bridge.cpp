@@ -28,8 +28,25 @@ inline namespace detail
 namespace
 {
 
-// rakau's default_ncrit without AVX-512 (tree.hpp:584-595 of the reference).
-thread_local std::size_t t_next_ncrit = 128;
+// rakau's default_ncrit (tree.hpp:584-595 of the reference): 256 when the library is built for AVX-512, 128 otherwise.
+// The reference tests xsimd's macros; a translation unit that has not seen xsimd (this one normally has not) gets the
+// same answer from the compiler's own macro, because xsimd derives XSIMD_X86_INSTR_SET >= XSIMD_X86_AVX512_VERSION from
+// __AVX512F__ and this file is compiled with the flags of the rest of the reference's library.
+constexpr std::size_t default_ncrit_of_this_build =
+#if defined(XSIMD_X86_INSTR_SET) && defined(XSIMD_X86_AVX512_VERSION)
+#if XSIMD_X86_INSTR_SET >= XSIMD_X86_AVX512_VERSION
+    256
+#else
+    128
+#endif
+#elif defined(__AVX512F__)
+    256
+#else
+    128
+#endif
+    ;
+// Value announced by rakau_amd_set_ncrit() for the NEXT rocm_state constructed on this thread (0: none announced).
+thread_local std::size_t t_next_ncrit = 0;
 
 // Status code -> the exception type the reference throws for that class of error ("Errors").
 void rk_throw(int rc)
@@ -105,10 +122,14 @@ rocm_state<NDim, F, UInt, MAC>::rocm_state(const std::array<const F *, NDim + 1u
         nodes = widened.data();
     }
     (void)codes;
+    // The announcement is consumed by the constructor it was made for: a later tree on this thread that announces
+    // nothing gets the build's default again, not the previous tree's value.
+    const std::size_t ncrit = t_next_ncrit ? t_next_ncrit : default_ncrit_of_this_build;
+    t_next_ncrit = 0;
     rk_state *s = nullptr;
     rk_throw(rk_state_create_nd(&s, static_cast<int>(NDim), std::is_same_v<F, float> ? RK_F32 : RK_F64,
                                 MAC == mac::bh ? RK_MAC_BH : RK_MAC_BH_GEOM, /* device */ 0, p, nullptr, nparts, nodes,
-                                tree_size, static_cast<std::int64_t>(sizeof(wide_node)), t_next_ncrit));
+                                tree_size, static_cast<std::int64_t>(sizeof(wide_node)), ncrit));
     m_state = s;
 }
 

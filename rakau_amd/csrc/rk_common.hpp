@@ -56,6 +56,19 @@ __host__ __device__ constexpr int class_R(int c)
 #ifndef RK_TIE_HIGH
 #define RK_TIE_HIGH 0
 #endif
+// Relative cost per lane-iteration of the classes R = 1..4 in the class choice (1: the choice minimises idle lanes only).
+#ifndef RK_CLASS_W1
+#define RK_CLASS_W1 1.0
+#endif
+#ifndef RK_CLASS_W2
+#define RK_CLASS_W2 1.0
+#endif
+#ifndef RK_CLASS_W3
+#define RK_CLASS_W3 1.0
+#endif
+#ifndef RK_CLASS_W4
+#define RK_CLASS_W4 1.0
+#endif
 // Targets per lane of the variant-2 (list kernel) classes.
 __host__ __device__ constexpr int class2_R(int c)
 {
@@ -80,7 +93,10 @@ __host__ __device__ inline int class2_of_compute(int64_t size)
     for (int c = RK_MIN_R - 1; c < RK_MAX_R; ++c) { // R = RK_MIN_R .. RK_MAX_R
         const int64_t R = class2_R(c), TP = (size + R - 1) / R;
         if (TP > 64) continue;
-        const double cost = static_cast<double>(R) / static_cast<double>(64 / TP);
+        // Cost of one source for all targets of the node, in lane-iterations (R / NS), times the relative cost of a
+        // lane-iteration with R targets per lane: every source is one broadcast LDS read, which R targets share.
+        constexpr double w[6] = {RK_CLASS_W1, RK_CLASS_W2, RK_CLASS_W3, RK_CLASS_W4, 1.0, 1.0};
+        const double cost = static_cast<double>(R) / static_cast<double>(64 / TP) * w[c];
 #if RK_TIE_HIGH
         if (best < 0 || cost < best_cost + 1e-12) { // ties go to the larger R
 #else
@@ -129,6 +145,17 @@ constexpr uint32_t max_list_nodes = 1u << 29;
 // Capacities of the per-supergroup lists written by the pre-pass kernel.
 constexpr uint32_t SUP_CAPC = 1536, SUP_CAPR = 512;
 
+// Split traversal (variant 4: k_lists writes the interaction list of every critical node to HBM, k_dense evaluates
+// them). A list is a chain of segments of SL_SEG 32-bit entries; an entry names one source: the depth-first index of an
+// accepted node, or SL_PART | the Morton index of a particle of an opened leaf. Segment s < (number of critical nodes
+// of the call) is the first segment of node sl_g0 + s; further segments are taken from a bump counter (sl_ctl[0]) and
+// linked through sl_next[].
+constexpr uint32_t SL_SEG = 1024;         // entries per segment: 8 tiles of 128 sources
+constexpr uint32_t SL_PART = 0x80000000u; // list entry: particle (else node)
+constexpr uint32_t SL_OVER = 0x80000000u; // sl_cnt[g]: the list was not completed (pool exhausted or longer than
+                                          // sl_max_len): the node is served by the fused list kernel instead
+constexpr uint32_t SL_RING = 512;         // entries of the LDS ring in which k_lists stages a list
+
 // Kernel parameter block (passed by value).
 template <typename F>
 struct kparams {
@@ -155,6 +182,23 @@ struct kparams {
     typename vt<F>::v4 *sup_common;
     uint32_t *sup_resid;
     uint2 *sup_cnt;
+    // Split traversal (variant 4), see SL_SEG above.
+    uint32_t *sl_idx;    // list segments
+    uint32_t *sl_next;   // sl_next[s] = segment that continues segment s
+    uint32_t *sl_cnt;    // per critical node: entries of its list | SL_OVER
+    uint32_t *sl_ctl;    // [0] segments taken from the pool, [1] nodes on the fallback list, [2] entries written, [3] nodes
+                         // that found a pool exhausted, [4] partial-sum slots taken (8 words, zeroed before every call)
+    uint32_t *sl_fb;     // fallback list: nodes whose list was not completed
+    uint32_t sl_g0;      // first critical node of the call (segment of node g = g - sl_g0)
+    uint32_t sl_nslot;   // fixed first segments (critical nodes of the call); pool segments follow
+    uint32_t sl_nseg;    // segments in all
+    uint32_t sl_max_len; // longest list k_lists writes (a property of the call's parameters, not of the launch)
+    // Calls over few critical nodes: one wavefront per part of a node (sl_parts_mode); the per-lane sums of every part go
+    // to sl_part (slots of 64 x 16 values, sl_pbase[g] = first slot of node g, taken from the counter sl_ctl[4]).
+    int sl_parts_mode;
+    uint32_t sl_npart;   // slots in sl_part
+    uint32_t *sl_pbase;
+    void *sl_part;
 };
 
 // Index of the output element of Morton particle i.
@@ -263,6 +307,26 @@ struct rk_state {
     int64_t sup_b = 0, sup_e = 0; // supergroups [sup_b, sup_e) are valid for sup_mac (empty: nothing cached)
     hipEvent_t sup_ev = nullptr;  // recorded after the last k_super
     int super_k = -1;      // -1 = not initialised (read RK_SUPER_K, default 8)
+    // Split traversal (variant 4): list pool and control words, sized per call (grown, never shrunk, until the state goes).
+    void *sl_idx = nullptr, *sl_next = nullptr, *sl_cnt = nullptr, *sl_ctl = nullptr, *sl_fb = nullptr;
+    int64_t sl_nseg = 0, sl_ncnt = 0;   // segments / per-node counters allocated
+    void *sl_pbase = nullptr, *sl_part = nullptr;
+    int64_t sl_npart = 0, sl_part_hint = 0; // partial-sum slots allocated / asked for by the last reports
+    int64_t sl_extra_hint = 0;          // pool segments (beyond the fixed first ones) the last reports ask for
+    uint32_t *sl_host = nullptr;        // pinned mirror of sl_ctl, filled by the report copy of a call
+    hipEvent_t sl_rep_ev = nullptr;     // recorded behind that copy
+    hipStream_t sl_stream = nullptr;    // stream of the last split call (a call on another stream waits for it)
+    bool sl_used = false;
+    struct sl_key {                     // (range, MAC value) of a call
+        int64_t p_begin = -1, p_end = -1;
+        double mac_value = 0.;
+        bool operator==(const sl_key &o) const
+        {
+            return p_begin == o.p_begin && p_end == o.p_end && mac_value == o.mac_value;
+        }
+    };
+    sl_key sl_rep_key, sl_clean_key;    // call whose report is in flight / call known to need no fallback launch
+    bool sl_rep_pending = false, sl_clean_valid = false;
     // Filled by the device-side tree build (rk_state_build); null for states created from a host tree.
     void *bld_codes = nullptr;     // uint64 sorted Morton codes [nparts]
     void *bld_perm = nullptr;      // uint32 original index of the particle at Morton position i [nparts]
@@ -281,13 +345,22 @@ void launch_traversal(const rk_state &s, int q, const kparams<F> &p, const int64
 template <typename F>
 void launch_list(const rk_state &s, int q, const kparams<F> &p, const int64_t cls_begin[n_classes],
                  const int64_t cls_end[n_classes], hipStream_t const streams[n_list_R], unsigned class_mask = ~0u);
+// n_dev (optional): the number of list entries lives in device memory (at most n).
 template <typename F>
-void launch_list_big(const rk_state &s, int q, const kparams<F> &p, const uint32_t *list, int64_t n, hipStream_t stream);
+void launch_list_big(const rk_state &s, int q, const kparams<F> &p, const uint32_t *list, int64_t n, hipStream_t stream,
+                     const uint32_t *n_dev = nullptr);
 template <typename F>
 void launch_pc(const rk_state &s, int q, const kparams<F> &p, const int64_t cls_begin[n_classes],
                const int64_t cls_end[n_classes], hipStream_t const streams[n_list_R], unsigned class_mask = ~0u);
 template <typename F>
 void launch_super(const rk_state &s, const kparams<F> &p, int64_t s_begin, int64_t s_end, hipStream_t stream);
+// Split traversal (rk_kernels_split.hip): list building for the critical nodes [g_begin, g_end), dense evaluation per class.
+template <typename F>
+void launch_lists(const rk_state &s, const kparams<F> &p, int64_t g_begin, int64_t g_end, hipStream_t stream);
+template <typename F>
+// what: 0 = one wavefront per node, 1 = one wavefront per part of a node (partial sums to sl_part), 2 = k_combine.
+void launch_dense(const rk_state &s, int q, const kparams<F> &p, const int64_t cls_begin[n_classes],
+                  const int64_t cls_end[n_classes], hipStream_t const streams[n_list_R], unsigned class_mask, int what);
 template <typename F>
 void launch_block(const rk_state &s, int q, const kparams<F> &p, const uint32_t *list, int64_t n, hipStream_t stream);
 template <typename F, int ND>

@@ -25,7 +25,7 @@ namespace rk
 {
 
 template <typename F, int Q, int MAC, int R, int ND, bool BIG = false>
-__global__ void __launch_bounds__(64 * (BIG ? LK_BIG_WPB : RK_WPB), BIG ? (sizeof(F) == 4 ? RK_WBIG : RK_W64) : (sizeof(F) == 4 ? (R <= 2 ? RK_W12 : (R == 3 ? RK_W3 : (R == 4 ? RK_W4 : (R == 5 ? RK_W5 : RK_W6)))) : RK_W64)) k_list(const kparams<F> P, const uint32_t *__restrict__ list, int n_list)
+__global__ void __launch_bounds__(64 * (BIG ? LK_BIG_WPB : RK_WPB), BIG ? (sizeof(F) == 4 ? RK_WBIG : RK_W64) : (sizeof(F) == 4 ? (R <= 2 ? RK_W12 : (R == 3 ? RK_W3 : (R == 4 ? RK_W4 : (R == 5 ? RK_W5 : RK_W6)))) : RK_W64)) k_list(const kparams<F> P, const uint32_t *__restrict__ list, int n_list, const uint32_t *__restrict__ n_list_dev = nullptr)
 {
     using v4 = typename vt<F>::v4;
     using v2 = typename vt<F>::v2;
@@ -43,6 +43,10 @@ __global__ void __launch_bounds__(64 * (BIG ? LK_BIG_WPB : RK_WPB), BIG ? (sizeo
     // and the exact test range over the node, not the chunk), so the interaction set is the reference's.
     const unsigned blk = BIG ? blockIdx.x : xcd_map_block(blockIdx.x, gridDim.x, P.xcd_mode);
     const int wave = __builtin_amdgcn_readfirstlane(BIG ? static_cast<int>(blk) : static_cast<int>(blk * unsigned(RK_WPB)) + wib);
+    if (BIG && n_list_dev) {
+        // The fallback list of the split traversal: its length is only known on the device.
+        n_list = static_cast<int>(__builtin_amdgcn_readfirstlane(*n_list_dev));
+    }
     if (wave >= n_list) {
         return;
     }
@@ -735,11 +739,11 @@ static void launch_list_qm(const rk_state &s, const kparams<F> &p, const int64_t
         const auto grid = static_cast<unsigned>((n + RK_WPB - 1) / RK_WPB);
         if (s.ndim == 3 || !RK_QUAD_BODY) {
             hipLaunchKernelGGL((k_list<F, Q, MAC, R, 3>), dim3(grid), dim3(64 * RK_WPB), 0, streams[c], p,
-                               lists + s.cur_off[c] + cb[c], static_cast<int>(n));
+                               lists + s.cur_off[c] + cb[c], static_cast<int>(n), nullptr);
         } else if constexpr (R <= RK_MAX_R) {
             // Quadtrees: the same kernel without the z terms of the interaction (10 instead of 13 operations).
             hipLaunchKernelGGL((k_list<F, Q, MAC, R, 2>), dim3(grid), dim3(64 * RK_WPB), 0, streams[c], p,
-                               lists + s.cur_off[c] + cb[c], static_cast<int>(n));
+                               lists + s.cur_off[c] + cb[c], static_cast<int>(n), nullptr);
         } else {
             throw error(RK_ERUNTIME, "internal error: quadtree group in a lane-mapping class beyond RK_MAX_R");
         }
@@ -770,7 +774,8 @@ void launch_list(const rk_state &s, int q, const kparams<F> &p, const int64_t cb
 
 // Critical nodes of more than 64 * RK_MAX_R particles: k_list<..., BIG> (one workgroup per node).
 template <typename F>
-void launch_list_big(const rk_state &s, int q, const kparams<F> &p, const uint32_t *list, int64_t n, hipStream_t stream)
+void launch_list_big(const rk_state &s, int q, const kparams<F> &p, const uint32_t *list, int64_t n, hipStream_t stream,
+                     const uint32_t *n_dev)
 {
     if (n <= 0) {
         return;
@@ -780,9 +785,9 @@ void launch_list_big(const rk_state &s, int q, const kparams<F> &p, const uint32
     auto go = [&](auto Qt, auto Mt) {
         constexpr int Q = decltype(Qt)::value, M = decltype(Mt)::value;
         if (s.ndim == 3 || !RK_QUAD_BODY) {
-            hipLaunchKernelGGL((k_list<F, Q, M, 2, 3, true>), grid, block, 0, stream, p, list, cnt);
+            hipLaunchKernelGGL((k_list<F, Q, M, 2, 3, true>), grid, block, 0, stream, p, list, cnt, n_dev);
         } else {
-            hipLaunchKernelGGL((k_list<F, Q, M, 2, 2, true>), grid, block, 0, stream, p, list, cnt);
+            hipLaunchKernelGGL((k_list<F, Q, M, 2, 2, true>), grid, block, 0, stream, p, list, cnt, n_dev);
         }
     };
     using i0 = std::integral_constant<int, 0>;
@@ -799,8 +804,10 @@ void launch_list_big(const rk_state &s, int q, const kparams<F> &p, const uint32
     }
     RK_HIP(hipGetLastError());
 }
-template void launch_list_big<float>(const rk_state &, int, const kparams<float> &, const uint32_t *, int64_t, hipStream_t);
-template void launch_list_big<double>(const rk_state &, int, const kparams<double> &, const uint32_t *, int64_t, hipStream_t);
+template void launch_list_big<float>(const rk_state &, int, const kparams<float> &, const uint32_t *, int64_t, hipStream_t,
+                                     const uint32_t *);
+template void launch_list_big<double>(const rk_state &, int, const kparams<double> &, const uint32_t *, int64_t, hipStream_t,
+                                      const uint32_t *);
 
 template void launch_list<float>(const rk_state &, int, const kparams<float> &, const int64_t[n_classes],
                                  const int64_t[n_classes], hipStream_t const[n_list_R], unsigned);

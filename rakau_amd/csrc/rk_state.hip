@@ -122,6 +122,8 @@ void release_tree(rk_state *s)
         s->graph_exec = nullptr;
     }
     s->have_last_key = false;
+    s->sl_rep_pending = false; // the device was synchronised above
+    s->sl_clean_valid = false;
 }
 
 void free_state(rk_state *s)
@@ -133,8 +135,15 @@ void free_state(rk_state *s)
     (void)hipGetDevice(&prev);
     (void)hipSetDevice(phys(s->device));
     release_tree(s);
-    for (void *b : {s->d_out, s->sup_common, s->sup_resid, s->sup_cnt, s->z_scratch}) {
+    for (void *b : {s->d_out, s->sup_common, s->sup_resid, s->sup_cnt, s->z_scratch, s->sl_idx, s->sl_next, s->sl_cnt,
+                    s->sl_ctl, s->sl_fb, s->sl_pbase, s->sl_part}) {
         rk::pool_free(b);
+    }
+    if (s->sl_host) {
+        (void)hipHostFree(s->sl_host);
+    }
+    if (s->sl_rep_ev) {
+        (void)hipEventDestroy(s->sl_rep_ev);
     }
     if (s->h_stage) {
         (void)hipHostFree(s->h_stage);
@@ -588,8 +597,12 @@ void range_to_classes(rk_state &s, int64_t p_begin, int64_t p_end, int64_t cb[rk
     const bool b_ok = p_begin == s.nparts || (g0 < s.n_crit && s.crit_begin[g0] == p_begin);
     const bool e_ok = p_end == s.nparts || (g1 < s.n_crit && s.crit_begin[g1] == p_end);
     if (!b_ok || !e_ok) {
+        // The usual cause behind a drop-in seam: the caller's tree was built with another ncrit than this state was told
+        // (the reference's default is 256 when it is compiled for AVX-512, 128 otherwise: tree.hpp:589-595).
         throw rk::error(RK_EINVAL, "the particle range [" + std::to_string(p_begin) + ", " + std::to_string(p_end)
-                                       + ") does not start and end at critical node boundaries");
+                                       + ") does not start and end at critical node boundaries of a tree with ncrit = "
+                                       + std::to_string(s.ncrit)
+                                       + " (was the state created with the ncrit the tree was built with?)");
     }
     for (int c = 0; c < rk::n_classes; ++c) {
         const auto &l = variant2 ? s.class2_list[c] : s.class_list[c];
@@ -785,6 +798,146 @@ bool super_cache_enabled()
         return !(e && std::atoi(e) == 0);
     }();
     return on;
+}
+
+// ---- split traversal (variant 4, rk_kernels_split.hip): scratch of a call ----
+bool split_default()
+{
+    static const bool on = [] {
+        const char *e = std::getenv("RK_SPLIT"); // 0: the automatic variant keeps to the fused kernels
+        return !(e && std::atoi(e) == 0);
+    }();
+    return on;
+}
+
+// Longest list k_lists writes; longer ones (tiny opening angles) go to the fused kernel. A property of the call's
+// parameters only, so that a node is served by the same kernel in every launch.
+uint32_t split_max_len()
+{
+    static const uint32_t v = [] {
+        const char *e = std::getenv("RK_SL_MAX_LEN");
+        const long long x = e ? std::atoll(e) : 32768;
+        return static_cast<uint32_t>(std::min<long long>(std::max<long long>(x, rk::SL_SEG), 1ll << 24));
+    }();
+    return v;
+}
+
+// Sizes the list pool for the critical nodes [g_lo, g_hi) of this call, (re)allocates it if it has to grow, digests the
+// report of an earlier call and fills the kernel parameters. Returns whether the fallback launch is needed.
+template <typename F>
+bool prepare_split(rk_state &s, rk::kparams<F> &p, int64_t p_begin, int64_t p_end, int64_t g_lo, int64_t g_hi, double mac_value,
+                   hipStream_t stream)
+{
+    const rk_state::sl_key key{p_begin, p_end, mac_value};
+    if (!s.sl_rep_ev) {
+        RK_HIP(hipEventCreateWithFlags(&s.sl_rep_ev, hipEventDisableTiming));
+        RK_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.sl_host), 8 * sizeof(uint32_t), hipHostMallocDefault));
+        std::fill(s.sl_host, s.sl_host + 8, 0u);
+    }
+    // A call on another stream must not overwrite lists an earlier call may still be reading.
+    if (s.sl_used && s.sl_stream != stream) {
+        RK_HIP(hipStreamSynchronize(s.sl_stream));
+    }
+    s.sl_stream = stream;
+    s.sl_used = true;
+    if (s.sl_rep_pending && hipEventQuery(s.sl_rep_ev) == hipSuccess) {
+        s.sl_rep_pending = false;
+        const uint32_t used = s.sl_host[0], fallback = s.sl_host[1], exhausted = s.sl_host[3];
+        s.sl_clean_key = s.sl_rep_key;
+        s.sl_clean_valid = fallback == 0u;
+        // Keep a quarter of the pool in reserve; double what a call that ran out of segments had.
+        int64_t want = static_cast<int64_t>(used) + static_cast<int64_t>(used) / 4 + 1024;
+        if (exhausted) {
+            want = std::max<int64_t>(want, 2 * static_cast<int64_t>(used) + 4096);
+        }
+        s.sl_extra_hint = std::max(s.sl_extra_hint, want);
+        const int64_t slots = s.sl_host[4];
+        if (slots) {
+            s.sl_part_hint = std::max(s.sl_part_hint, (exhausted ? 2 : 1) * (slots + slots / 4) + 256);
+        }
+    }
+    const int64_t n_slot = g_hi - g_lo;
+    // First guess of the pool: list lengths grow like theta^-3 (about 900 entries at 0.75 on a Plummer sphere).
+    const double theta = s.mac == RK_MAC_BH ? 1. / std::sqrt(mac_value) : 1. / mac_value;
+    const double est_len = std::min(900. * std::pow(0.75 / std::max(theta, 1e-3), 3.), static_cast<double>(split_max_len()));
+    const int64_t extra_per_node = static_cast<int64_t>(std::ceil(1.5 * est_len / rk::SL_SEG));
+    static const int64_t pool_max_seg = [] {
+        const char *e = std::getenv("RK_SL_POOL_MB"); // upper bound of the list pool
+        const long long mb = e ? std::atoll(e) : 24576;
+        return static_cast<int64_t>(std::max<long long>(mb, 16)) * (1ll << 20) / (rk::SL_SEG * 4);
+    }();
+    int64_t extra = std::max<int64_t>(n_slot * extra_per_node + 4096, s.sl_extra_hint);
+    extra = std::min(extra, std::max<int64_t>(pool_max_seg - n_slot, 4096));
+    const int64_t nseg = n_slot + extra;
+    if (nseg >= (int64_t(1) << 31)) {
+        throw rk::error(RK_EINVAL, "too many critical nodes for the split traversal");
+    }
+    // Calls over few critical nodes spread every node over several wavefronts (one per part of four tiles).
+    // (read on every call: tests switch it between calls to compare the two forms bit for bit.)
+    const int64_t parts_below = [] {
+        const char *e = std::getenv("RK_SL_PARTS_BELOW");
+        return e ? std::atoll(e) : int64_t(40000);
+    }();
+    const bool parts_mode = n_slot <= parts_below;
+    int64_t npart = 0;
+    if (parts_mode) {
+        const double est_parts = std::ceil((800. + est_len + 256.) / 512.);
+        npart = std::max<int64_t>(static_cast<int64_t>(1.5 * est_parts * static_cast<double>(n_slot)) + 1024, s.sl_part_hint);
+        npart = std::min<int64_t>(npart, (int64_t(1) << 31) / 1024);
+    }
+    if (s.sl_nseg < nseg || s.sl_ncnt < s.n_crit || !s.sl_ctl || s.sl_npart < npart) {
+        RK_HIP(hipDeviceSynchronize());
+        if (s.graph_exec) {
+            (void)hipGraphExecDestroy(s.graph_exec); // it holds the old addresses
+            s.graph_exec = nullptr;
+        }
+        if (s.sl_nseg < nseg) {
+            for (void **b : {&s.sl_idx, &s.sl_next}) {
+                rk::pool_free(*b);
+                *b = nullptr;
+            }
+            s.sl_nseg = 0;
+            const int64_t alloc = nseg + nseg / 8;
+            s.sl_idx = rk::pool_alloc(static_cast<size_t>(alloc) * rk::SL_SEG * sizeof(uint32_t));
+            s.sl_next = rk::pool_alloc(static_cast<size_t>(alloc) * sizeof(uint32_t));
+            s.sl_nseg = alloc;
+        }
+        if (s.sl_ncnt < s.n_crit) {
+            for (void **b : {&s.sl_cnt, &s.sl_fb, &s.sl_pbase}) {
+                rk::pool_free(*b);
+                *b = nullptr;
+            }
+            s.sl_ncnt = 0;
+            s.sl_cnt = rk::pool_alloc(static_cast<size_t>(s.n_crit) * sizeof(uint32_t));
+            s.sl_fb = rk::pool_alloc(static_cast<size_t>(s.n_crit) * sizeof(uint32_t));
+            s.sl_pbase = rk::pool_alloc(static_cast<size_t>(s.n_crit) * sizeof(uint32_t));
+            s.sl_ncnt = s.n_crit;
+        }
+        if (s.sl_npart < npart) {
+            rk::pool_free(s.sl_part);
+            s.sl_part = nullptr;
+            s.sl_npart = 0;
+            s.sl_part = rk::pool_alloc(static_cast<size_t>(npart) * 1024 * sizeof(F));
+            s.sl_npart = npart;
+        }
+        if (!s.sl_ctl) {
+            s.sl_ctl = rk::pool_alloc(8 * sizeof(uint32_t));
+        }
+    }
+    p.sl_idx = static_cast<uint32_t *>(s.sl_idx);
+    p.sl_next = static_cast<uint32_t *>(s.sl_next);
+    p.sl_cnt = static_cast<uint32_t *>(s.sl_cnt);
+    p.sl_ctl = static_cast<uint32_t *>(s.sl_ctl);
+    p.sl_fb = static_cast<uint32_t *>(s.sl_fb);
+    p.sl_g0 = static_cast<uint32_t>(g_lo);
+    p.sl_nslot = static_cast<uint32_t>(n_slot);
+    p.sl_nseg = static_cast<uint32_t>(s.sl_nseg);
+    p.sl_max_len = split_max_len();
+    p.sl_parts_mode = parts_mode ? 1 : 0;
+    p.sl_npart = static_cast<uint32_t>(parts_mode ? s.sl_npart : 0);
+    p.sl_pbase = static_cast<uint32_t *>(s.sl_pbase);
+    p.sl_part = s.sl_part;
+    return !(s.sl_clean_valid && s.sl_clean_key == key);
 }
 
 template <typename F>
@@ -1000,9 +1153,19 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
             // The pre-pass that produced the lists may have run on another stream.
             RK_HIP(hipStreamWaitEvent(stream, s.sup_ev, 0));
         }
-        auto enqueue = [&](hipStream_t st) {
+        // Variant 4 (and the automatic variant unless RK_SPLIT=0): list building and dense evaluation as two kernels.
+        const bool split = g_hi > g_lo && (s.variant == 4 || (s.variant == 0 && split_default()));
+        bool split_fb = false;
+        if (split) {
+            split_fb = prepare_split<F>(s, p, p_begin, p_end, g_lo, g_hi, mac_value, stream);
+        }
+        auto enqueue = [&](hipStream_t st, bool capturing) {
             if (need_super) {
                 rk::launch_super<F>(s, p, sb, se, st);
+            }
+            if (split) {
+                RK_HIP(hipMemsetAsync(s.sl_ctl, 0, 8 * sizeof(uint32_t), st));
+                rk::launch_lists<F>(s, p, g_lo, g_hi, st);
             }
             hipStream_t streams[rk::n_list_R];
             for (int i = 0; i < rk::n_list_R; ++i) {
@@ -1038,11 +1201,21 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                 const int64_t ng = g_hi - g_lo;
                 pc_mask = ng <= pc_all_below ? 0xfu : (ng <= pc_r2_below ? 0x2u : 0u);
             }
-            if (pc_mask) {
-                rk::launch_pc<F>(s, q, p, cb, ce, streams, pc_mask);
-            }
-            if (pc_mask != 0xfu) {
-                rk::launch_list<F>(s, q, p, cb, ce, streams, ~pc_mask);
+            if (split) {
+                if (p.sl_parts_mode) {
+                    // One wavefront per part, then the per-node sums (same stream per class: ordered).
+                    rk::launch_dense<F>(s, q, p, cb, ce, streams, 0xfu, 1);
+                    rk::launch_dense<F>(s, q, p, cb, ce, streams, 0xfu, 2);
+                } else {
+                    rk::launch_dense<F>(s, q, p, cb, ce, streams, 0xfu, 0);
+                }
+            } else {
+                if (pc_mask) {
+                    rk::launch_pc<F>(s, q, p, cb, ce, streams, pc_mask);
+                }
+                if (pc_mask != 0xfu) {
+                    rk::launch_list<F>(s, q, p, cb, ce, streams, ~pc_mask);
+                }
             }
             if (!serial) {
                 for (int i = 0; i < rk::n_list_R - 1; ++i) {
@@ -1062,6 +1235,19 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
             } else {
                 rk::launch_list_big<F>(s, q, p, big_list, big_e - big_b, st);
             }
+            if (split && split_fb) {
+                // Nodes whose list k_lists did not complete (longer than the cap, or the pool ran out): the chunked form of
+                // the fused kernel, over a list whose length is only known on the device. Skipped once a report of this
+                // very call (range, MAC value) has shown the list to be empty.
+                rk::launch_list_big<F>(s, q, p, static_cast<const uint32_t *>(s.sl_fb), g_hi - g_lo, st,
+                                       static_cast<const uint32_t *>(s.sl_ctl) + 1);
+                if (!capturing && !s.sl_rep_pending) {
+                    RK_HIP(hipMemcpyAsync(s.sl_host, s.sl_ctl, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                    RK_HIP(hipEventRecord(s.sl_rep_ev, st));
+                    s.sl_rep_key = rk_state::sl_key{p_begin, p_end, mac_value};
+                    s.sl_rep_pending = true;
+                }
+            }
         };
         if (use_graph && allow_graph) {
             // A call that repeats the previous one (same range, outputs, parameters) replays a captured graph:
@@ -1070,6 +1256,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
             key.q = q, key.p_begin = p_begin, key.p_end = p_end, key.mac_value = mac_value, key.G = G, key.eps2 = eps2;
             key.offset_output = offset_output, key.super_k = s.super_k, key.variant = s.variant;
             key.with_super = need_super ? 1 : 0;
+            key.pad = split ? (split_fb ? 2 : 1) : 0;
             for (int k = 0; k < rk::nres_of(q); ++k) {
                 key.out[k] = d_out[k];
             }
@@ -1081,7 +1268,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
             if (!replay && !repeats) {
                 // First call of its kind (e.g. once per rebuilt tree in a time-stepping loop): launch directly,
                 // a capture + instantiation would cost more than it saves.
-                enqueue(stream);
+                enqueue(stream, false);
             } else {
             if (!replay) {
                 if (s.graph_exec) {
@@ -1091,7 +1278,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                 hipGraph_t graph = nullptr;
                 RK_HIP(hipStreamBeginCapture(s.cap_stream, hipStreamCaptureModeThreadLocal));
                 try {
-                    enqueue(s.cap_stream);
+                    enqueue(s.cap_stream, true);
                 } catch (...) {
                     (void)hipStreamEndCapture(s.cap_stream, &graph);
                     if (graph) {
@@ -1108,7 +1295,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
             RK_HIP(hipGraphLaunch(s.graph_exec, stream));
             }
         } else {
-            enqueue(stream);
+            enqueue(stream, false);
         }
     } else {
         rk::launch_traversal<F>(s, q, p, cb, ce, stream);
@@ -2061,7 +2248,7 @@ int rk_device_memcpy(void *dst, const void *src, int64_t bytes, int device)
 int rk_set_kernel_variant(rk_state *s, int variant)
 {
     return guard([&] {
-        if (!s || variant < 0 || variant > 3) {
+        if (!s || variant < 0 || variant > 5) {
             throw rk::error(RK_EINVAL, "invalid kernel variant");
         }
         s->variant = variant;

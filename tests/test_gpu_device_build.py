@@ -53,10 +53,14 @@ def test_plummer_tree_and_traversal(dtype, mac):
     # Same thing in the original order through perm.
     perm = st.download("perm").astype(np.int64)
     ref_o = ot.acc_pot(2, 0.75, ordered=True, nthreads=8)
-    for g, r in zip(got, ref_o):
+    # (per-particle vector norms for the accelerations: component-wise ratios blow up near zero components.)
+    back = []
+    for g in got:
         out = np.empty_like(g)
         out[perm] = g
-        assert rel_err(out, r).max() <= tol * 50 or True  # component-wise ratios blow up near zero; norms checked above
+        back.append(out)
+    assert rel_err_vec(back, ref_o).max() <= tol
+    assert rel_err(back[3], ref_o[3]).max() <= tol
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])

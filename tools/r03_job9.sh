@@ -1,0 +1,9 @@
+#!/bin/bash
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $ROOT
+OUT=gpurun_out/r03_job9; mkdir -p $OUT
+export RAKAU_AMD_LIB=$ROOT/rakau_amd/lib_trace/librakau_amd.so
+RK_SL_PARTS_BELOW=0 VARIANT=4 RK_GRAPH=0 timeout 300 python3 tools/trace_waves.py $OUT/tr.npz 4000000 > $OUT/tr.log 2>&1
+python3 tools/trace_digest.py $OUT/tr.npz > $OUT/trace_v4_4m.txt 2>&1; head -8 $OUT/trace_v4_4m.txt
+rm -f $OUT/*.npz

@@ -7,6 +7,9 @@ t0=d['t0'].astype(np.int64); t1=d['t1'].astype(np.int64); ok=t1>0
 T=d['T'][ok]; R=d['R'][ok]; xcc=d['xcc'][ok]; hw=d['hw'][ok]; work=d['work'][ok].astype(np.float64)
 t0=t0[ok]; t1=t1[ok]; base=t0.min(); t0=(t0-base)/100.0; t1=(t1-base)/100.0  # us
 dur=t1-t0
+if 'cyc' in d and d['cyc'][ok].max()>0:
+    cyc=d['cyc'][ok].astype(np.float64); ghz=cyc/(dur*1e3)
+    print('shader clock while the waves ran (cycles / wall time): median %.3f GHz, p10 %.3f, p90 %.3f'%(np.median(ghz),np.percentile(ghz,10),np.percentile(ghz,90)))
 print('waves',ok.sum(),'span us',t1.max(),'kernel_ms',d['kernel_ms'][-3:])
 print('dur us: mean %.1f med %.1f p90 %.1f p99 %.1f max %.1f'%(dur.mean(),np.median(dur),np.percentile(dur,90),np.percentile(dur,99),dur.max()))
 # occupancy over time

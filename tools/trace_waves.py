@@ -17,6 +17,8 @@ from bench import plummer_numpy, shard_cuts
 m, x, y, z = plummer_numpy(n, "float32")
 t = rakau_amd.Octree(x, y, z, m)
 st = t.state()
+if os.environ.get("VARIANT"):
+    st.set_variant(int(os.environ["VARIANT"]))
 mv = rakau_amd.mac_value_of(0.75, "bh", np.float32)
 work = st.group_work(mv)
 cr = st.crit_ranges()
@@ -35,7 +37,11 @@ for _ in range(6):
     ms.append(st.last_kernel_ms())
 raw = np.fromfile(tf, dtype=np.uint64).reshape(-1, 4)
 os.remove(tf)
+new = (raw[:, 3] >> np.uint64(56)) != 0  # k_dense records {R, T, shader cycles}; the fused kernels {R, T}
+Tn = np.where(new, (raw[:, 3] >> np.uint64(32)) & np.uint64(0xffffff), raw[:, 3] & np.uint64(0xffffffff)).astype(np.uint32)
+Rn = np.where(new, raw[:, 3] >> np.uint64(56), raw[:, 3] >> np.uint64(32)).astype(np.uint8)
+cyc = np.where(new, raw[:, 3] & np.uint64(0xffffffff), 0).astype(np.uint64)
 np.savez_compressed(out, t0=raw[:, 0], t1=raw[:, 1], hw=(raw[:, 2] & np.uint64(0xffffffff)).astype(np.uint32),
-                    xcc=(raw[:, 2] >> np.uint64(32)).astype(np.uint8), T=(raw[:, 3] & np.uint64(0xffffffff)).astype(np.uint32),
-                    R=(raw[:, 3] >> np.uint64(32)).astype(np.uint8), work=work, crit=cr, kernel_ms=np.array(ms), range=np.array([pb, pe]))
+                    xcc=(raw[:, 2] >> np.uint64(32)).astype(np.uint8), T=Tn, R=Rn, cyc=cyc, work=work, crit=cr,
+                    kernel_ms=np.array(ms), range=np.array([pb, pe]))
 print("kernel ms", ms, "range", pb, pe)

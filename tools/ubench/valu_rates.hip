@@ -21,6 +21,9 @@ __global__ void __launch_bounds__(256) k(float *out, int iters, float seed)
         for (int i = threadIdx.x; i < 1024; i += blockDim.x) lds[i] = make_float4(i, i + 1, i + 2, 1.f);
         __syncthreads();
     }
+    // Shader clock (s_memtime) against the fixed 100 MHz counter (s_memrealtime): the clock the chip SUSTAINS while this
+    // row runs is d(memtime) / d(memrealtime) * 100 MHz -- cycles per instruction are quoted at that clock, not at 2.4 GHz.
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
     long long t0 = clock64();
     for (int i = 0; i < iters; ++i) {
         if (MODE == 0) { // plain fma, 8 independent chains
@@ -94,9 +97,13 @@ __global__ void __launch_bounds__(256) k(float *out, int iters, float seed)
         }
     }
     long long t1 = clock64();
+    const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
     float r = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y + p4.x + p5.x + p6.x + p7.x;
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
-    if (threadIdx.x == 0) ((long long *)(out + gridDim.x * blockDim.x))[blockIdx.x] = t1 - t0;
+    if (threadIdx.x == 0) {
+        ((long long *)(out + gridDim.x * blockDim.x))[2 * blockIdx.x] = t1 - t0;
+        ((long long *)(out + gridDim.x * blockDim.x))[2 * blockIdx.x + 1] = static_cast<long long>(rt1 - rt0);
+    }
 }
 
 template <int MODE>
@@ -113,23 +120,29 @@ int run(const char *name, int ninstr_per_iter, float *d_out, int nblk_per_cu, in
     CHECK(hipEventRecord(e1));
     CHECK(hipDeviceSynchronize());
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
-    std::vector<long long> cyc(nblk);
-    CHECK(hipMemcpy(cyc.data(), d_out + (size_t)nblk * threads, nblk * sizeof(long long), hipMemcpyDeviceToHost));
-    double avg = 0; for (auto c : cyc) avg += c; avg /= nblk;
+    std::vector<long long> cyc(2 * (size_t)nblk);
+    CHECK(hipMemcpy(cyc.data(), d_out + (size_t)nblk * threads, 2 * nblk * sizeof(long long), hipMemcpyDeviceToHost));
+    double avg = 0, ghz = 0;
+    for (int b = 0; b < nblk; ++b) {
+        avg += cyc[2 * b];
+        ghz += (double)cyc[2 * b] / (double)cyc[2 * b + 1] * 0.1; // shader cycles per 10 ns tick
+    }
+    avg /= nblk;
+    ghz /= nblk;
     double waves_per_simd = (double)nblk_per_cu * threads / 64 / 4;
     double winstr = (double)iters * ninstr_per_iter; // wave-instrs per wave
     // wall-based: total wave-instr per SIMD / time
     double per_simd_instr = winstr * waves_per_simd;
     double ns_per = ms * 1e6 / per_simd_instr;
-    printf("%-28s waves/SIMD=%4.1f  ms=%8.3f  ns/wave-instr/SIMD=%6.3f  (cyc@2.4GHz=%5.2f)  clock64-cyc/instr/wave=%6.2f\n", name, waves_per_simd, ms,
-           ns_per, ns_per * 2.4, avg / winstr);
+    printf("%-28s waves/SIMD=%4.1f  ms=%8.3f  ns/wave-instr/SIMD=%6.3f  sustained clock=%5.3f GHz  cyc/wave-instr/SIMD at that clock=%5.2f  "
+           "clock64-cyc/instr/wave=%6.2f\n", name, waves_per_simd, ms, ns_per, ghz, ns_per * ghz, avg / winstr);
     return 0;
 }
 
 int main()
 {
     float *d_out;
-    CHECK(hipMalloc(&d_out, (size_t)256 * 8 * 256 * 4 + 256 * 8 * 8 + 4096));
+    CHECK(hipMalloc(&d_out, (size_t)256 * 8 * 256 * 4 + 256 * 8 * 16 + 4096));
     hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
     printf("device %s CUs=%d clock=%d kHz\n", prop.name, prop.multiProcessorCount, prop.clockRate);
     for (int w : {1, 2, 4, 8}) { // blocks of 256 threads (1 wave per SIMD each) per CU
