@@ -250,7 +250,23 @@ def main():
             t_dev_build = str(e)
         finally:
             rakau_amd.set_build_exact(args.builder == "device")
-    if world > 1:
+    replicate_via = None
+    if world > 1 and backend == "nccl":
+        # The replicate step lives in the library: rk_comm_* + rk_state_broadcast (ncclBroadcast of the meta block and of
+        # every buffer of the state, RCCL over xGMI). torch.distributed only ships the 128-byte communicator id.
+        from rakau_amd.state import Comm
+        payload = [Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(payload, src=0)
+        comm = Comm(world, payload[0], rank, dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        state = rakau_amd.State.broadcast(state if rank == 0 else None, 0, rank, dev, comm)
+        torch.cuda.synchronize()
+        t_replicate = time.perf_counter() - t0
+        comm.close()
+        replicate_via = "rk_state_broadcast (RCCL)"
+    elif world > 1:
+        # One-GPU rehearsal of the multi-rank path (gloo): the exported buffers travel through host memory.
         payload = [None]
         if rank == 0:
             ptrs, nbytes, meta = state.export()
@@ -264,17 +280,15 @@ def main():
             for t, p, b in zip(bufs, ptrs, nbytes):
                 _capi.check(lib.rk_device_memcpy(t.data_ptr(), p, b, dev))
         for t in bufs:
-            if backend == "nccl":
-                dist.broadcast(t, src=0)  # RCCL over xGMI
-            else:
-                h = t.cpu()
-                dist.broadcast(h, src=0)
-                t.copy_(h)
+            h = t.cpu()
+            dist.broadcast(h, src=0)
+            t.copy_(h)
         torch.cuda.synchronize()
         t_replicate = time.perf_counter() - t0
         if rank != 0:
             state = rakau_amd.State.from_buffers(dev, [t.data_ptr() for t in bufs], nbytes, meta)
         del bufs
+        replicate_via = "rk_state_export / import through host memory (gloo rehearsal)"
     else:
         t_replicate = 0.0
     if args.variant:
@@ -432,13 +446,17 @@ def main():
             "bound": "mfma", "bound_detail": "compute bound on the vector ALU (rsqrt/FMA per pair; no MFMA instructions)",
             "achieved": round(achieved_tflops, 3), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
             "frac": round(achieved_tflops / PEAK_TFLOPS[dtype], 4), "traffic": traffic,
+            # `traffic` is a committed PMC figure of this very command (profiles/traffic.json, separate rocprofv3 --pmc
+            # passes), not something this run measured; null when no figure for this workload has been committed.
+            "traffic_source": "profiles/traffic.json (committed rocprofv3 --pmc measurement of this command; not measured in this run)"
+                              if traffic is not None else None,
             "flop_per_interaction": flop_per_inter, "interactions_per_launch": int(inter_local),
             "kernel_ms": round(kernel_ms, 4),
             "hbm": {"achieved": round(hbm_gbs, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(hbm_gbs / PEAK_HBM_GBS, 5), "algorithmic_bytes_per_launch": int(bytes_launch)},
         },
         "host": {"builder": args.builder, "tree_build_s": round(t_build, 3), "upload_s": round(t_upload, 3),
-                 "replicate_s": round(t_replicate, 4),
+                 "replicate_s": round(t_replicate, 4), "replicate_via": replicate_via,
                  "device_build_s": round(t_dev_build, 4) if isinstance(t_dev_build, float) else t_dev_build,
                  "device_build_exact_s": round(t_dev_build_exact, 4) if isinstance(t_dev_build_exact, float) else None},
         "reference_published": {"best_cpu_2xXeon6148_Mps": 48.8, "V100_Mps": 42.1, "RX570_rocm_path_Mps": 15.6,

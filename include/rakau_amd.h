@@ -21,7 +21,8 @@
  * The remaining entry points have no counterpart in the reference's seam; they serve the callers either side of it
  *  and the measurements:
  *   device-resident outputs      rk_acc_pot_device (+ RK_OUT_ORDERED = the accs_o/pots_o scatter, tree.hpp:3320-3330)
- *   multi-GPU replication        rk_state_clone (one process, peer copies over xGMI),
+ *   multi-GPU replication        rk_state_clone / rk_state_clone_all (one process, peer copies over xGMI),
+ *                                rk_state_broadcast + rk_comm_* (one process per GPU: RCCL broadcast inside the library),
  *                                rk_state_export / rk_state_import / rk_device_memcpy (RCCL broadcast of the exported
  *                                buffers: the replacement of the reference's multi-GPU split, src/rakau_cuda.cu:410-527),
  *                                rk_state_crit_ranges, rk_group_work (where to cut)
@@ -197,6 +198,25 @@ RK_EXPORT int rk_state_import(rk_state **out, int device, int count, void *const
  * GPUs -- instead of being converted and uploaded from host memory again. The C++ header replicates the state of
  * device 0 this way for kwargs::split = {cpu, dev0, dev1, ...}. */
 RK_EXPORT int rk_state_clone(rk_state **out, const rk_state *src, int device);
+/* Replicas of `src` on the n devices devices[0..n) of this process at once, outs[i] on devices[i]. The copies fan out as a
+ * doubling tree (every device that holds the state sends it on, all transfers of a round concurrently: asynchronous peer
+ * copies over xGMI on one stream per destination), ceil(log2(n + 1)) rounds instead of n copies out of the source one after
+ * the other. Replaces the per-call, per-device upload of src/rakau_cuda.cu:492-527. All or nothing. */
+RK_EXPORT int rk_state_clone_all(rk_state **outs, const rk_state *src, const int *devices, int n);
+
+/* One process per GPU: the replicate step over RCCL (xGMI), inside the library. librccl.so.1 is bound at run time (the copy
+ * the process has already mapped, e.g. PyTorch's, otherwise the system's); without it these calls fail with RK_ERUNTIME.
+ *   rk_comm_unique_id : ncclGetUniqueId on one rank; ship the RK_COMM_ID_BYTES bytes to the others by any means.
+ *   rk_comm_init      : ncclCommInitRank for this rank on `device` (collective over all ranks).
+ *   rk_state_broadcast: *state of rank `root` (resident on its `device`) is replicated: on every other rank *state is
+ *                       created on that rank's `device`. Meta block and buffers travel with ncclBroadcast on `stream`
+ *                       (a hipStream_t, may be NULL); blocking. No collective is needed on the data path afterwards.
+ * The caller may pass any ncclComm_t of its own as `comm` instead of one made by rk_comm_init. */
+#define RK_COMM_ID_BYTES 128
+RK_EXPORT int rk_comm_unique_id(char id[RK_COMM_ID_BYTES]);
+RK_EXPORT int rk_comm_init(void **comm, int n_ranks, const char id[RK_COMM_ID_BYTES], int rank, int device);
+RK_EXPORT int rk_comm_destroy(void *comm);
+RK_EXPORT int rk_state_broadcast(rk_state **state, int root, int rank, int device, void *comm, void *stream);
 
 /*
  * Device-side tree construction: what rakau::tree's constructor does on the

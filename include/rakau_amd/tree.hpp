@@ -1461,6 +1461,32 @@ private:
                                                   parts, out, mac_value, G, eps2, flavour, nthreads);
     }
 
+    // Device 0's state, then replicas of it on every further device that has a share and none yet: one rk_state_clone_all
+    // call, whose peer copies fan out as a doubling tree over xGMI (the reference converts and uploads tree and particles
+    // to every device from the host on every call: src/rakau_cuda.cu:410-527).
+    void replicate_to_devices(const std::vector<size_type> &cuts, std::size_t n_dev) const
+    {
+        rk_state *first = device_state_for(0);
+        std::lock_guard<std::mutex> lk(m_dev_mutex);
+        if (m_dev.size() < n_dev) {
+            m_dev.resize(n_dev);
+        }
+        std::vector<int> need;
+        for (std::size_t d = 1; d < n_dev; ++d) {
+            if (cuts[d + 2u] > cuts[d + 1u] && !m_dev[d].h) {
+                need.push_back(static_cast<int>(d));
+            }
+        }
+        if (need.empty()) {
+            return;
+        }
+        std::vector<rk_state *> made(need.size(), nullptr);
+        throw_status(rk_state_clone_all(made.data(), first, need.data(), static_cast<int>(need.size())));
+        for (std::size_t i = 0; i < need.size(); ++i) {
+            m_dev[static_cast<std::size_t>(need[i])].h = made[i];
+        }
+    }
+
     // Run the engines for [0, nparts) and leave the results in res[j][0..nparts) (Morton order): the devices on one
     // host thread each (rocm_state::acc_pot / cuda_acc_pot_impl of the reference), the CPU share on the calling
     // thread meanwhile; every future is joined so that exceptions propagate (tree.hpp:3071-3113).
@@ -1499,7 +1525,9 @@ private:
             return;
         }
         if (n_dev > 1u) {
-            device_state_for(0); // the other devices replicate it (rk_state_clone) instead of uploading from the host
+            // Every replica exists before the first device thread starts: the threads then only look handles up, and no
+            // state is created (or has its host mirrors filled) while another thread traverses with it.
+            replicate_to_devices(cuts, n_dev);
         }
         std::vector<std::future<void>> futs;
         // Device 0 gets a thread of its own only if this thread is busy with the CPU share.

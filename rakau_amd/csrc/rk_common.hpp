@@ -145,14 +145,13 @@ constexpr uint32_t max_list_nodes = 1u << 29;
 // Capacities of the per-supergroup lists written by the pre-pass kernel.
 constexpr uint32_t SUP_CAPC = 1536, SUP_CAPR = 512;
 
-// Split traversal (variant 4: k_lists writes the interaction list of every critical node to HBM, k_dense evaluates
-// them). A list is a chain of segments of SL_SEG 32-bit entries; an entry names one source: the depth-first index of an
-// accepted node, or SL_PART | the Morton index of a particle of an opened leaf. Segment s < (number of critical nodes
-// of the call) is the first segment of node sl_g0 + s; further segments are taken from a bump counter (sl_ctl[0]) and
-// linked through sl_next[].
-constexpr uint32_t SL_SEG = 1024;         // entries per segment: 8 tiles of 128 sources
-constexpr uint32_t SL_PART = 0x80000000u; // list entry: particle (else node)
-constexpr uint32_t SL_OVER = 0x80000000u; // sl_cnt[g]: the list was not completed (pool exhausted or longer than
+// Split traversal (variant 4: k_lists writes the interaction lists of every critical node to HBM, k_dense evaluates
+// them). Two lists per node: the depth-first indices of the accepted nodes, and the Morton indices of the particles of
+// the opened leaves. A list is a chain of segments of SL_SEG 32-bit entries. Segments 2 s and 2 s + 1, s < (number of
+// critical nodes of the call), are the first segments of the two lists of node sl_g0 + s; further segments are taken
+// from a bump counter (sl_ctl[0]) and linked through sl_next[].
+constexpr uint32_t SL_SEG = 512;          // entries per segment: 4 tiles of 128 sources
+constexpr uint32_t SL_OVER = 0x80000000u; // sl_cnt[2 g]: the lists were not completed (pool exhausted or longer than
                                           // sl_max_len): the node is served by the fused list kernel instead
 constexpr uint32_t SL_RING = 512;         // entries of the LDS ring in which k_lists stages a list
 
@@ -185,12 +184,12 @@ struct kparams {
     // Split traversal (variant 4), see SL_SEG above.
     uint32_t *sl_idx;    // list segments
     uint32_t *sl_next;   // sl_next[s] = segment that continues segment s
-    uint32_t *sl_cnt;    // per critical node: entries of its list | SL_OVER
+    uint32_t *sl_cnt;    // per critical node g: [2 g] entries of its node list | SL_OVER, [2 g + 1] of its particle list
     uint32_t *sl_ctl;    // [0] segments taken from the pool, [1] nodes on the fallback list, [2] entries written, [3] nodes
                          // that found a pool exhausted, [4] partial-sum slots taken (8 words, zeroed before every call)
     uint32_t *sl_fb;     // fallback list: nodes whose list was not completed
-    uint32_t sl_g0;      // first critical node of the call (segment of node g = g - sl_g0)
-    uint32_t sl_nslot;   // fixed first segments (critical nodes of the call); pool segments follow
+    uint32_t sl_g0;      // first critical node of the call (first segments of node g: 2 (g - sl_g0) and that + 1)
+    uint32_t sl_nslot;   // fixed first segments (two per critical node of the call); pool segments follow
     uint32_t sl_nseg;    // segments in all
     uint32_t sl_max_len; // longest list k_lists writes (a property of the call's parameters, not of the launch)
     // Calls over few critical nodes: one wavefront per part of a node (sl_parts_mode); the per-lane sums of every part go
@@ -306,6 +305,7 @@ struct rk_state {
     double sup_mac = 0.;
     int64_t sup_b = 0, sup_e = 0; // supergroups [sup_b, sup_e) are valid for sup_mac (empty: nothing cached)
     hipEvent_t sup_ev = nullptr;  // recorded after the last k_super
+    hipStream_t sup_stream = nullptr; // stream of the call that wrote / last used the cached lists
     int super_k = -1;      // -1 = not initialised (read RK_SUPER_K, default 8)
     // Split traversal (variant 4): list pool and control words, sized per call (grown, never shrunk, until the state goes).
     void *sl_idx = nullptr, *sl_next = nullptr, *sl_cnt = nullptr, *sl_ctl = nullptr, *sl_fb = nullptr;
@@ -327,6 +327,8 @@ struct rk_state {
     };
     sl_key sl_rep_key, sl_clean_key;    // call whose report is in flight / call known to need no fallback launch
     bool sl_rep_pending = false, sl_clean_valid = false;
+    sl_key plan_key;                    // (range, MAC value) of the previous call: a launch plan is built when a call repeats
+    bool have_plan_key = false;
     // Filled by the device-side tree build (rk_state_build); null for states created from a host tree.
     void *bld_codes = nullptr;     // uint64 sorted Morton codes [nparts]
     void *bld_perm = nullptr;      // uint32 original index of the particle at Morton position i [nparts]

@@ -24,16 +24,16 @@
 #include "rk_list_common.hpp"
 
 #ifndef RK_SLA_W
-#define RK_SLA_W 6 // k_lists: waves per SIMD it is compiled for
+#define RK_SLA_W 5 // k_lists: waves per SIMD it is compiled for (its 8 KiB of LDS per wave allow no more)
 #endif
 #ifndef RK_SLD_W12
-#define RK_SLD_W12 8 // k_dense, R <= 2
+#define RK_SLD_W12 6 // k_dense, R <= 2 (4 to 8 waves per SIMD measure the same; fewer leave registers for the pipeline)
 #endif
 #ifndef RK_SLD_W3
-#define RK_SLD_W3 6
+#define RK_SLD_W3 5
 #endif
 #ifndef RK_SLD_W4
-#define RK_SLD_W4 5
+#define RK_SLD_W4 4
 #endif
 #ifndef RK_SLD_W64
 #define RK_SLD_W64 4 // fp64
@@ -61,18 +61,26 @@ namespace rk
 
 constexpr int SL_TILE = 128;
 
-// Per-wave LDS of k_lists: 2 + 2 + 1 + 0.5 + 1 KiB (fp32).
+// Per-wave LDS of k_lists: frontier 2 + two staging rings 2 + 2 + leaf queue 1 + exact-test candidates 1 KiB (fp32).
+constexpr int SL_FQ_CAP = 512;
 template <typename F>
 struct sl_lds {
-    uint32_t stack[LK_STACK_CAP];
-    uint32_t ring[SL_RING];
-    uint2 lq[LK_LQ_CAP];
-    uint32_t uq[LK_UQ_CAP];
-    typename vt<F>::v4 cand[64]; // candidates of the lane = target exact test
+    uint32_t fq[SL_FQ_CAP];   // frontier: runs of sibling nodes, (first record << 3) | (count - 1), first in first out
+    uint32_t ring[2][SL_RING]; // staging of the node list [0] and the particle list [1]
+    uint2 lq[LK_LQ_CAP];      // opened leaves, in the order they were opened
+    typename vt<F>::v4 cand[64]; // {centre of mass, MAC threshold} of the candidates of the exact test
 };
 
 // ------------------------------------------------------------------------------------------------
-// k_lists: interaction list of one critical node per wavefront.
+// k_lists: interaction lists of one critical node per wavefront.
+//
+// A breadth-first walk: the candidates the supergroup pre-pass left to its members first, then the frontier queue
+// (children of opened nodes) first in, first out. Every batch of up to 64 candidates is decided completely before the
+// next one (box accept, probe open, and for what is left the exact all-targets test with lane = target), so the order in
+// which nodes are accepted and leaves are opened is the breadth-first order of the candidates -- whatever the batch
+// boundaries, which lets the records of the next batch be requested before the current one is classified. Two lists per
+// node: accepted nodes (depth-first indices) and the particles of opened leaves, each in that order.
+// The decisions are those of the reference (include/rakau/tree.hpp:2662-2672, 2828-2838 of the reference).
 // ------------------------------------------------------------------------------------------------
 template <typename F, int MAC>
 __global__ void __launch_bounds__(64, RK_SLA_W) k_lists(const kparams<F> P, uint32_t g_begin, uint32_t g_end)
@@ -105,12 +113,14 @@ __global__ void __launch_bounds__(64, RK_SLA_W) k_lists(const kparams<F> P, uint
     const v4 pr0 = P.part4[gb], pr1 = P.part4[ge - 1u];
 
     RK_STAMP_DECL
-    int size = 0, n_lq = 0, n_uq = 0;
-    uint32_t head = 0, tail = 0; // entries written to HBM / appended to the ring
-    uint32_t cur_seg = g - P.sl_g0;
+    uint32_t fq_head = 0, fq_tail = 0; // frontier entries popped / pushed
+    int n_lq = 0;
+    // The two lists: entries written to HBM / appended to the ring, current segment.
+    uint32_t head[2] = {0u, 0u}, tail[2] = {0u, 0u};
+    uint32_t cur_seg[2] = {2u * (g - P.sl_g0), 2u * (g - P.sl_g0) + 1u};
     bool over = false;
 
-    uint32_t sup_S = 0, sup_nresid = 0, sup_rpos = 0;
+    uint32_t sup_S = 0, sup_nresid = 0;
     bool from_root = true;
     if (P.super_k != 0u) {
         sup_S = g / P.super_k;
@@ -125,20 +135,20 @@ __global__ void __launch_bounds__(64, RK_SLA_W) k_lists(const kparams<F> P, uint
         const uint32_t r_nch = root->nch, r_a = root->a, r_b = root->b;
         if (cnode != 0u && r_nch != 0u) {
             if (lane == 0) {
-                L.stack[0] = (r_a << 3) | (r_b - 1u);
+                L.fq[0] = (r_a << 3) | (r_b - 1u);
             }
-            size = 1;
+            fq_tail = 1;
         }
     }
     wave_sync();
 
-    // Write the whole 128-entry blocks of the ring (everything when `final`) to the node's list.
-    auto flush_blocks = [&](bool final) __attribute__((always_inline)) {
-        while (!over && (tail - head >= static_cast<uint32_t>(SL_TILE) || (final && tail > head))) {
-            const uint32_t n = tail - head < static_cast<uint32_t>(SL_TILE) ? tail - head : static_cast<uint32_t>(SL_TILE);
-            if ((head & (SL_SEG - 1u)) == 0u && head != 0u) {
+    // Write the whole 128-entry blocks of ring w (everything when `final`) to list w of the node.
+    auto flush_blocks = [&](int w, bool final) __attribute__((always_inline)) {
+        while (!over && (tail[w] - head[w] >= static_cast<uint32_t>(SL_TILE) || (final && tail[w] > head[w]))) {
+            const uint32_t n = tail[w] - head[w] < static_cast<uint32_t>(SL_TILE) ? tail[w] - head[w] : static_cast<uint32_t>(SL_TILE);
+            if ((head[w] & (SL_SEG - 1u)) == 0u && head[w] != 0u) {
                 // The current segment is full: take the next one from the pool and link it.
-                if (head >= P.sl_max_len) {
+                if (head[w] >= P.sl_max_len) {
                     over = true; // a property of the node and the MAC value: the same in every launch
                     break;
                 }
@@ -155,30 +165,30 @@ __global__ void __launch_bounds__(64, RK_SLA_W) k_lists(const kparams<F> P, uint
                     break;
                 }
                 if (lane == 0) {
-                    P.sl_next[cur_seg] = ns;
+                    P.sl_next[cur_seg[w]] = ns;
                 }
-                cur_seg = ns;
+                cur_seg[w] = ns;
             }
-            uint32_t *dst = P.sl_idx + static_cast<size_t>(cur_seg) * SL_SEG + (head & (SL_SEG - 1u));
+            uint32_t *dst = P.sl_idx + static_cast<size_t>(cur_seg[w]) * SL_SEG + (head[w] & (SL_SEG - 1u));
 #pragma unroll
             for (uint32_t i = 0; i < 2u; ++i) {
                 const uint32_t j = static_cast<uint32_t>(lane) + 64u * i;
                 if (j < n) {
-                    dst[j] = L.ring[(head + j) & (SL_RING - 1u)];
+                    dst[j] = L.ring[w][(head[w] + j) & (SL_RING - 1u)];
                 }
             }
-            head += n;
+            head[w] += n;
         }
     };
 
-    // Expand the queued leaves into particle indices.
+    // Expand the queued leaves into particle indices (list 1), oldest first.
     auto drain_leaves = [&]() __attribute__((always_inline)) {
         while (n_lq > 0 && !over) {
-            flush_blocks(false); // fewer than 128 entries stay in the ring
+            flush_blocks(1, false); // fewer than 128 entries stay in the ring
             if (over) {
                 break;
             }
-            const uint32_t room = SL_RING - (tail - head);
+            const uint32_t room = SL_RING - (tail[1] - head[1]);
             uint2 lf = make_uint2(0u, 0u);
             if (lane < n_lq) {
                 lf = L.lq[lane];
@@ -191,23 +201,23 @@ __global__ void __launch_bounds__(64, RK_SLA_W) k_lists(const kparams<F> P, uint
                 // The first leaf is larger than the free part of the ring: take `room` of its particles.
                 const uint32_t b0 = __builtin_amdgcn_readfirstlane(lf.x);
                 for (uint32_t j = static_cast<uint32_t>(lane); j < room; j += 64u) {
-                    L.ring[(tail + j) & (SL_RING - 1u)] = (b0 + j) | SL_PART;
+                    L.ring[1][(tail[1] + j) & (SL_RING - 1u)] = b0 + j;
                 }
                 if (lane == 0) {
                     L.lq[0] = make_uint2(b0 + room, lf.y);
                 }
-                tail += room;
+                tail[1] += room;
                 wave_sync();
                 continue;
             }
             const unsigned mycnt = fits ? cnt : 0u;
-            const uint32_t dst = tail + (incl - cnt);
+            const uint32_t dst = tail[1] + (incl - cnt);
             for (unsigned j = 0; __builtin_amdgcn_ballot_w64(j < mycnt) != 0ull; ++j) {
                 if (j < mycnt) {
-                    L.ring[(dst + j) & (SL_RING - 1u)] = (lf.x + j) | SL_PART;
+                    L.ring[1][(dst + j) & (SL_RING - 1u)] = lf.x + j;
                 }
             }
-            tail += static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), m - 1));
+            tail[1] += static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), m - 1));
             const int rest = n_lq - m;
             wave_sync();
             for (int j0 = 0; j0 < rest; j0 += 64) {
@@ -241,55 +251,60 @@ __global__ void __launch_bounds__(64, RK_SLA_W) k_lists(const kparams<F> P, uint
         bt.ra = rec->a;
         bt.rb = rec->b;
     };
-    // Pop up to 8 sibling runs (64 candidates) and fetch their records; stack bounds as in the fused kernel.
-    auto pop_and_load = [&](batch_t &bt) __attribute__((always_inline)) -> int {
+    // Next batch of the frontier (requests the records; false: nothing to take). `pending` = runs that batches already
+    // taken may still push. Normally the OLDEST 8 runs; when the queue is about to overflow (tiny opening angles), the
+    // newest ones, fewer at a time: depth first, whose growth LK_DFS_RESERVE bounds.
+    auto pop_and_load = [&](batch_t &bt, int pending) __attribute__((always_inline)) -> bool {
+        const int size = static_cast<int>(fq_tail - fq_head);
         if (size == 0) {
-            return 0;
+            return false;
         }
         int k = size < 8 ? size : 8;
-        const int room = (LK_STACK_CAP - LK_DFS_RESERVE - n_uq - size) / 7;
-        if (room < k) {
-            k = room >= 1 ? room : 1;
-        }
+        const int room = (SL_FQ_CAP - LK_DFS_RESERVE - pending - size) / 7;
         const int e_idx = lane >> 3, e_sub = lane & 7;
         uint32_t entry = 0u;
-        if (e_idx < k) {
-            entry = L.stack[size - 1 - e_idx];
+        if (room >= k) {
+            if (e_idx < k) {
+                entry = L.fq[(fq_head + static_cast<uint32_t>(e_idx)) & (SL_FQ_CAP - 1)];
+            }
+            fq_head += static_cast<uint32_t>(k);
+        } else {
+            if (pending != 0) {
+                return false; // settle what is in flight first
+            }
+            k = room >= 1 ? room : 1;
+            if (e_idx < k) {
+                entry = L.fq[(fq_tail - 1u - static_cast<uint32_t>(e_idx)) & (SL_FQ_CAP - 1)];
+            }
+            fq_tail -= static_cast<uint32_t>(k);
         }
-        size -= k;
         bt.active = e_idx < k && static_cast<uint32_t>(e_sub) <= (entry & 7u);
         bt.rec = bt.active ? (entry >> 3) + static_cast<uint32_t>(e_sub) : 0u;
         load_rec(bt);
-        return k;
+        return true;
     };
-    auto route = [&](bool accept, bool open, bool undecided, const batch_t &bt) __attribute__((always_inline)) {
-        const bool leaf = open && bt.nch == 0u;
-        const bool expand = open && bt.nch != 0u;
-        const unsigned long long m_acc = __builtin_amdgcn_ballot_w64(accept);
-        if (accept) {
-            L.ring[(tail + wave_prefix_count(m_acc)) & (SL_RING - 1u)] = bt.node;
+    uint32_t sup_rpos = 0;
+    auto resid_load = [&](batch_t &bt, int pending) __attribute__((always_inline)) -> bool {
+        if (sup_rpos >= sup_nresid) {
+            return false;
         }
-        tail += static_cast<uint32_t>(__builtin_popcountll(m_acc));
-        const unsigned long long m_leaf = __builtin_amdgcn_ballot_w64(leaf);
-        if (leaf) {
-            L.lq[n_lq + static_cast<int>(wave_prefix_count(m_leaf))] = make_uint2(bt.ra, bt.rb);
+        // Every candidate may push a run: leave the frontier room for that (otherwise take from the frontier first).
+        if (SL_FQ_CAP - LK_DFS_RESERVE - pending - static_cast<int>(fq_tail - fq_head) < 64) {
+            return false;
         }
-        n_lq += __builtin_popcountll(m_leaf);
-        const unsigned long long m_exp = __builtin_amdgcn_ballot_w64(expand);
-        if (expand) {
-            L.stack[size + static_cast<int>(wave_prefix_count(m_exp))] = (bt.ra << 3) | (bt.rb - 1u);
-        }
-        size += __builtin_popcountll(m_exp);
-        const unsigned long long m_und = __builtin_amdgcn_ballot_w64(undecided);
-        if (undecided) {
-            L.uq[n_uq + static_cast<int>(wave_prefix_count(m_und))] = bt.rec;
-        }
-        n_uq += __builtin_popcountll(m_und);
-        wave_sync();
+        const uint32_t left = sup_nresid - sup_rpos, k = left < 64u ? left : 64u;
+        bt.active = static_cast<uint32_t>(lane) < k;
+        bt.rec = bt.active ? P.sup_resid[static_cast<size_t>(sup_S) * SUP_CAPR + sup_rpos + static_cast<uint32_t>(lane)] : 0u;
+        sup_rpos += k;
+        load_rec(bt);
+        return true;
     };
-    // First-stage MAC test (bounding box accept, probe open), see rk_kernels_list.hip: the decisions are the reference's.
+
+    // Decide a batch completely and route it: accepted nodes to list 0, opened leaves to the leaf queue, the children of
+    // opened internal nodes to the back of the frontier.
     auto process = [&](const batch_t &bt) __attribute__((always_inline)) {
         const v4 com = bt.com;
+        // Ancestor-or-self of the target node, on the depth-first index interval of the subtree.
         const bool anc = bt.active && bt.node <= cnode && cnode <= bt.node + bt.nch;
         const bool self = anc && bt.node == cnode;
         const bool test = bt.active && !anc;
@@ -299,6 +314,8 @@ __global__ void __launch_bounds__(64, RK_SLA_W) k_lists(const kparams<F> P, uint
         st_acc[6] += 1;
 #endif
         RK_STAMP(0)
+        // Accept if the squared distance from the centre of mass to the node's bounding box exceeds the threshold by a
+        // margin (then every target passes); open if one of two probe targets fails; the rest: exact test.
         const F bx = rk_max3(blo.x - com.x, com.x - bhi.x, F(0)), by = rk_max3(blo.y - com.y, com.y - bhi.y, F(0)),
                 bz = rk_max3(blo.z - com.z, com.z - bhi.z, F(0));
         const F dbox2 = rk_fma(bz, bz, rk_fma(by, by, bx * bx));
@@ -307,122 +324,139 @@ __global__ void __launch_bounds__(64, RK_SLA_W) k_lists(const kparams<F> P, uint
         const F p1x = com.x - pr1.x, p1y = com.y - pr1.y, p1z = com.z - pr1.z;
         const F d2p0 = rk_fma(p0z, p0z, rk_fma(p0y, p0y, p0x * p0x)), d2p1 = rk_fma(p1z, p1z, rk_fma(p1y, p1y, p1x * p1x));
         const bool probe_open = mac_lh >= rk_min(d2p0, d2p1);
-        const bool accept = test && box_accept;
-        const bool open = (test && !box_accept && probe_open) || (anc && !self);
         const bool undecided = test && !box_accept && !probe_open;
         RK_STAMP(1)
-        route(accept, open, undecided, bt);
-        RK_STAMP(2)
-    };
-    // Exact MAC test (all targets) of up to 64 queued candidates.
-    auto process_exact = [&]() __attribute__((always_inline)) {
-        const int k = n_uq < 64 ? n_uq : 64;
-        batch_t bt;
-        bt.active = lane < k;
-        bt.rec = bt.active ? L.uq[n_uq - 1 - lane] : 0u;
-        n_uq -= k;
-        load_rec(bt);
-        const v4 com = bt.com;
-        const F mac_lh = mac_lhs<F>(MAC, bt.mp, mac_value);
-        bool fail;
-        if (k * (7 * RT + 3) < TG * 7) {
-            // Few candidates: lane = target.
-            v4 cd;
-            cd.x = com.x, cd.y = com.y, cd.z = com.z, cd.w = mac_lh;
-            if (bt.active) {
-                L.cand[lane] = cd;
-            }
-            wave_sync();
-            unsigned long long fail_mask = 0ull;
-            for (int ci = 0; ci < k; ++ci) {
-                const v4 cand = L.cand[ci];
-                bool f = false;
+        bool fail = false; // exact test outcome of the undecided candidates
+        const unsigned long long m_und = __builtin_amdgcn_ballot_w64(undecided);
+        if (m_und != 0ull) {
+            const int k = __builtin_popcountll(m_und);
+            if (k * (7 * RT + 3) < TG * 7) {
+                // lane = target: the candidates go through LDS, two per step.
+                if (undecided) {
+                    v4 cd;
+                    cd.x = com.x, cd.y = com.y, cd.z = com.z, cd.w = mac_lh;
+                    L.cand[wave_prefix_count(m_und)] = cd;
+                }
+                wave_sync();
+                unsigned long long fail_mask = 0ull;
+                for (int ci = 0; ci < k; ci += 2) {
+                    const v4 c0 = L.cand[ci], c1 = L.cand[ci + 1 < k ? ci + 1 : ci];
+                    bool f0 = false, f1 = false;
 #pragma unroll
-                for (int r = 0; r < RK_MAX_R; ++r) {
-                    if (r < RT) {
-                        const F dx = cand.x - tp[r].x, dy = cand.y - tp[r].y, dz = cand.z - tp[r].z;
-                        const F d2 = rk_fma(dz, dz, rk_fma(dy, dy, dx * dx));
-                        f |= cand.w >= d2;
+                    for (int r = 0; r < RK_MAX_R; ++r) {
+                        if (r < RT) {
+                            const F ax = c0.x - tp[r].x, ay = c0.y - tp[r].y, az = c0.z - tp[r].z;
+                            f0 |= c0.w >= rk_fma(az, az, rk_fma(ay, ay, ax * ax));
+                            const F bx2 = c1.x - tp[r].x, by2 = c1.y - tp[r].y, bz2 = c1.z - tp[r].z;
+                            f1 |= c1.w >= rk_fma(bz2, bz2, rk_fma(by2, by2, bx2 * bx2));
+                        }
+                    }
+                    if (__builtin_amdgcn_ballot_w64(f0) != 0ull) {
+                        fail_mask |= 1ull << ci;
+                    }
+                    if (__builtin_amdgcn_ballot_w64(f1) != 0ull) {
+                        fail_mask |= 1ull << (ci + 1 < k ? ci + 1 : ci);
                     }
                 }
-                if (__builtin_amdgcn_ballot_w64(f) != 0ull) {
-                    fail_mask |= 1ull << ci;
-                }
-            }
-            fail = ((fail_mask >> lane) & 1ull) != 0ull;
-            wave_sync();
-        } else {
-            // lane = candidate; the targets arrive through scalar loads as SGPR operands.
-            F mind2 = std::numeric_limits<F>::infinity();
-            for (int t = 0; t < TG; t += 4) {
+                fail = undecided && ((fail_mask >> wave_prefix_count(m_und)) & 1ull) != 0ull;
+                wave_sync();
+            } else {
+                // lane = candidate; the targets arrive through scalar loads as SGPR operands.
+                F mind2 = std::numeric_limits<F>::infinity();
+                for (int t = 0; t < TG; t += 4) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int ti = (t + u < TG) ? t + u : TG - 1;
-                    const v4 tg = P.part4[gb + static_cast<uint32_t>(ti)];
-                    const F dx = com.x - tg.x, dy = com.y - tg.y, dz = com.z - tg.z;
-                    const F d2 = rk_fma(dz, dz, rk_fma(dy, dy, dx * dx));
-                    mind2 = rk_min(mind2, d2);
+                    for (int u = 0; u < 4; ++u) {
+                        const int ti = (t + u < TG) ? t + u : TG - 1;
+                        const v4 tg = P.part4[gb + static_cast<uint32_t>(ti)];
+                        const F dx = com.x - tg.x, dy = com.y - tg.y, dz = com.z - tg.z;
+                        mind2 = rk_min(mind2, rk_fma(dz, dz, rk_fma(dy, dy, dx * dx)));
+                    }
                 }
+                fail = undecided && mac_lh >= mind2;
             }
-            fail = mac_lh >= mind2;
         }
-        route(bt.active && !fail, bt.active && fail, false, bt);
         RK_STAMP(3)
-    };
-    auto resid_load = [&](batch_t &bt) __attribute__((always_inline)) -> int {
-        if (sup_rpos >= sup_nresid) {
-            return 0;
+        const bool accept = test && (box_accept || (undecided && !fail));
+        const bool open = (test && !box_accept && (probe_open || fail)) || (anc && !self);
+        const bool leaf = open && bt.nch == 0u;
+        const bool expand = open && bt.nch != 0u;
+        const unsigned long long m_acc = __builtin_amdgcn_ballot_w64(accept);
+        if (accept) {
+            L.ring[0][(tail[0] + wave_prefix_count(m_acc)) & (SL_RING - 1u)] = bt.node;
         }
-        const uint32_t left = sup_nresid - sup_rpos, k = left < 64u ? left : 64u;
-        bt.active = static_cast<uint32_t>(lane) < k;
-        bt.rec = bt.active ? P.sup_resid[static_cast<size_t>(sup_S) * SUP_CAPR + sup_rpos + static_cast<uint32_t>(lane)] : 0u;
-        sup_rpos += k;
-        load_rec(bt);
-        return 1;
+        tail[0] += static_cast<uint32_t>(__builtin_popcountll(m_acc));
+        const unsigned long long m_leaf = __builtin_amdgcn_ballot_w64(leaf);
+        if (leaf) {
+            L.lq[n_lq + static_cast<int>(wave_prefix_count(m_leaf))] = make_uint2(bt.ra, bt.rb);
+        }
+        n_lq += __builtin_popcountll(m_leaf);
+        const unsigned long long m_exp = __builtin_amdgcn_ballot_w64(expand);
+        if (expand) {
+            L.fq[(fq_tail + wave_prefix_count(m_exp)) & (SL_FQ_CAP - 1)] = (bt.ra << 3) | (bt.rb - 1u);
+        }
+        fq_tail += static_cast<uint32_t>(__builtin_popcountll(m_exp));
+        wave_sync();
+        RK_STAMP(2)
     };
-
-    bool done = false;
-    for (;;) {
+    // Room for the worst-case output of one batch (64 nodes, 64 leaves).
+    auto settle = [&]() __attribute__((always_inline)) {
         RK_STAMP(7)
-        if (n_lq + 64 > LK_LQ_CAP || done) {
+        if (n_lq + 64 > LK_LQ_CAP) {
             drain_leaves();
         }
         RK_STAMP(4)
-        flush_blocks(done);
+        flush_blocks(0, false);
         RK_STAMP(5)
-        if (done || over) {
-            break;
-        }
-        if (n_uq >= 64) {
-            process_exact();
-            continue;
-        }
-        if (n_uq > 0 && LK_STACK_CAP - LK_DFS_RESERVE - n_uq - size < 7) {
-            process_exact();
-            continue;
-        }
-        batch_t A;
-        int k = pop_and_load(A);
-        if (k == 0) {
-            k = resid_load(A);
-        }
-        if (k == 0) {
-            if (n_uq > 0) {
-                process_exact();
-            } else {
-                done = true;
-            }
-            continue;
+    };
+
+    // Two batches in flight: the records of the next one are requested before the current one is classified.
+    batch_t A, B;
+    bool haveA = resid_load(A, 0);
+    if (!haveA) {
+        haveA = pop_and_load(A, 0);
+    }
+    while (haveA && !over) {
+        bool haveB = resid_load(B, 64);
+        if (!haveB) {
+            haveB = pop_and_load(B, 64);
         }
         process(A);
+        settle();
+        if (over) {
+            break;
+        }
+        if (!haveB) {
+            haveB = resid_load(B, 0) || pop_and_load(B, 0); // A may have pushed what B can take now
+        }
+        if (!haveB) {
+            break;
+        }
+        bool haveA2 = resid_load(A, 64);
+        if (!haveA2) {
+            haveA2 = pop_and_load(A, 64);
+        }
+        process(B);
+        settle();
+        if (!haveA2) {
+            haveA2 = resid_load(A, 0) || pop_and_load(A, 0);
+        }
+        haveA = haveA2;
     }
+    RK_STAMP(7)
+    drain_leaves();
+    RK_STAMP(4)
+    flush_blocks(0, true);
+    flush_blocks(1, true);
+    RK_STAMP(5)
+
     if (!over && P.sl_parts_mode) {
         // The call evaluates one part per wavefront: reserve the node's partial-sum slots.
         uint32_t n1 = 0u;
         if (!from_root) {
             n1 = P.sup_cnt[sup_S].x;
         }
-        const uint32_t ntt = (n1 + SL_TILE - 1) / SL_TILE + (tail + SL_TILE - 1) / SL_TILE + (static_cast<uint32_t>(TG) + SL_TILE - 1) / SL_TILE;
+        const uint32_t ntt = (n1 + SL_TILE - 1) / SL_TILE + (tail[0] + SL_TILE - 1) / SL_TILE + (tail[1] + SL_TILE - 1) / SL_TILE
+                             + (static_cast<uint32_t>(TG) + SL_TILE - 1) / SL_TILE;
         const uint32_t n_parts = (ntt + 3u) / 4u;
         uint32_t pb = 0u;
         if (lane == 0) {
@@ -440,12 +474,13 @@ __global__ void __launch_bounds__(64, RK_SLA_W) k_lists(const kparams<F> P, uint
     }
     if (lane == 0) {
         if (over) {
-            P.sl_cnt[g] = SL_OVER;
+            P.sl_cnt[2u * g] = SL_OVER;
             const uint32_t slot = __hip_atomic_fetch_add(&P.sl_ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             P.sl_fb[slot] = g;
         } else {
-            P.sl_cnt[g] = tail;
-            __hip_atomic_fetch_add(&P.sl_ctl[2], tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            P.sl_cnt[2u * g] = tail[0];
+            P.sl_cnt[2u * g + 1u] = tail[1];
+            __hip_atomic_fetch_add(&P.sl_ctl[2], tail[0] + tail[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     RK_STAMP(7)
@@ -455,18 +490,18 @@ __global__ void __launch_bounds__(64, RK_SLA_W) k_lists(const kparams<F> P, uint
 // ------------------------------------------------------------------------------------------------
 // k_dense: the interactions of one critical node, sources streamed from the lists.
 //
-// The sources of a node form a sequence of TILES of (at most) 128: the supergroup's common sources, the node's own list,
-// the node's own particles (self pair masked). Four consecutive tiles are a PART. Every lane (target slot x source
-// split, the fused kernel's mapping) accumulates a part from zero, and adds the parts up in order; the splits are
-// summed in order at the very end. That order is a function of the node and the MAC value only, and it can be walked by
-// one wavefront (PARTS = false: all parts one after the other, the sums in registers) or by one wavefront per part
-// (PARTS = true: calls over few critical nodes, whose heaviest nodes would otherwise keep single wavefronts busy long
-// after the rest of the device has drained; the per-lane sums of each part go to a scratch array and k_combine adds them
-// up in the same order). Same bits either way.
+// The sources of a node form a sequence of TILES of (at most) 128: the supergroup's common sources, the node's own
+// lists (nodes, then particles), the node's own particles (self pair masked). Four consecutive tiles are a PART. Every
+// lane (target slot x source split, the fused kernel's mapping) accumulates a part from zero, and adds the parts up in
+// order; the splits are summed in order at the very end. That order is a function of the node and the MAC value only,
+// and it can be walked by one wavefront (PARTS = false: all parts one after the other, the sums in registers) or by one
+// wavefront per part (PARTS = true: calls over few critical nodes, whose heaviest nodes would otherwise keep single
+// wavefronts busy long after the rest of the device has drained; the per-lane sums of each part go to a scratch array
+// and k_combine adds them up in the same order). Same bits either way.
 // ------------------------------------------------------------------------------------------------
 constexpr int SL_PART_TILES = 4;
-constexpr int SL_PARTS_PER_NODE = 4;  // PARTS launches: wavefronts per node (part k, k + 4, ... each)
-constexpr int SL_SLOT = 64 * 4 * 4;   // values per partial-sum slot: 64 lanes x at most 4 targets x 4 results
+constexpr int SL_PARTS_PER_NODE = 4; // PARTS launches: wavefronts per node (part k, k + 4, ... each)
+constexpr int SL_SLOT = 64 * 4 * 4;  // values per partial-sum slot: 64 lanes x at most 4 targets x 4 results
 
 // Dense targets x sources evaluation of one LDS tile for k_dense: the arithmetic and the assignment of sources to splits
 // of lk_eval_tile() (split sp owns the contiguous sources [sp * full, (sp + 1) * full), the n_src - ns * full left over
@@ -542,16 +577,16 @@ __device__ __forceinline__ void sl_eval_tile(const typename vt<F>::v4 *__restric
 // Geometry of a node's work, the same in k_dense and k_combine.
 template <typename F>
 struct sl_node_geom {
-    uint32_t tb, te, n1, n2;
-    int T, nt1, nt2, nts, ntt, n_parts;
+    uint32_t tb, te, n1, n2, n3;
+    int T, nt1, nt2, nt3, nts, ntt, n_parts;
     const typename vt<F>::v4 *common;
 };
 template <typename F>
 __device__ __forceinline__ bool sl_geom(const kparams<F> &P, uint32_t g, sl_node_geom<F> &o)
 {
-    const uint32_t n2w = __builtin_amdgcn_readfirstlane(P.sl_cnt[g]);
+    const uint32_t n2w = __builtin_amdgcn_readfirstlane(P.sl_cnt[2u * g]);
     if (n2w & SL_OVER) {
-        return false; // the list was not completed: the fused kernel serves this node
+        return false; // the lists were not completed: the fused kernel serves this node
     }
     const uint4 c = P.crit[g];
     o.tb = c.x, o.te = c.y;
@@ -567,10 +602,12 @@ __device__ __forceinline__ bool sl_geom(const kparams<F> &P, uint32_t g, sl_node
         }
     }
     o.n2 = n2w;
+    o.n3 = __builtin_amdgcn_readfirstlane(P.sl_cnt[2u * g + 1u]);
     o.nt1 = static_cast<int>((o.n1 + SL_TILE - 1) / SL_TILE);
     o.nt2 = static_cast<int>((o.n2 + SL_TILE - 1) / SL_TILE);
+    o.nt3 = static_cast<int>((o.n3 + SL_TILE - 1) / SL_TILE);
     o.nts = (o.T + SL_TILE - 1) / SL_TILE;
-    o.ntt = o.nt1 + o.nt2 + o.nts;
+    o.ntt = o.nt1 + o.nt2 + o.nt3 + o.nts;
     o.n_parts = (o.ntt + SL_PART_TILES - 1) / SL_PART_TILES;
     return true;
 }
@@ -677,27 +714,35 @@ __global__ void __launch_bounds__(64, sizeof(F) == 4 ? (R <= 2 ? RK_SLD_W12 : (R
     const F eps2 = P.eps2;
     const int inv_ns = (65536 + NS - 1) / NS; // n / NS for n <= 128 without a division per tile
     static_assert(SL_TILE * 64 < 65536);
-    const uint32_t n1 = N.n1, n2 = N.n2;
-    const int nt1 = N.nt1, nt12 = N.nt1 + N.nt2, ntt = N.ntt;
+    const uint32_t n1 = N.n1, n2 = N.n2, n3 = N.n3;
+    const int nt1 = N.nt1, nt12 = N.nt1 + N.nt2, nt123 = nt12 + N.nt3, ntt = N.ntt;
     const v4 *common = N.common;
+    constexpr uint32_t TPS = SL_SEG / SL_TILE; // tiles per segment
 
-    // Segment of the own-list tile whose indices are fetched next (tiles are visited in increasing order).
-    uint32_t seg_no = 0, seg_id = g - P.sl_g0;
+    // Segment of the list tile whose indices are fetched next (tiles are visited in increasing order).
+    int seg_list = -1;
+    uint32_t seg_no = 0, seg_id = 0;
     uint32_t ix[2] = {0u, 0u};
     v4 pv[2];
-    // Indices of tile u (own-list tiles only).
+    // Indices of tile u (list tiles only: the node list, then the particle list).
     auto stage1 = [&](int u) __attribute__((always_inline)) {
-        if (u >= nt1 && u < nt12) {
-            const uint32_t t2 = static_cast<uint32_t>(u - nt1);
-            while (seg_no < (t2 >> 3)) {
+        if (u >= nt1 && u < nt123) {
+            const int w = u < nt12 ? 0 : 1;
+            const uint32_t t2 = static_cast<uint32_t>(u - (w ? nt12 : nt1)), nw = w ? n3 : n2;
+            if (seg_list != w) {
+                seg_list = w;
+                seg_no = 0;
+                seg_id = 2u * (g - P.sl_g0) + static_cast<uint32_t>(w);
+            }
+            while (seg_no < t2 / TPS) {
                 seg_id = __builtin_amdgcn_readfirstlane(P.sl_next[seg_id]);
                 ++seg_no;
             }
-            const uint32_t *src = P.sl_idx + static_cast<size_t>(seg_id) * SL_SEG + (t2 & 7u) * SL_TILE;
+            const uint32_t *src = P.sl_idx + static_cast<size_t>(seg_id) * SL_SEG + (t2 % TPS) * SL_TILE;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const uint32_t j = static_cast<uint32_t>(lane) + 64u * i;
-                ix[i] = t2 * SL_TILE + j < n2 ? src[j] : 0u;
+                ix[i] = t2 * SL_TILE + j < nw ? src[j] : 0u;
             }
         }
     };
@@ -709,17 +754,16 @@ __global__ void __launch_bounds__(64, sizeof(F) == 4 ? (R <= 2 ? RK_SLD_W12 : (R
                 const uint32_t j = static_cast<uint32_t>(u) * SL_TILE + static_cast<uint32_t>(lane) + 64u * i;
                 pv[i] = common[j < n1 ? j : 0u];
             }
-        } else if (u < nt12) {
+        } else if (u < nt123) {
+            const v4 *base = u < nt12 ? P.node_com : P.part4;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const uint32_t e = ix[i];
-                const v4 *base = (e & SL_PART) ? P.part4 : P.node_com;
-                pv[i] = base[e & ~SL_PART];
+                pv[i] = base[ix[i]];
             }
         } else {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int j = (u - nt12) * SL_TILE + lane + 64 * i;
+                const int j = (u - nt123) * SL_TILE + lane + 64 * i;
                 pv[i] = P.part4[tb + static_cast<uint32_t>(j < T ? j : 0)];
             }
         }
@@ -749,14 +793,15 @@ __global__ void __launch_bounds__(64, sizeof(F) == 4 ? (R <= 2 ? RK_SLD_W12 : (R
                 stage1(u + 2);
             }
 #endif
-            if (u < nt12) {
+            if (u < nt123) {
                 const uint32_t left = u < nt1 ? n1 - static_cast<uint32_t>(u) * SL_TILE
-                                              : n2 - static_cast<uint32_t>(u - nt1) * SL_TILE;
+                                              : (u < nt12 ? n2 - static_cast<uint32_t>(u - nt1) * SL_TILE
+                                                          : n3 - static_cast<uint32_t>(u - nt12) * SL_TILE);
                 const int n = left < static_cast<uint32_t>(SL_TILE) ? static_cast<int>(left) : SL_TILE;
                 sl_eval_tile<F, Q, R, false, ND>(tile, n, (n * inv_ns) >> 16, sp, NS, lane_on, tp, acc, eps2, tidx);
             } else {
                 // The node's own particles: the self pair is masked.
-                const int b0 = (u - nt12) * SL_TILE;
+                const int b0 = (u - nt123) * SL_TILE;
                 const int n = (T - b0) < SL_TILE ? (T - b0) : SL_TILE;
                 int tloc[R];
 #pragma unroll

@@ -266,6 +266,28 @@ class State:
         _capi.check(_capi.lib().rk_state_clone(C.byref(h), self._h, device))
         return State._from_handle(h, self.dtype, self.mac)
 
+    def clone_all(self, devices):
+        """rk_state_clone_all: replicas on several devices of this process at once (doubling tree of peer copies)."""
+        n = len(devices)
+        outs = (C.c_void_p * n)()
+        devs = (C.c_int * n)(*devices)
+        _capi.check(_capi.lib().rk_state_clone_all(outs, self._h, devs, n))
+        return [State._from_handle(C.c_void_p(outs[i]), self.dtype, self.mac) for i in range(n)]
+
+    @classmethod
+    def broadcast(cls, state, root, rank, device, comm, dtype=None, mac=None, stream=None):
+        """rk_state_broadcast: `state` of rank `root` is replicated on every rank of the RCCL communicator `comm` (Comm below).
+        Returns the state of this rank (the root's own on the root)."""
+        h = C.c_void_p(state._h.value if state is not None else None)
+        _capi.check(_capi.lib().rk_state_broadcast(C.byref(h), root, rank, device, comm.handle, stream))
+        if rank == root:
+            return state
+        info = (C.c_int64 * 8)()
+        _capi.check(_capi.lib().rk_state_info(h, info))
+        fp = int(info[4])
+        mac_id = int(info[5])
+        return cls._from_handle(h, np.float32 if fp == _capi.RK_F32 else np.float64, "bh" if mac_id == _capi.RK_MAC_BH else "bh_geom")
+
     @classmethod
     def from_buffers(cls, device, ptrs, nbytes, meta):
         h = C.c_void_p()
@@ -277,3 +299,23 @@ class State:
         dtype = np.float32 if meta[1] == _capi.RK_F32 else np.float64
         mac = "bh" if meta[2] == _capi.RK_MAC_BH else "bh_geom"
         return cls._from_handle(h, dtype, mac)
+
+
+class Comm:
+    """RCCL communicator made by the library (rk_comm_*): Comm.unique_id() on one rank, ship the bytes, Comm(n, id, rank, device)
+    on every rank."""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        _capi.check(_capi.lib().rk_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, n_ranks, uid, rank, device):
+        self.handle = C.c_void_p()
+        _capi.check(_capi.lib().rk_comm_init(C.byref(self.handle), n_ranks, uid, rank, device))
+
+    def close(self):
+        if self.handle:
+            _capi.lib().rk_comm_destroy(self.handle)
+            self.handle = C.c_void_p()

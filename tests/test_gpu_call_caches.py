@@ -72,7 +72,7 @@ cr = st.crit_ranges()
 cuts = [0, int(cr[len(cr) // 3, 0]), n]
 mv = rakau_amd.mac_value_of(0.75, "bh", np.float32)
 res = {}
-for variant in (0, 2, 3):
+for variant in (0, 2, 3, 4):
     st.set_variant(variant)
     for q in (0, 2):
         for b, e in ((0, n), (cuts[0], cuts[1]), (cuts[1], cuts[2])):
@@ -93,7 +93,7 @@ np.savez(sys.argv[1], **res)
         out = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True, timeout=600, env=env, cwd=root)
         assert out.returncode == 0, out.stderr[-2000:]
         files.append(np.load(f))
-    assert len(files[0].files) == 36
+    assert len(files[0].files) == 48
     for k in files[0].files:
         assert np.isfinite(files[0][k]).all()
         assert np.array_equal(files[0][k], files[1][k]), k

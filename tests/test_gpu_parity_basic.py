@@ -1,5 +1,6 @@
 """GPU parity: HIP path (through the C ABI) vs the CPU oracle on identical trees, every kernel variant (1 = depth-first
-wave kernel, 2 = list kernel, 3 = producer / consumer kernel; 0 = automatic mixes 2 and 3 by launch size)."""
+wave kernel, 2 = list kernel, 3 = producer / consumer kernel, 4 = split traversal (lists in HBM); 0 = automatic mixes 2
+and 3 by launch size)."""
 import numpy as np
 import pytest
 
@@ -14,7 +15,7 @@ pytestmark = pytest.mark.gpu
 # fp64 <= 2e-11 (test/ordering_acc.cpp:94); identical lists deliver far better, so a tighter regression
 # bound is asserted (~1e-7 median, < 1e-5 max in fp32).
 TIGHT = {np.float32: 2e-5, np.float64: 1e-12}
-VARIANTS = [1, 2, 3]
+VARIANTS = [1, 2, 3, 4]
 
 
 def check(got, ref, q, dtype, tol=None, ndim=3):
@@ -163,7 +164,7 @@ def test_list_and_producer_consumer_kernels_give_the_same_bits(dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
 def test_accs_pots_equal_accs_and_pots(dtype, variant):
     """accs_u(), pots_u() and accs_pots_u() evaluate the same expressions (as the reference's batch_batch_3d_* do,
     tree.hpp:2008-2068): the accelerations of Q = 0 and the potentials of Q = 1 are those of Q = 2, bit for bit."""
@@ -177,3 +178,32 @@ def test_accs_pots_equal_accs_and_pots(dtype, variant):
     for k in range(3):
         assert np.array_equal(accs[k], both[k])
     assert np.array_equal(pots[0], both[3])
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_split_traversal_one_wave_per_node_or_per_part_same_bits(dtype, monkeypatch):
+    """Variant 4 sums every target's contributions in an order that is a function of the node and the MAC value only (tiles
+    of 128 sources, parts of four tiles added up in order): one wavefront per node, one wavefront per part (+ k_combine),
+    and shards that run in the other form than the full range all give the same bits; octree and quadtree, Q = 0, 1, 2."""
+    for n, ndim in ((40000, 3), (20000, 2)):
+        if ndim == 3:
+            m, x, y, z = oracle.plummer(n, dtype)
+            ot = oracle.Tree(x, y, z, m)
+        else:
+            m, x, y = oracle.Rng(4).uniform_particles(n, 3.0, dtype, ndim=2)
+            ot = oracle.Tree(x, y, None, m, ndim=2)
+        st = state_from_oracle(ot)
+        st.set_variant(4)
+        mv = mac_value_of(0.6, ot.mac, dtype)
+        cr = st.crit_ranges()
+        b, e = int(cr[len(cr) // 5, 0]), int(cr[4 * len(cr) // 5, 0])
+        for q in (0, 1, 2):
+            monkeypatch.setenv("RK_SL_PARTS_BELOW", "0")
+            whole = st.acc_pot(q, mv, eps2=1e-5, G=1.25)
+            monkeypatch.setenv("RK_SL_PARTS_BELOW", "100000000")
+            parts = st.acc_pot(q, mv, eps2=1e-5, G=1.25)
+            monkeypatch.setenv("RK_SL_PARTS_BELOW", str(len(cr) // 2))  # the shard runs per part, the full range per node
+            shard = st.acc_pot(q, mv, eps2=1e-5, G=1.25, p_begin=b, p_end=e, offset_output=False)
+            for w, p, s in zip(whole, parts, shard):
+                assert np.array_equal(w, p), (n, ndim, q)
+                assert np.array_equal(w[b:e], s), (n, ndim, q)
