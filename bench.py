@@ -200,6 +200,11 @@ def main():
     if dev >= torch.cuda.device_count():
         raise SystemExit("bench.py --gpus %d needs %d GPUs, %d visible (RK_BENCH_SINGLE_DEVICE=1 RK_BENCH_BACKEND=gloo "
                          "rehearses the multi-rank path on one GPU)" % (args.gpus, args.gpus, torch.cuda.device_count()))
+    # Cold start, measured before anything else in this process touches the GPU: rk_init() = HIP runtime + device context +
+    # the code objects of all kernel families (seconds on a box whose libraries are not yet in the page cache).
+    t0 = time.perf_counter()
+    _capi.check(_capi.lib().rk_init(dev))
+    t_init = time.perf_counter() - t0
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
@@ -251,22 +256,43 @@ def main():
         finally:
             rakau_amd.set_build_exact(args.builder == "device")
     replicate_via = None
+    lib_comm = None
     if world > 1 and backend == "nccl":
         # The replicate step lives in the library: rk_comm_* + rk_state_broadcast (ncclBroadcast of the meta block and of
-        # every buffer of the state, RCCL over xGMI). torch.distributed only ships the 128-byte communicator id.
+        # every buffer of the state, RCCL over xGMI). torch.distributed only ships the 128-byte communicator id -- and
+        # remains the fallback (same buffers through dist.broadcast) should the library's communicator not come up on
+        # every rank (all ranks take the same branch: the outcome is all-reduced).
         from rakau_amd.state import Comm
-        payload = [Comm.unique_id() if rank == 0 else None]
+        ok = 1
+        try:
+            payload = [Comm.unique_id() if rank == 0 else None]
+        except Exception as e:  # pragma: no cover
+            payload, ok = [None], 0
+            print("rank %d: rk_comm_unique_id failed: %s" % (rank, e), file=sys.stderr)
         dist.broadcast_object_list(payload, src=0)
-        comm = Comm(world, payload[0], rank, dev)
+        try:
+            if payload[0] is None:
+                raise RuntimeError("no communicator id")
+            lib_comm = Comm(world, payload[0], rank, dev) if ok else None
+        except Exception as e:  # pragma: no cover
+            ok = 0
+            print("rank %d: rk_comm_init failed: %s" % (rank, e), file=sys.stderr)
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0 and lib_comm is not None:
+            lib_comm.close()
+            lib_comm = None
+    if lib_comm is not None:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        state = rakau_amd.State.broadcast(state if rank == 0 else None, 0, rank, dev, comm)
+        state = rakau_amd.State.broadcast(state if rank == 0 else None, 0, rank, dev, lib_comm)
         torch.cuda.synchronize()
         t_replicate = time.perf_counter() - t0
-        comm.close()
-        replicate_via = "rk_state_broadcast (RCCL)"
+        lib_comm.close()
+        replicate_via = "rk_state_broadcast (RCCL, inside the library)"
     elif world > 1:
-        # One-GPU rehearsal of the multi-rank path (gloo): the exported buffers travel through host memory.
+        # rk_state_export -> torch.distributed broadcast -> rk_state_import: the one-GPU rehearsal of the multi-rank path
+        # (gloo: the buffers travel through host memory) and the fallback of the branch above (nccl: device to device).
         payload = [None]
         if rank == 0:
             ptrs, nbytes, meta = state.export()
@@ -280,15 +306,18 @@ def main():
             for t, p, b in zip(bufs, ptrs, nbytes):
                 _capi.check(lib.rk_device_memcpy(t.data_ptr(), p, b, dev))
         for t in bufs:
-            h = t.cpu()
-            dist.broadcast(h, src=0)
-            t.copy_(h)
+            if backend == "nccl":
+                dist.broadcast(t, src=0)
+            else:
+                h = t.cpu()
+                dist.broadcast(h, src=0)
+                t.copy_(h)
         torch.cuda.synchronize()
         t_replicate = time.perf_counter() - t0
         if rank != 0:
             state = rakau_amd.State.from_buffers(dev, [t.data_ptr() for t in bufs], nbytes, meta)
         del bufs
-        replicate_via = "rk_state_export / import through host memory (gloo rehearsal)"
+        replicate_via = "rk_state_export / torch.distributed broadcast (%s) / rk_state_import" % backend
     else:
         t_replicate = 0.0
     if args.variant:
@@ -324,6 +353,12 @@ def main():
     # (2.80, 2.71, 2.65, 2.60, 2.53, 2.49, 2.45, 2.43, 2.43, 2.38, ... 2.33 ms; RK_BENCH_DEBUG=1 prints the series), more
     # than W = 3-5 steps provide. Hence at least 5 calls and 80 ms of kernel time here; the median of the last (up to)
     # 10 is `kernel_ms`. Workloads whose calls take tens of milliseconds need, and get, no more than that.
+    # The very first traversal call on this state (launch-path set-up, scratch allocation, the supergroup pre-pass).
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    first_call_ms = (time.perf_counter() - t0) * 1e3
     census = state.count_interactions(mac_value, p_begin, p_end)
     inter_local = census["com"] + census["pp"] + census["self"]
     kms, busy_ms = [], 0.0
@@ -456,6 +491,9 @@ def main():
                     "frac": round(hbm_gbs / PEAK_HBM_GBS, 5), "algorithmic_bytes_per_launch": int(bytes_launch)},
         },
         "host": {"builder": args.builder, "tree_build_s": round(t_build, 3), "upload_s": round(t_upload, 3),
+                 # Cold start: rk_init (first GPU touch of the process), the first state of the process, its first call.
+                 "rk_init_s": round(t_init, 3), "state_create_cold_s": round(t_upload, 3),
+                 "first_call_ms": round(first_call_ms, 3),
                  "replicate_s": round(t_replicate, 4), "replicate_via": replicate_via,
                  "device_build_s": round(t_dev_build, 4) if isinstance(t_dev_build, float) else t_dev_build,
                  "device_build_exact_s": round(t_dev_build_exact, 4) if isinstance(t_dev_build_exact, float) else None},

@@ -31,6 +31,7 @@
  *                                rk_state_tree_info, rk_state_device_ptr, rk_state_set_perm, rk_set_build_exact,
  *                                rk_pool_trim
  *   CPU share of kwargs::split   rk_cpu_engine_run (AVX-512 flavour of the header's CPU engine, chosen at run time)
+ *   warm-up                      rk_init
  *   diagnostics                  rk_state_info, rk_state_ndim, rk_last_kernel_ms, rk_state_set_timing, rk_count_interactions,
  *                                rk_set_kernel_variant
  *
@@ -80,6 +81,10 @@ RK_EXPORT int rk_has_accelerator(void);
 /* Number of visible HIP devices (0 on failure). Test knob: RK_ALIAS_DEVICES=<n> makes the library report n LOGICAL
  * devices mapped round-robin onto the physical ones, so that multi-device host logic can run on a 1-GPU box. */
 RK_EXPORT int rk_device_count(void);
+/* Optional: pay the one-off costs of the first call on `device` now (HIP runtime and device context, the code objects of all
+ * kernel families, the device-memory cache) -- 0.1-0.3 s on a warm box, seconds on a box whose libraries are not yet in the
+ * page cache -- so that the first rk_state_create / rk_acc_pot of a latency-sensitive caller do not. */
+RK_EXPORT int rk_init(int device);
 
 /*
  * Build the device-resident state for a constructed tree (3-D, 64-bit codes).

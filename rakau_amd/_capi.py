@@ -27,7 +27,7 @@ SYMBOLS = [
     "rk_state_tree_info", "rk_state_download", "rk_state_build_device", "rk_state_set_perm", "rk_state_device_ptr",
     "rk_state_rebuild_device", "rk_pool_trim", "rk_set_build_exact", "rk_cpu_engine_run", "rk_group_work", "rk_state_create_nd", "rk_state_build_nd",
     "rk_state_ndim", "rk_host_alloc", "rk_host_free", "rk_state_set_timing", "rk_state_clone_all", "rk_comm_unique_id",
-    "rk_comm_init", "rk_comm_destroy", "rk_state_broadcast",
+    "rk_comm_init", "rk_comm_destroy", "rk_state_broadcast", "rk_init",
     # host-side tree builder (include/rakau_amd_tree.h)
     "rk_tree_create", "rk_tree_create_nd", "rk_tree_destroy", "rk_tree_info", "rk_tree_get", "rk_tree_nodes", "rk_tree_state",
     "rk_tree_acc_pot", "rk_tree_exact", "rk_tree_update_particles", "rk_tree_cpu_acc_pot",
@@ -87,6 +87,7 @@ def lib():
     L.rk_state_export.argtypes = [vp, C.POINTER(ci), C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)]
     L.rk_state_import.argtypes = [C.POINTER(vp), ci, ci, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)]
     L.rk_state_clone.argtypes = [C.POINTER(vp), vp, ci]
+    L.rk_init.argtypes = [ci]
     L.rk_state_clone_all.argtypes = [C.POINTER(vp), vp, C.POINTER(ci), ci]
     L.rk_comm_unique_id.argtypes = [C.c_char_p]
     L.rk_comm_init.argtypes = [C.POINTER(vp), ci, C.c_char_p, ci, ci]

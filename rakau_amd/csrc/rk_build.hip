@@ -1136,4 +1136,11 @@ template void build_device<double, 3>(rk_state &, const void *const[4], bool, in
 template void build_device<float, 2>(rk_state &, const void *const[4], bool, int64_t, double, uint64_t, std::string &);
 template void build_device<double, 2>(rk_state &, const void *const[4], bool, int64_t, double, uint64_t, std::string &);
 
+// Makes the runtime load this translation unit's code object now (rk_init) instead of at the first build.
+void touch_build()
+{
+    hipFuncAttributes attr{};
+    RK_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&bld::k_box<float>)));
+}
+
 } // namespace rk

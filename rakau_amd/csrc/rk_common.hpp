@@ -261,6 +261,9 @@ struct rk_state {
     // the device's address space), delivered to the caller's pageable arrays by host threads.
     void *h_stage = nullptr;
     size_t h_stage_bytes = 0;
+    // Output arrays of the previous rk_acc_pot() call (pageable arrays seen before are registered whatever their size).
+    const void *last_host_out[4] = {};
+    size_t last_host_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // Side streams (and fork/join events) that let the per-class kernels of one call overlap.
     hipStream_t aux_stream[rk::n_list_R] = {};
@@ -370,6 +373,11 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
                   uint64_t max_leaf_n, std::string &bad_coord_msg);
 // Device builder: sum node properties in the reference's serial association (rk_set_build_exact / RK_BUILD_EXACT).
 bool exact_node_sums();
+void touch_kernels();
+void touch_list();
+void touch_pc();
+void touch_split();
+void touch_build();
 template <typename F>
 void launch_census(const rk_state &s, const kparams<F> &p, int64_t g_begin, int64_t g_end,
                    unsigned long long *d_counts, unsigned long long *d_per_group, hipStream_t stream);

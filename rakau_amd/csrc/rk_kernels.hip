@@ -383,4 +383,11 @@ template void launch_traversal<float>(const rk_state &, int, const kparams<float
 template void launch_traversal<double>(const rk_state &, int, const kparams<double> &, const int64_t[n_classes],
                                        const int64_t[n_classes], hipStream_t);
 
+// Makes the runtime load this translation unit's code object now (rk_init) instead of at the first launch.
+void touch_kernels()
+{
+    hipFuncAttributes attr{};
+    RK_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_census<float, 0>)));
+}
+
 } // namespace rk

@@ -814,4 +814,11 @@ template void launch_list<float>(const rk_state &, int, const kparams<float> &, 
 template void launch_list<double>(const rk_state &, int, const kparams<double> &, const int64_t[n_classes],
                                   const int64_t[n_classes], hipStream_t const[n_list_R], unsigned);
 
+// Makes the runtime load this translation unit's code object now (rk_init) instead of at the first launch.
+void touch_list()
+{
+    hipFuncAttributes attr{};
+    RK_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_super<float, 0>)));
+}
+
 } // namespace rk

@@ -610,4 +610,11 @@ template void launch_pc<float>(const rk_state &, int, const kparams<float> &, co
 template void launch_pc<double>(const rk_state &, int, const kparams<double> &, const int64_t[n_classes],
                                 const int64_t[n_classes], hipStream_t const[n_list_R], unsigned);
 
+// Makes the runtime load this translation unit's code object now (rk_init) instead of at the first launch.
+void touch_pc()
+{
+    hipFuncAttributes attr{};
+    RK_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_pc<float, 0, 0, 2, 3>)));
+}
+
 } // namespace rk

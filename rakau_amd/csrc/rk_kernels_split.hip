@@ -989,4 +989,11 @@ template void launch_dense<float>(const rk_state &, int, const kparams<float> &,
 template void launch_dense<double>(const rk_state &, int, const kparams<double> &, const int64_t[n_classes],
                                    const int64_t[n_classes], hipStream_t const[n_list_R], unsigned, int);
 
+// Makes the runtime load this translation unit's code object now (rk_init) instead of at the first launch.
+void touch_split()
+{
+    hipFuncAttributes attr{};
+    RK_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_lists<float, 0>)));
+}
+
 } // namespace rk
