@@ -506,12 +506,17 @@ def main():
     try:
         if world == 1:
             host_out = [np.zeros(n, dtype=dtype) for _ in range(nres)]
-            ts = []
-            for _ in range(7):  # the first call touches the arrays, the second captures the launch graph
-                t0 = time.perf_counter()
-                state.acc_pot(q, mac_value, eps2=eps2, out=host_out)
-                ts.append(time.perf_counter() - t0)
-            t_host = float(np.median(ts[2:]))
+            # The GPU has idled through the CPU baseline above: like the device-output loop this one first runs until the
+            # clocks have settled (at least 7 calls and 80 ms), then takes the median of the last calls.
+            def settle_and_time(arrays):
+                ts, busy = [], 0.0
+                while len(ts) < 7 or (busy < 0.08 and len(ts) < 200):
+                    t0 = time.perf_counter()
+                    state.acc_pot(q, mac_value, eps2=eps2, out=arrays)
+                    ts.append(time.perf_counter() - t0)
+                    busy += ts[-1] if len(ts) > 2 else 0.0
+                return float(np.median(ts[-min(10, len(ts) - 2):]))
+            t_host = settle_and_time(host_out)
             line["host"]["kernel_ms_host_outputs"] = round(state.last_kernel_ms(), 4)
             line["host"]["acc_pot_host_outputs_ms"] = round(t_host * 1e3, 3)
             line["value_host_outputs"] = round(n / t_host / 1e6, 2)
@@ -519,12 +524,7 @@ def main():
             # Same call, output arrays in pinned host memory (rk_host_alloc / rakau_amd::pinned_allocator): the kernels
             # write the results into the caller's arrays themselves.
             pin_out = [rakau_amd.pinned_empty(n, dtype) for _ in range(nres)]
-            ts = []
-            for _ in range(7):
-                t0 = time.perf_counter()
-                state.acc_pot(q, mac_value, eps2=eps2, out=pin_out)
-                ts.append(time.perf_counter() - t0)
-            t_pin = float(np.median(ts[2:]))
+            t_pin = settle_and_time(pin_out)
             line["host"]["kernel_ms_pinned_outputs"] = round(state.last_kernel_ms(), 4)
             line["value_host_outputs_pinned"] = round(n / t_pin / 1e6, 2)
             line["ms_per_call_host_outputs_pinned"] = round(t_pin * 1e3, 4)

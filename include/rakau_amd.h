@@ -332,8 +332,10 @@ RK_EXPORT int rk_cpu_engine_run(const rk_cpu_job *job);
 
 /* Select the traversal kernel: 0 = automatic (default: the producer / consumer kernel for calls over few critical nodes,
  * the list kernel otherwise), 1 = wave-per-group scalar DFS, 2 = LDS interaction-list kernel (one wave per critical
- * node), 3 = producer / consumer waves per critical node. 2 and 3 give bit-identical results (same interaction lists,
- * same summation order); 1 sums in the CPU engine's order. For tests and benchmarks. */
+ * node), 3 = producer / consumer waves per critical node, 4 = split traversal (list building and dense evaluation as two
+ * kernels, the lists in HBM; slower, kept as a cross-check). 2 and 3 give bit-identical results (same interaction lists,
+ * same summation order); 1 sums in the CPU engine's order, 4 in a breadth-first order of its own that does not depend on
+ * the launch either. For tests and benchmarks. */
 RK_EXPORT int rk_set_kernel_variant(rk_state *s, int variant);
 
 #ifdef __cplusplus

@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(64 * (BIG ? LK_BIG_WPB : RK_WPB), BIG ? (sizeo
         RK_STAMP_DECL
 #ifdef RK_TRACE
         // Diagnostic build: wall-clock interval (100 MHz counter) and placement of every wave, for occupancy timelines.
-        const unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime(), tr_c0 = __builtin_amdgcn_s_memtime();
 #endif
         int size = 0, n_src = 0, n_lq = 0, n_uq = 0;
         // Supergroup pre-pass results for this group's supergroup (if enabled and not overflowed).
@@ -564,7 +564,9 @@ __global__ void __launch_bounds__(64 * (BIG ? LK_BIG_WPB : RK_WPB), BIG ? (sizeo
             P.dbg[4u * g] = tr_t0;
             P.dbg[4u * g + 1u] = __builtin_amdgcn_s_memrealtime();
             P.dbg[4u * g + 2u] = (static_cast<unsigned long long>(xcc) << 32) | hw;
-            P.dbg[4u * g + 3u] = (static_cast<unsigned long long>(R) << 32) | static_cast<unsigned>(T);
+            // {R, T, shader cycles of this wave}: cycles / duration = the clock the chip held meanwhile.
+            P.dbg[4u * g + 3u] = (static_cast<unsigned long long>(R) << 56) | (static_cast<unsigned long long>(T) << 32)
+                                 | ((__builtin_amdgcn_s_memtime() - tr_c0) & 0xffffffffull);
         }
 #endif
     }; // run_targets

@@ -93,7 +93,7 @@ constexpr int LK_UQ_CAP = 128;
 // Critical nodes too large for one wavefront (k_list<..., BIG>): wavefronts per workgroup, targets per chunk.
 #ifndef RK_BIG_WPB
 #define RK_BIG_WPB 4 // 8: 1.9 instead of 3.2 ms when only 512 such nodes exist, 2.86 instead of 2.44 s on the 256M tree of
-                     // profiles/r02/big_runs.txt (tools/r02_job33.sh)
+                     // profiles/r02/big_runs.txt (tools/archive_r02/r02_job33.sh)
 #endif
 #ifndef RK_WBIG
 #define RK_WBIG 7 // waves per SIMD the BIG kernels are compiled for (5: spill-free, equal or slower)

@@ -665,11 +665,11 @@ void census_impl(rk_state &s, int64_t p_begin, int64_t p_end, double mac_value, 
 //  * lpt (calls of at most RK_PLAN_MAX_GROUPS nodes): sorted by decreasing work (longest processing time first), so
 //    that a launch of only a few rounds of waves ends with its lightest nodes. (Sorting whole supergroups by their mean
 //    work instead -- spatially compact runs that share the pre-pass lists -- measured 3-7 % slower from 100k particles
-//    to the 0.5M-particle shards of the 4M tree: tools/r02_job27.sh.)
+//    to the 0.5M-particle shards of the 4M tree: tools/archive_r02/r02_job27.sh.)
 //  * otherwise: Morton order (neighbouring nodes share tree nodes and leaves in the L2), but the lightest quarter of the
 //    nodes goes last: the device then drains over the duration of short waves instead of average ones (4M: 2.32-2.33
-//    -> 2.27-2.28 ms; a full LPT order costs 60 % there: tools/r02_job41.sh), and every XCD works through one spatial
-//    region of the range in ALL class kernels (same time, 8.5 % fewer bytes fetched past the L2: tools/r02_job46.sh).
+//    -> 2.27-2.28 ms; a full LPT order costs 60 % there: tools/archive_r02/r02_job41.sh), and every XCD works through one spatial
+//    region of the range in ALL class kernels (same time, 8.5 % fewer bytes fetched past the L2: tools/archive_r02/r02_job46.sh).
 bool plan_regions_enabled()
 {
     static const bool on = [] {
@@ -684,7 +684,7 @@ void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64
 {
     ensure_mirrors(s);
     // Weight of a node = its number of particles: as good a predictor of a wave's duration as the interaction census
-    // (4M: 2.24-2.26 ms either way; tools/r02_job54.sh) and free, where the census is a traversal of its own (13 ms at 4M).
+    // (4M: 2.24-2.26 ms either way; tools/archive_r02/r02_job54.sh) and free, where the census is a traversal of its own (13 ms at 4M).
     if (s.work_cache.size() != static_cast<size_t>(s.n_crit)) {
         s.work_cache.resize(static_cast<size_t>(s.n_crit));
         for (int64_t g = 0; g < s.n_crit; ++g) {
@@ -946,6 +946,62 @@ bool prepare_split(rk_state &s, rk::kparams<F> &p, int64_t p_begin, int64_t p_en
     return !(s.sl_clean_valid && s.sl_clean_key == key);
 }
 
+// Streams, events and the supergroup scratch a traversal call needs. Created with the state (so that the first call does not
+// pay for them: 166 MB of scratch at 4M) and checked again by every call (a rebuilt tree may have more critical nodes).
+template <typename F>
+void ensure_call_resources(rk_state &s)
+{
+    if (!s.ev0) {
+        RK_HIP(hipEventCreate(&s.ev0));
+        RK_HIP(hipEventCreate(&s.ev1));
+    }
+    if (s.super_k < 0) {
+        const char *e = std::getenv("RK_SUPER_K");
+        s.super_k = e ? std::atoi(e) : 16;
+        if (s.super_k < 0 || s.super_k > 64) {
+            s.super_k = 16;
+        }
+    }
+    if (s.super_k > 0 && s.n_crit > 0) {
+        const int64_t n_super = (s.n_crit + s.super_k - 1) / s.super_k;
+        if (s.sup_alloc < n_super) {
+            RK_HIP(hipDeviceSynchronize());
+            for (void **b : {&s.sup_common, &s.sup_resid, &s.sup_cnt}) {
+                rk::pool_free(*b);
+                *b = nullptr;
+            }
+            s.sup_alloc = 0;
+            s.sup_b = s.sup_e = 0;
+            s.sup_common = rk::pool_alloc(static_cast<size_t>(n_super) * rk::SUP_CAPC * sizeof(typename rk::vt<F>::v4));
+            s.sup_resid = rk::pool_alloc(static_cast<size_t>(n_super) * rk::SUP_CAPR * sizeof(uint32_t));
+            s.sup_cnt = rk::pool_alloc(static_cast<size_t>(n_super) * sizeof(uint2));
+            s.sup_alloc = n_super;
+        }
+    }
+    // Side streams / events of the fork-join (created once, outside any capture).
+    if (!s.aux_stream[0]) {
+        for (int i = 0; i < rk::n_list_R - 1; ++i) {
+            RK_HIP(hipStreamCreateWithFlags(&s.aux_stream[i], hipStreamNonBlocking));
+            RK_HIP(hipEventCreateWithFlags(&s.ev_join[i], hipEventDisableTiming));
+        }
+        RK_HIP(hipEventCreateWithFlags(&s.ev_fork, hipEventDisableTiming));
+        RK_HIP(hipStreamCreateWithFlags(&s.cap_stream, hipStreamNonBlocking));
+    }
+    if (!s.sup_ev) {
+        RK_HIP(hipEventCreateWithFlags(&s.sup_ev, hipEventDisableTiming));
+    }
+}
+
+void ensure_call_resources_any(rk_state &s)
+{
+    device_guard dg(s.device);
+    if (s.fp == RK_F32) {
+        ensure_call_resources<float>(s);
+    } else {
+        ensure_call_resources<double>(s);
+    }
+}
+
 template <typename F>
 void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d_out, double mac_value, double G,
               double eps2, int offset_output, hipStream_t stream, bool allow_graph = true)
@@ -1035,10 +1091,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
         p.dbg = d_tr;
     }
 #endif
-    if (!s.ev0) {
-        RK_HIP(hipEventCreate(&s.ev0));
-        RK_HIP(hipEventCreate(&s.ev1));
-    }
+    ensure_call_resources<F>(s);
     // allow_graph is false on the host-output path, which waits on ev1 for completion.
     const bool need_done_event = !allow_graph;
     if (s.timing) {
@@ -1051,42 +1104,12 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
     p.sup_resid = nullptr;
     p.sup_cnt = nullptr;
     if (v2) {
-        // Supergroup pre-pass: K consecutive groups share the upper part of list building (0 disables).
-        if (s.super_k < 0) {
-            const char *e = std::getenv("RK_SUPER_K");
-            s.super_k = e ? std::atoi(e) : 16;
-            if (s.super_k < 0 || s.super_k > 64) {
-                s.super_k = 16;
-            }
-        }
+        // Supergroup pre-pass: K consecutive groups share the upper part of list building (RK_SUPER_K=0 disables).
         if (s.super_k > 0 && s.n_crit > 0) {
-            const int64_t n_super = (s.n_crit + s.super_k - 1) / s.super_k;
-            if (s.sup_alloc < n_super) {
-                RK_HIP(hipDeviceSynchronize());
-                for (void **b : {&s.sup_common, &s.sup_resid, &s.sup_cnt}) {
-                    rk::pool_free(*b);
-                    *b = nullptr;
-                }
-                s.sup_alloc = 0;
-                s.sup_b = s.sup_e = 0;
-                s.sup_common = rk::pool_alloc(static_cast<size_t>(n_super) * rk::SUP_CAPC * sizeof(typename rk::vt<F>::v4));
-                s.sup_resid = rk::pool_alloc(static_cast<size_t>(n_super) * rk::SUP_CAPR * sizeof(uint32_t));
-                s.sup_cnt = rk::pool_alloc(static_cast<size_t>(n_super) * sizeof(uint2));
-                s.sup_alloc = n_super;
-            }
             p.super_k = static_cast<uint32_t>(s.super_k);
             p.sup_common = static_cast<typename rk::vt<F>::v4 *>(s.sup_common);
             p.sup_resid = static_cast<uint32_t *>(s.sup_resid);
             p.sup_cnt = static_cast<uint2 *>(s.sup_cnt);
-        }
-        // Side streams / events of the fork-join (created once, outside any capture).
-        if (!s.aux_stream[0]) {
-            for (int i = 0; i < rk::n_list_R - 1; ++i) {
-                RK_HIP(hipStreamCreateWithFlags(&s.aux_stream[i], hipStreamNonBlocking));
-                RK_HIP(hipEventCreateWithFlags(&s.ev_join[i], hipEventDisableTiming));
-            }
-            RK_HIP(hipEventCreateWithFlags(&s.ev_fork, hipEventDisableTiming));
-            RK_HIP(hipStreamCreateWithFlags(&s.cap_stream, hipStreamNonBlocking));
         }
         static const bool serial = [] {
             // RK_SERIAL_CLASSES=1 keeps the class kernels on one stream (one after the other), which gives
@@ -1160,9 +1183,6 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
         }
         const bool need_super = se > sb && !(sup_cache && s.sup_mac == mac_value && s.sup_b <= sb && se <= s.sup_e);
         ran_super = need_super;
-        if (!s.sup_ev) {
-            RK_HIP(hipEventCreateWithFlags(&s.sup_ev, hipEventDisableTiming));
-        }
         if (se > sb) {
             s.sup_stream = stream;
         }
@@ -1194,7 +1214,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
             // ends with its longest serial chains running alone. Such calls hand lane-mapping classes to the producer /
             // consumer kernel (1 + R waves per node): all of them below 5 000 critical nodes, the class with the longest
             // chains (R = 2: 64 < T <= 128 targets on one wave) below 20 000. Both kernels give the same bits, so this is
-            // a pure scheduling decision (measured: tools/r02_job11.sh, r02_job12.sh).
+            // a pure scheduling decision (measured: tools/archive_r02/r02_job11.sh, r02_job12.sh).
             static const int64_t pc_all_below = [] {
                 const char *e = std::getenv("RK_PC_ALL_BELOW");
                 return e ? std::atoll(e) : int64_t(5000);
@@ -1214,6 +1234,13 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                 const int64_t ng = g_hi - g_lo;
                 pc_mask = ng <= pc_all_below ? 0xfu : (ng <= pc_r2_below ? 0x2u : 0u);
             }
+            // Order in which the class kernels are handed to the GPU. The dispatcher serves the queues roughly in launch
+            // order until the device is full, so the classes launched last start late, and their longest nodes end the
+            // call: RK_CLASS_ORDER (e.g. "4312": R = 4 first) overrides the default.
+            static const std::string class_order = [] {
+                const char *e = std::getenv("RK_CLASS_ORDER");
+                return std::string(e ? e : "");
+            }();
             if (split) {
                 if (p.sl_parts_mode) {
                     // One wavefront per part, then the per-node sums (same stream per class: ordered).
@@ -1222,6 +1249,24 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                 } else {
                     rk::launch_dense<F>(s, q, p, cb, ce, streams, 0xfu, 0);
                 }
+            } else if (!class_order.empty()) {
+                unsigned done_mask = 0u;
+                for (const char ch : class_order) {
+                    const int c = ch - '1';
+                    if (c < 0 || c >= RK_MAX_R || ((done_mask >> c) & 1u)) {
+                        continue;
+                    }
+                    done_mask |= 1u << c;
+                    if ((pc_mask >> c) & 1u) {
+                        rk::launch_pc<F>(s, q, p, cb, ce, streams, 1u << c);
+                    } else {
+                        rk::launch_list<F>(s, q, p, cb, ce, streams, 1u << c);
+                    }
+                }
+                if (pc_mask & ~done_mask) {
+                    rk::launch_pc<F>(s, q, p, cb, ce, streams, pc_mask & ~done_mask);
+                }
+                rk::launch_list<F>(s, q, p, cb, ce, streams, ~pc_mask & ~done_mask);
             } else {
                 if (pc_mask) {
                     rk::launch_pc<F>(s, q, p, cb, ce, streams, pc_mask);
@@ -1552,6 +1597,7 @@ int rk_state_create_nd(rk_state **out, int ndim, int fp, int mac, int device, co
             } else {
                 create_impl<double>(*s, parts, nparts, tree, tree_size, node_stride);
             }
+            ensure_call_resources_any(*s);
         }
         *out = s.release();
     });
@@ -2030,6 +2076,7 @@ static void replica_finish(rk_state &s)
         RK_HIP(hipMemcpy(crit.data(), s.buf[RK_BUF_CRIT], crit.size() * sizeof(uint4), hipMemcpyDeviceToHost));
     }
     build_host_mirrors(s, crit);
+    ensure_call_resources_any(s);
 }
 
 // rk_state_import (buffers already on `device`: src_device < 0) and rk_state_clone (buffers on src_device).
@@ -2376,6 +2423,7 @@ static int state_build_impl(rk_state **out, int ndim, int fp, int mac, int devic
         s->ncrit = ncrit;
         s->max_leaf_n = max_leaf_n;
         fill_from_build(*s, parts, on_device, nparts, box_size);
+        ensure_call_resources_any(*s);
         *out = s.release();
     });
 }

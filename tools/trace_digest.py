@@ -36,3 +36,9 @@ for a,b in ((0,0.5),(0.5,0.8),(0.8,0.9),(0.9,1.0)):
 # late starters
 order=np.argsort(-t1)[:10]
 for i in order: print('late end: start %.0f end %.0f dur %.0f T %d R %d work %.3g xcd %d'%(t0[i],t1[i],dur[i],T[i],R[i],work[i],xcc[i]))
+# start-time histogram (waves started per 5 % slice of the span) per class: how fast the launch fills the device
+edges=np.linspace(0,t1.max(),21)
+for r in sorted(set(R)):
+    s=R==r
+    h,_=np.histogram(t0[s],bins=edges)
+    print('R',r,'starts per 5% slice:',' '.join('%d'%v for v in h))
