@@ -298,6 +298,9 @@ struct rk_state {
         void *d_lists = nullptr;
         int64_t alloc = 0; // entries allocated
         int64_t off[rk::n_classes + 1] = {};
+        // Heavy-first plans also carry merged lists for the one-launch kernels (k_pc_any / k_list_any): the wave-kernel
+        // classes together, and without the R = 2 class (which then keeps its own producer / consumer launch).
+        int64_t off_all = 0, n_all = 0, off_oth = 0, n_oth = 0, off_123 = 0, n_123 = 0;
     } plan;
     std::vector<uint64_t> work_cache; // launch-plan weight of every critical node (its size; empty: not computed)
     // Scratch of the supergroup pre-pass (allocated on first use).
@@ -350,6 +353,12 @@ void launch_traversal(const rk_state &s, int q, const kparams<F> &p, const int64
 template <typename F>
 void launch_list(const rk_state &s, int q, const kparams<F> &p, const int64_t cls_begin[n_classes],
                  const int64_t cls_end[n_classes], hipStream_t const streams[n_list_R], unsigned class_mask = ~0u);
+// One launch over critical nodes of any lane-mapping class (small calls): the list kernel, the producer / consumer kernel.
+template <typename F>
+void launch_list_any(const rk_state &s, int q, const kparams<F> &p, const uint32_t *list, int64_t n, hipStream_t stream,
+                     int rmax = 4);
+template <typename F>
+void launch_pc_any(const rk_state &s, int q, const kparams<F> &p, const uint32_t *list, int64_t n, hipStream_t stream);
 // n_dev (optional): the number of list entries lives in device memory (at most n).
 template <typename F>
 void launch_list_big(const rk_state &s, int q, const kparams<F> &p, const uint32_t *list, int64_t n, hipStream_t stream,

@@ -24,38 +24,17 @@
 namespace rk
 {
 
-template <typename F, int Q, int MAC, int R, int ND, bool BIG = false>
-__global__ void __launch_bounds__(64 * (BIG ? LK_BIG_WPB : RK_WPB), BIG ? (sizeof(F) == 4 ? RK_WBIG : RK_W64) : (sizeof(F) == 4 ? (R <= 2 ? RK_W12 : (R == 3 ? RK_W3 : (R == 4 ? RK_W4 : (R == 5 ? RK_W5 : RK_W6)))) : RK_W64)) k_list(const kparams<F> P, const uint32_t *__restrict__ list, int n_list, const uint32_t *__restrict__ n_list_dev = nullptr)
+// Everything one wavefront does for critical node g (BIG: for the chunks wib, wib + LK_BIG_WPB, ... of its targets). Shared
+// by the per-class kernels k_list<..., R> and by k_list_any, which picks R per node at run time: the same code, hence the
+// same bits, whichever kernel runs it.
+template <typename F, int Q, int MAC, int R, int ND, bool BIG>
+__device__ __forceinline__ void list_node(const kparams<F> &P, lk_wave_lds<F> &L, const uint32_t g, const int lane, const int wib)
 {
     using v4 = typename vt<F>::v4;
     using v2 = typename vt<F>::v2;
     constexpr int NR = nres_of(Q);
     constexpr int SRC_CAP = lk_cfg<F>::src_cap;
     static_assert(sizeof(lk_wave_lds<F>) >= 64 * 4 * sizeof(F), "reduction scratch does not fit");
-    __shared__ lk_wave_lds<F> s_lds[BIG ? LK_BIG_WPB : RK_WPB];
-
-    const int wib = threadIdx.x >> 6;
-    const int lane = threadIdx.x & 63;
-    // BIG: one workgroup per critical node too large for one wavefront (more than 64 * RK_MAX_R particles: ncrit or
-    // max_leaf_n above 256, or a tree that ran out of levels). Its targets are cut into chunks of at most
-    // LK_BIG_CHUNK, every wavefront of the workgroup serves chunks wib, wib + LK_BIG_WPB, ... exactly like a group of
-    // its own -- except that every MAC decision is taken for ALL particles of the critical node (bounding box, probes
-    // and the exact test range over the node, not the chunk), so the interaction set is the reference's.
-    const unsigned blk = BIG ? blockIdx.x : xcd_map_block(blockIdx.x, gridDim.x, P.xcd_mode);
-    const int wave = __builtin_amdgcn_readfirstlane(BIG ? static_cast<int>(blk) : static_cast<int>(blk * unsigned(RK_WPB)) + wib);
-    if (BIG && n_list_dev) {
-        // The fallback list of the split traversal: its length is only known on the device.
-        n_list = static_cast<int>(__builtin_amdgcn_readfirstlane(*n_list_dev));
-    }
-    if (wave >= n_list) {
-        return;
-    }
-    lk_wave_lds<F> &L = s_lds[wib];
-
-    const uint32_t g = __builtin_amdgcn_readfirstlane(list[wave]);
-    if (g == RK_PLAN_PAD_VALUE) {
-        return; // padding of a launch plan
-    }
     const uint4 c = P.crit[g];
     const uint32_t gb = c.x, ge = c.y, cnode = c.z;
     const int TG = static_cast<int>(ge - gb);
@@ -583,6 +562,65 @@ __global__ void __launch_bounds__(64 * (BIG ? LK_BIG_WPB : RK_WPB), BIG ? (sizeo
     }
 }
 
+template <typename F, int Q, int MAC, int R, int ND, bool BIG = false>
+__global__ void __launch_bounds__(64 * (BIG ? LK_BIG_WPB : RK_WPB), BIG ? (sizeof(F) == 4 ? RK_WBIG : RK_W64) : (sizeof(F) == 4 ? (R <= 2 ? RK_W12 : (R == 3 ? RK_W3 : (R == 4 ? RK_W4 : (R == 5 ? RK_W5 : RK_W6)))) : RK_W64)) k_list(const kparams<F> P, const uint32_t *__restrict__ list, int n_list, const uint32_t *__restrict__ n_list_dev = nullptr)
+{
+    __shared__ lk_wave_lds<F> s_lds[BIG ? LK_BIG_WPB : RK_WPB];
+
+    const int wib = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    // BIG: one workgroup per critical node too large for one wavefront (more than 64 * RK_MAX_R particles: ncrit or
+    // max_leaf_n above 256, or a tree that ran out of levels). Its targets are cut into chunks of at most
+    // LK_BIG_CHUNK, every wavefront of the workgroup serves chunks wib, wib + LK_BIG_WPB, ... exactly like a group of
+    // its own -- except that every MAC decision is taken for ALL particles of the critical node (bounding box, probes
+    // and the exact test range over the node, not the chunk), so the interaction set is the reference's.
+    const unsigned blk = BIG ? blockIdx.x : xcd_map_block(blockIdx.x, gridDim.x, P.xcd_mode);
+    const int wave = __builtin_amdgcn_readfirstlane(BIG ? static_cast<int>(blk) : static_cast<int>(blk * unsigned(RK_WPB)) + wib);
+    if (BIG && n_list_dev) {
+        // The fallback list of the split traversal: its length is only known on the device.
+        n_list = static_cast<int>(__builtin_amdgcn_readfirstlane(*n_list_dev));
+    }
+    if (wave >= n_list) {
+        return;
+    }
+    const uint32_t g = __builtin_amdgcn_readfirstlane(list[wave]);
+    if (g == RK_PLAN_PAD_VALUE) {
+        return; // padding of a launch plan
+    }
+    list_node<F, Q, MAC, R, ND, BIG>(P, s_lds[wib], g, lane, wib);
+}
+
+// One launch for the critical nodes of ALL lane-mapping classes (calls over few critical nodes, whose four class kernels
+// would otherwise start 25-45 us apart and leave the device to drain over the class launched last): every wavefront
+// picks the R of its node and runs the same list_node<..., R> the class kernels run. Compiled for the registers of the
+// largest R; the launch is too small to fill the device anyway.
+template <typename F, int Q, int MAC, int ND, int RMAX = 4>
+__global__ void __launch_bounds__(64, sizeof(F) == 4 ? (RMAX >= 4 ? RK_W4 : RK_W3) : RK_W64) k_list_any(const kparams<F> P, const uint32_t *__restrict__ list, int n_list)
+{
+    __shared__ lk_wave_lds<F> s_lds;
+    const int lane = threadIdx.x;
+    const unsigned blk = xcd_map_block(blockIdx.x, gridDim.x, P.xcd_mode);
+    if (static_cast<int>(blk) >= n_list) {
+        return;
+    }
+    const uint32_t g = __builtin_amdgcn_readfirstlane(list[blk]);
+    if (g == RK_PLAN_PAD_VALUE) {
+        return;
+    }
+    static_assert(RK_MAX_R == 4, "k_list_any dispatches R = 1..4");
+    switch (class2_of_compute(static_cast<int64_t>(__builtin_amdgcn_readfirstlane(P.crit[g].w)))) {
+        case 0: list_node<F, Q, MAC, 1, ND, false>(P, s_lds, g, lane, 0); break;
+        case 1: list_node<F, Q, MAC, 2, ND, false>(P, s_lds, g, lane, 0); break;
+        case 2: list_node<F, Q, MAC, 3, ND, false>(P, s_lds, g, lane, 0); break;
+        case 3:
+            if constexpr (RMAX >= 4) {
+                list_node<F, Q, MAC, 4, ND, false>(P, s_lds, g, lane, 0);
+            }
+            break;
+        default: break; // oversized nodes are not on this list
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Supergroup pre-pass. K consecutive target groups (a "supergroup" S) visit almost the same upper part of the
 // tree. One wavefront per S walks it once with tests that are valid for EVERY member group:
@@ -773,6 +811,46 @@ void launch_list(const rk_state &s, int q, const kparams<F> &p, const int64_t cb
     }
     RK_HIP(hipGetLastError());
 }
+
+// One launch over a list of critical nodes of any lane-mapping class (k_list_any).
+template <typename F>
+void launch_list_any(const rk_state &s, int q, const kparams<F> &p, const uint32_t *list, int64_t n, hipStream_t stream, int rmax)
+{
+    if (n <= 0) {
+        return;
+    }
+    const dim3 grid(static_cast<unsigned>(n)), block(64);
+    const int cnt = static_cast<int>(n);
+    auto go = [&](auto Qt, auto Mt) {
+        constexpr int Q = decltype(Qt)::value, M = decltype(Mt)::value;
+        if (s.ndim == 3 || !RK_QUAD_BODY) {
+            if (rmax >= 4) {
+                hipLaunchKernelGGL((k_list_any<F, Q, M, 3, 4>), grid, block, 0, stream, p, list, cnt);
+            } else {
+                hipLaunchKernelGGL((k_list_any<F, Q, M, 3, 3>), grid, block, 0, stream, p, list, cnt);
+            }
+        } else if (rmax >= 4) {
+            hipLaunchKernelGGL((k_list_any<F, Q, M, 2, 4>), grid, block, 0, stream, p, list, cnt);
+        } else {
+            hipLaunchKernelGGL((k_list_any<F, Q, M, 2, 3>), grid, block, 0, stream, p, list, cnt);
+        }
+    };
+    using i0 = std::integral_constant<int, 0>;
+    using i1 = std::integral_constant<int, 1>;
+    using i2 = std::integral_constant<int, 2>;
+    switch (q * 2 + s.mac) {
+        case 0: go(i0{}, i0{}); break;
+        case 1: go(i0{}, i1{}); break;
+        case 2: go(i1{}, i0{}); break;
+        case 3: go(i1{}, i1{}); break;
+        case 4: go(i2{}, i0{}); break;
+        case 5: go(i2{}, i1{}); break;
+        default: throw error(RK_EINVAL, "invalid q / mac combination");
+    }
+    RK_HIP(hipGetLastError());
+}
+template void launch_list_any<float>(const rk_state &, int, const kparams<float> &, const uint32_t *, int64_t, hipStream_t, int);
+template void launch_list_any<double>(const rk_state &, int, const kparams<double> &, const uint32_t *, int64_t, hipStream_t, int);
 
 // Critical nodes of more than 64 * RK_MAX_R particles: k_list<..., BIG> (one workgroup per node).
 template <typename F>

@@ -43,9 +43,11 @@ struct pc_lds {
     typename vt<F>::v4 tile[2][lk_cfg<F>::src_cap];
 };
 
+// Everything the workgroup (1 + R wavefronts; `role` 0 = producer, 1 + c = consumer c) does for critical node g. Shared by
+// the per-class kernels k_pc<..., R> and by k_pc_any, which picks R per node at run time (its surplus wavefronts leave at
+// once): the same code, hence the same bits, whichever kernel runs it.
 template <typename F, int Q, int MAC, int R, int ND>
-__global__ void __launch_bounds__(64 * (1 + R), (sizeof(F) == 4 ? RK_PC_W : RK_PC_W64))
-    k_pc(const kparams<F> P, const uint32_t *__restrict__ list, int n_list)
+__device__ __forceinline__ void pc_node(const kparams<F> &P, pc_lds<F> &L, const uint32_t g, const int role, const int lane)
 {
     using v4 = typename vt<F>::v4;
     using v2 = typename vt<F>::v2;
@@ -55,18 +57,6 @@ __global__ void __launch_bounds__(64 * (1 + R), (sizeof(F) == 4 ? RK_PC_W : RK_P
     static_assert(R >= 1 && R <= 4);
     // The consumers' split-reduction scratch (64 * NR values each) lives in the two tiles.
     static_assert(2 * lk_cfg<F>::src_cap * 4 * sizeof(F) >= size_t(R) * 64 * 4 * sizeof(F), "reduction scratch does not fit");
-    __shared__ pc_lds<F> L;
-
-    const int role = threadIdx.x >> 6; // 0 = producer, 1 + c = consumer c
-    const int lane = threadIdx.x & 63;
-    const unsigned blk = xcd_map_block(blockIdx.x, gridDim.x, P.xcd_mode);
-    if (static_cast<int>(blk) >= n_list) {
-        return;
-    }
-    const uint32_t g = __builtin_amdgcn_readfirstlane(list[blk]);
-    if (g == RK_PLAN_PAD_VALUE) {
-        return; // padding of a launch plan
-    }
     const uint4 c = P.crit[g];
     const uint32_t tb = c.x, te = c.y, cnode = c.z;
     const int T = static_cast<int>(te - tb);
@@ -553,6 +543,54 @@ __global__ void __launch_bounds__(64 * (1 + R), (sizeof(F) == 4 ? RK_PC_W : RK_P
     publish(true);
 }
 
+template <typename F, int Q, int MAC, int R, int ND>
+__global__ void __launch_bounds__(64 * (1 + R), (sizeof(F) == 4 ? RK_PC_W : RK_PC_W64))
+    k_pc(const kparams<F> P, const uint32_t *__restrict__ list, int n_list)
+{
+    __shared__ pc_lds<F> L;
+    const int role = threadIdx.x >> 6; // 0 = producer, 1 + c = consumer c
+    const int lane = threadIdx.x & 63;
+    const unsigned blk = xcd_map_block(blockIdx.x, gridDim.x, P.xcd_mode);
+    if (static_cast<int>(blk) >= n_list) {
+        return;
+    }
+    const uint32_t g = __builtin_amdgcn_readfirstlane(list[blk]);
+    if (g == RK_PLAN_PAD_VALUE) {
+        return; // padding of a launch plan
+    }
+    pc_node<F, Q, MAC, R, ND>(P, L, g, role, lane);
+}
+
+// One launch for the critical nodes of ALL lane-mapping classes (calls over very few critical nodes): workgroups of five
+// wavefronts, of which a node of class R uses 1 + R; the others return before the first barrier (a barrier waits only for
+// the wavefronts of the workgroup that are still alive).
+template <typename F, int Q, int MAC, int ND>
+__global__ void __launch_bounds__(64 * 5, (sizeof(F) == 4 ? RK_PC_W : RK_PC_W64))
+    k_pc_any(const kparams<F> P, const uint32_t *__restrict__ list, int n_list)
+{
+    __shared__ pc_lds<F> L;
+    const int role = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const unsigned blk = xcd_map_block(blockIdx.x, gridDim.x, P.xcd_mode);
+    if (static_cast<int>(blk) >= n_list) {
+        return;
+    }
+    const uint32_t g = __builtin_amdgcn_readfirstlane(list[blk]);
+    if (g == RK_PLAN_PAD_VALUE) {
+        return;
+    }
+    const int cls = class2_of_compute(static_cast<int64_t>(__builtin_amdgcn_readfirstlane(P.crit[g].w)));
+    if (cls < 0 || cls >= RK_MAX_R || role > cls + 1) {
+        return;
+    }
+    switch (cls) {
+        case 0: pc_node<F, Q, MAC, 1, ND>(P, L, g, role, lane); break;
+        case 1: pc_node<F, Q, MAC, 2, ND>(P, L, g, role, lane); break;
+        case 2: pc_node<F, Q, MAC, 3, ND>(P, L, g, role, lane); break;
+        default: pc_node<F, Q, MAC, 4, ND>(P, L, g, role, lane); break;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Launch.
 // ------------------------------------------------------------------------------------------------
@@ -583,6 +621,39 @@ static void launch_pc_qm(const rk_state &s, const kparams<F> &p, const int64_t c
     go(std::integral_constant<int, 3>{}, 2);
     go(std::integral_constant<int, 1>{}, 0);
 }
+
+template <typename F>
+void launch_pc_any(const rk_state &s, int q, const kparams<F> &p, const uint32_t *list, int64_t n, hipStream_t stream)
+{
+    if (n <= 0) {
+        return;
+    }
+    const dim3 grid(static_cast<unsigned>(n)), block(64 * 5);
+    const int cnt = static_cast<int>(n);
+    auto go = [&](auto Qt, auto Mt) {
+        constexpr int Q = decltype(Qt)::value, M = decltype(Mt)::value;
+        if (s.ndim == 3 || !RK_QUAD_BODY) {
+            hipLaunchKernelGGL((k_pc_any<F, Q, M, 3>), grid, block, 0, stream, p, list, cnt);
+        } else {
+            hipLaunchKernelGGL((k_pc_any<F, Q, M, 2>), grid, block, 0, stream, p, list, cnt);
+        }
+    };
+    using i0 = std::integral_constant<int, 0>;
+    using i1 = std::integral_constant<int, 1>;
+    using i2 = std::integral_constant<int, 2>;
+    switch (q * 2 + s.mac) {
+        case 0: go(i0{}, i0{}); break;
+        case 1: go(i0{}, i1{}); break;
+        case 2: go(i1{}, i0{}); break;
+        case 3: go(i1{}, i1{}); break;
+        case 4: go(i2{}, i0{}); break;
+        case 5: go(i2{}, i1{}); break;
+        default: throw error(RK_EINVAL, "invalid q / mac combination");
+    }
+    RK_HIP(hipGetLastError());
+}
+template void launch_pc_any<float>(const rk_state &, int, const kparams<float> &, const uint32_t *, int64_t, hipStream_t);
+template void launch_pc_any<double>(const rk_state &, int, const kparams<double> &, const uint32_t *, int64_t, hipStream_t);
 
 template <typename F>
 void launch_pc(const rk_state &s, int q, const kparams<F> &p, const int64_t cb[n_classes], const int64_t ce[n_classes],

@@ -773,6 +773,24 @@ void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64
         }
     }
     s.plan.off[rk::n_classes] = static_cast<int64_t>(lists.size());
+    s.plan.off_all = s.plan.n_all = s.plan.off_oth = s.plan.n_oth = s.plan.off_123 = s.plan.n_123 = 0;
+    if (lpt) {
+        // Merged heavy-first lists over the wave-kernel classes (stable: equal weights keep class, then Morton order): all
+        // of them, all but R = 2, all but R = 4.
+        for (int pass = 0; pass < 3; ++pass) {
+            const auto first = static_cast<std::ptrdiff_t>(lists.size());
+            for (int c = 0; c < RK_MAX_R; ++c) {
+                if ((pass == 1 && c == 1) || (pass == 2 && c == 3)) {
+                    continue;
+                }
+                lists.insert(lists.end(), lists.begin() + s.plan.off[c], lists.begin() + s.plan.off[c + 1]);
+            }
+            std::stable_sort(lists.begin() + first, lists.end(),
+                             [&](uint32_t a, uint32_t b2) { return s.work_cache[a] > s.work_cache[b2]; });
+            (pass == 0 ? s.plan.off_all : (pass == 1 ? s.plan.off_oth : s.plan.off_123)) = first;
+            (pass == 0 ? s.plan.n_all : (pass == 1 ? s.plan.n_oth : s.plan.n_123)) = static_cast<int64_t>(lists.size()) - first;
+        }
+    }
     if (s.plan.alloc < static_cast<int64_t>(lists.size())) {
         RK_HIP(hipDeviceSynchronize());
         rk::pool_free(s.plan.d_lists);
@@ -1133,7 +1151,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
             }();
             static const int64_t plan_max_groups = [] {
                 const char *e = std::getenv("RK_PLAN_MAX_GROUPS");
-                return e ? std::atoll(e) : int64_t(30000);
+                return e ? std::atoll(e) : int64_t(60000);
             }();
             const bool cached = s.plan.d_lists && s.plan.p_begin == p_begin && s.plan.p_end == p_end
                                 && s.plan.mac_value == mac_value;
@@ -1204,12 +1222,6 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
             for (int i = 0; i < rk::n_list_R; ++i) {
                 streams[i] = (serial || i == 0) ? st : s.aux_stream[i - 1];
             }
-            if (!serial) {
-                RK_HIP(hipEventRecord(s.ev_fork, st));
-                for (int i = 0; i < rk::n_list_R - 1; ++i) {
-                    RK_HIP(hipStreamWaitEvent(s.aux_stream[i], s.ev_fork, 0));
-                }
-            }
             // Variant 0 (automatic): a call over few critical nodes cannot fill the device with one wave per node, and
             // ends with its longest serial chains running alone. Such calls hand lane-mapping classes to the producer /
             // consumer kernel (1 + R waves per node): all of them below 5 000 critical nodes, the class with the longest
@@ -1241,6 +1253,36 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                 const char *e = std::getenv("RK_CLASS_ORDER");
                 return std::string(e ? e : "");
             }();
+            // 0: per-class launches; 1: k_pc_any; 2: k_pc for R = 2 + k_list_any for the rest; 3: k_list_any (heavy-first plans
+            // only, i.e. repeated calls over at most RK_PLAN_MAX_GROUPS critical nodes; RK_ANY=0 keeps the class launches).
+            static const int any_env = [] {
+                const char *e = std::getenv("RK_ANY");
+                return e ? std::atoi(e) : -1;
+            }();
+            int any_mode = 0;
+            if (!split && s.variant == 0 && any_env != 0 && s.cur_lists == static_cast<const uint32_t *>(s.plan.d_lists)
+                && s.plan.n_all > 0 && s.plan.n_all == g_hi - g_lo - (big_e - big_b)) {
+                // Measured (tools/any_probe.py, profiles/r03/one_launch_kernels.txt): k_pc_any at 2.9k nodes 0.134 ms (class
+                // launches 0.140, k_list_any 0.173); k_list_any at 9.4k nodes 0.23 (0.29-0.30; with R = 2 on k_pc 0.27), on the
+                // 13.4k-node shards of the 4M tree 0.373-0.379 (0.406-0.412; 0.40), at 26k nodes 0.62 (0.66).
+                // 4.2k nodes: class launches on the producer / consumer kernel 0.173, k_pc_any 0.196 (its five-wave workgroups
+                // are admitted four per CU), k_list_any 0.193; 5.6k nodes: k_list_any 0.205 (class launches 0.25), 6.5k: 0.215
+                // (0.27); 54k nodes (2M particles): 1.19 (1.22).
+                static const int64_t pc_any_below = [] {
+                    const char *e = std::getenv("RK_PC_ANY_BELOW");
+                    return e ? std::atoll(e) : int64_t(3200);
+                }();
+                any_mode = any_env > 0 ? any_env : (g_hi - g_lo <= pc_any_below ? 1 : (pc_mask == 0xfu ? 0 : 3));
+            }
+            // The class kernels run on side streams, forked from and joined back to the call's stream (a single launch
+            // needs neither).
+            const bool forked = !serial && any_mode != 1 && any_mode != 3;
+            if (forked) {
+                RK_HIP(hipEventRecord(s.ev_fork, st));
+                for (int i = 0; i < rk::n_list_R - 1; ++i) {
+                    RK_HIP(hipStreamWaitEvent(s.aux_stream[i], s.ev_fork, 0));
+                }
+            }
             if (split) {
                 if (p.sl_parts_mode) {
                     // One wavefront per part, then the per-node sums (same stream per class: ordered).
@@ -1248,6 +1290,23 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                     rk::launch_dense<F>(s, q, p, cb, ce, streams, 0xfu, 2);
                 } else {
                     rk::launch_dense<F>(s, q, p, cb, ce, streams, 0xfu, 0);
+                }
+            } else if (any_mode != 0) {
+                // A small repeated call: one launch over the heavy-first list of ALL classes (or two: the R = 2 class on its
+                // producer / consumer kernel, everything else on k_list_any) instead of four that start 25-45 us apart.
+                const auto *pl = static_cast<const uint32_t *>(s.plan.d_lists);
+                if (any_mode == 1) {
+                    rk::launch_pc_any<F>(s, q, p, pl + s.plan.off_all, s.plan.n_all, streams[0]);
+                } else if (any_mode == 2) {
+                    rk::launch_pc<F>(s, q, p, cb, ce, streams, 0x2u);
+                    rk::launch_list_any<F>(s, q, p, pl + s.plan.off_oth, s.plan.n_oth, streams[0]);
+                } else if (any_mode == 4) {
+                    // The R = 4 class on its own kernel (first: its nodes are the longest), the rest on a k_list_any compiled for
+                    // the registers of R = 3.
+                    rk::launch_list<F>(s, q, p, cb, ce, streams, 0x8u);
+                    rk::launch_list_any<F>(s, q, p, pl + s.plan.off_123, s.plan.n_123, streams[0], 3);
+                } else {
+                    rk::launch_list_any<F>(s, q, p, pl + s.plan.off_all, s.plan.n_all, streams[0]);
                 }
             } else if (!class_order.empty()) {
                 unsigned done_mask = 0u;
@@ -1275,7 +1334,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                     rk::launch_list<F>(s, q, p, cb, ce, streams, ~pc_mask);
                 }
             }
-            if (!serial) {
+            if (forked) {
                 for (int i = 0; i < rk::n_list_R - 1; ++i) {
                     RK_HIP(hipEventRecord(s.ev_join[i], s.aux_stream[i]));
                     RK_HIP(hipStreamWaitEvent(st, s.ev_join[i], 0));

@@ -53,9 +53,10 @@ def test_call_sequences_with_history_equal_fresh_calls(n):
 
 
 def test_light_tail_plan_equals_plain_order(tmp_path):
-    """The launch plan of calls above RK_PLAN_MAX_GROUPS critical nodes (Morton order per XCD region, light nodes last,
-    padded queues) only permutes the dispatch: with the limit lowered so that a 60k-particle tree takes that path, full
-    range, sub-ranges, Q = 0 / 2, ordered outputs and both list kernels give the bits of RK_PLAN=0."""
+    """The launch plans only permute the dispatch, and the one-launch kernels of small repeated calls (k_pc_any, k_list_any)
+    run the code of the class kernels: the light-tail plan (limit lowered so that a 60k-particle tree takes that path), the
+    heavy-first plan with every form of launch, full range, sub-ranges, Q = 0 / 2, ordered outputs, all kernel variants
+    give the bits of RK_PLAN=0."""
     import os
     import subprocess
     import sys
@@ -85,8 +86,13 @@ for variant in (0, 2, 3, 4):
 np.savez(sys.argv[1], **res)
 """
     files = []
+    # plain: no plan; tail / tail_chunks: the light-tail plan; the rest: the heavy-first plan of small calls with its
+    # one-launch kernels (k_pc_any below 3200 critical nodes, k_list_any above; forced both ways, and the mixed forms).
     for name, extra in (("plain", {"RK_PLAN": "0"}), ("tail", {"RK_PLAN_MAX_GROUPS": "64"}),
-                        ("tail_chunks", {"RK_PLAN_MAX_GROUPS": "64", "RK_PLAN_REGIONS": "0"})):
+                        ("tail_chunks", {"RK_PLAN_MAX_GROUPS": "64", "RK_PLAN_REGIONS": "0"}),
+                        ("heavy_first_auto", {}), ("pc_any", {"RK_ANY": "1"}), ("list_any", {"RK_ANY": "3"}),
+                        ("pc_r2_list_any", {"RK_ANY": "2"}), ("list_r4_list_any", {"RK_ANY": "4"}),
+                        ("class_launches", {"RK_ANY": "0"})):
         env = dict(os.environ, **extra)
         env["PYTHONPATH"] = os.pathsep.join([root, os.path.join(root, "tests"), env.get("PYTHONPATH", "")])
         f = str(tmp_path / (name + ".npz"))
@@ -96,5 +102,5 @@ np.savez(sys.argv[1], **res)
     assert len(files[0].files) == 48
     for k in files[0].files:
         assert np.isfinite(files[0][k]).all()
-        assert np.array_equal(files[0][k], files[1][k]), k
-        assert np.array_equal(files[0][k], files[2][k]), k
+        for other in files[1:]:
+            assert np.array_equal(files[0][k], other[k]), k
