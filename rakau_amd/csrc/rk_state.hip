@@ -695,20 +695,10 @@ void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64
     std::vector<uint32_t> lists;
     lists.reserve(static_cast<size_t>(g_hi - g_lo));
     std::vector<uint32_t> region_bound; // light-tail plans: first node of each of the 8 per-XCD regions (+ g_hi)
-    for (int c = 0; c < rk::n_classes; ++c) {
-        s.plan.off[c] = static_cast<int64_t>(lists.size());
-        if (c == rk::big_class) {
-            continue; // served by the block-per-group kernel from the state's own list
-        }
-        const auto &l = s.class2_list[c];
-        const auto b = std::lower_bound(l.begin(), l.end(), static_cast<uint32_t>(g_lo));
-        const auto e = std::lower_bound(l.begin(), l.end(), static_cast<uint32_t>(g_hi));
-        const auto first = static_cast<std::ptrdiff_t>(lists.size());
-        lists.insert(lists.end(), b, e);
-        if (lpt) {
-            std::stable_sort(lists.begin() + first, lists.end(),
-                             [&](uint32_t a, uint32_t b2) { return s.work_cache[a] > s.work_cache[b2]; });
-        } else if (lists.size() - static_cast<size_t>(first) > 1u) {
+    // Light-tail arrangement of lists[first ..): Morton order, the lightest quarter of the nodes moved to the end (in Morton
+    // order among themselves), one spatial region per XCD.
+    auto arrange_light_tail = [&](const std::ptrdiff_t first) {
+
             // Morton order, the lightest quarter of the nodes moved to the end (in Morton order among themselves).
             static const double tail_frac = [] {
                 const char *e = std::getenv("RK_PLAN_TAIL"); // fraction of the nodes dispatched last (0 = none)
@@ -770,10 +760,52 @@ void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64
             } else {
                 std::stable_partition(lists.begin() + first, lists.end(), [&](uint32_t a) { return s.work_cache[a] >= thr; });
             }
+            };
+    for (int c = 0; c < rk::n_classes; ++c) {
+        s.plan.off[c] = static_cast<int64_t>(lists.size());
+        if (c == rk::big_class) {
+            continue; // served by the block-per-group kernel from the state's own list
+        }
+        const auto &l = s.class2_list[c];
+        const auto b = std::lower_bound(l.begin(), l.end(), static_cast<uint32_t>(g_lo));
+        const auto e = std::lower_bound(l.begin(), l.end(), static_cast<uint32_t>(g_hi));
+        const auto first = static_cast<std::ptrdiff_t>(lists.size());
+        lists.insert(lists.end(), b, e);
+        if (lpt) {
+            std::stable_sort(lists.begin() + first, lists.end(),
+                             [&](uint32_t a, uint32_t b2) { return s.work_cache[a] > s.work_cache[b2]; });
+        } else if (lists.size() - static_cast<size_t>(first) > 1u) {
+            arrange_light_tail(first);
         }
     }
     s.plan.off[rk::n_classes] = static_cast<int64_t>(lists.size());
     s.plan.off_all = s.plan.n_all = s.plan.off_oth = s.plan.n_oth = s.plan.off_123 = s.plan.n_123 = 0;
+    s.plan.all_padded = !lpt;
+    if (!lpt) {
+        // One list of all wave-kernel classes in the light-tail arrangement (experiment: RK_ANY_TAIL=1 runs k_list_any on it.
+        // Measured: 4M 2.288 instead of 2.238 ms, 2M equal -- on a full device the occupancy the single kernel gives up
+        // (5 waves per SIMD for every class) costs more than the staggered starts of four class kernels; off by default).
+        static const bool any_tail = [] {
+            const char *e = std::getenv("RK_ANY_TAIL");
+            return e && std::atoi(e) != 0;
+        }();
+        if (any_tail) {
+            std::vector<uint32_t> merged;
+            for (int c = 0; c < RK_MAX_R; ++c) {
+                const auto &l = s.class2_list[c];
+                merged.insert(merged.end(), std::lower_bound(l.begin(), l.end(), static_cast<uint32_t>(g_lo)),
+                              std::lower_bound(l.begin(), l.end(), static_cast<uint32_t>(g_hi)));
+            }
+            std::sort(merged.begin(), merged.end());
+            const auto first = static_cast<std::ptrdiff_t>(lists.size());
+            lists.insert(lists.end(), merged.begin(), merged.end());
+            if (merged.size() > 1u) {
+                arrange_light_tail(first);
+            }
+            s.plan.off_all = first;
+            s.plan.n_all = static_cast<int64_t>(lists.size()) - first;
+        }
+    }
     if (lpt) {
         // Merged heavy-first lists over the wave-kernel classes (stable: equal weights keep class, then Morton order): all
         // of them, all but R = 2, all but R = 4.
@@ -1151,7 +1183,9 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
             }();
             static const int64_t plan_max_groups = [] {
                 const char *e = std::getenv("RK_PLAN_MAX_GROUPS");
-                return e ? std::atoll(e) : int64_t(60000);
+                // (60000 measured too: 2M particles = 54k nodes 1.19 instead of 1.22 ms, but the two 54k-node shards of the 4M
+                // tree 1.34-1.37 instead of 1.25-1.28: the heavy-first order gives up the L2 locality of neighbouring nodes.)
+                return e ? std::atoll(e) : int64_t(30000);
             }();
             const bool cached = s.plan.d_lists && s.plan.p_begin == p_begin && s.plan.p_end == p_end
                                 && s.plan.mac_value == mac_value;
@@ -1261,7 +1295,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
             }();
             int any_mode = 0;
             if (!split && s.variant == 0 && any_env != 0 && s.cur_lists == static_cast<const uint32_t *>(s.plan.d_lists)
-                && s.plan.n_all > 0 && s.plan.n_all == g_hi - g_lo - (big_e - big_b)) {
+                && s.plan.n_all > 0 && (s.plan.all_padded || s.plan.n_all == g_hi - g_lo - (big_e - big_b))) {
                 // Measured (tools/any_probe.py, profiles/r03/one_launch_kernels.txt): k_pc_any at 2.9k nodes 0.134 ms (class
                 // launches 0.140, k_list_any 0.173); k_list_any at 9.4k nodes 0.23 (0.29-0.30; with R = 2 on k_pc 0.27), on the
                 // 13.4k-node shards of the 4M tree 0.373-0.379 (0.406-0.412; 0.40), at 26k nodes 0.62 (0.66).
@@ -1273,6 +1307,9 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                     return e ? std::atoll(e) : int64_t(3200);
                 }();
                 any_mode = any_env > 0 ? any_env : (g_hi - g_lo <= pc_any_below ? 1 : (pc_mask == 0xfu ? 0 : 3));
+                if (s.plan.all_padded) {
+                    any_mode = 3; // the merged light-tail list (RK_ANY_TAIL=1)
+                }
             }
             // The class kernels run on side streams, forked from and joined back to the call's stream (a single launch
             // needs neither).
