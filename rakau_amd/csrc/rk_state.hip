@@ -815,7 +815,9 @@ void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64
                 if ((pass == 1 && c == 1) || (pass == 2 && c == 3)) {
                     continue;
                 }
-                lists.insert(lists.end(), lists.begin() + s.plan.off[c], lists.begin() + s.plan.off[c + 1]);
+                // (copied first: inserting a range of a vector into itself is undefined once it reallocates)
+                const std::vector<uint32_t> part(lists.begin() + s.plan.off[c], lists.begin() + s.plan.off[c + 1]);
+                lists.insert(lists.end(), part.begin(), part.end());
             }
             std::stable_sort(lists.begin() + first, lists.end(),
                              [&](uint32_t a, uint32_t b2) { return s.work_cache[a] > s.work_cache[b2]; });
