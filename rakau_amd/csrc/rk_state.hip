@@ -2,6 +2,12 @@
 #include "rk_common.hpp"
 
 #include <dlfcn.h>
+#include <functional>
+#include <deque>
+#include <condition_variable>
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
@@ -19,6 +25,29 @@ namespace
 {
 
 thread_local std::string g_err;
+
+// RK_BACKTRACE=1: print the native call stack (module + offset; resolve with addr2line against the same build) when the
+// process dies of SIGSEGV / SIGABRT / SIGBUS, then die the same way. A debugging aid for crashes that only show up in long runs.
+void crash_handler(int sig)
+{
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    const char msg[] = "rakau_amd: fatal signal, native stack:\n";
+    (void)!write(2, msg, sizeof(msg) - 1);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+const bool g_crash_handler_installed = [] {
+    const char *e = std::getenv("RK_BACKTRACE");
+    if (e && std::atoi(e) != 0) {
+        for (int sig : {SIGSEGV, SIGABRT, SIGBUS}) {
+            signal(sig, crash_handler);
+        }
+        return true;
+    }
+    return false;
+}();
 
 // -1: not set (the environment variable RK_BUILD_EXACT decides, default off).
 std::atomic<int> g_build_exact{-1};
@@ -1765,6 +1794,136 @@ void *device_view_of_host_range(void *p, size_t bytes)
     return a0.devicePointer;
 }
 
+// memcpy with non-temporal stores for the 16-byte aligned body of the destination (movntdq on the host): the delivery of a
+// staged result overwrites whole cache lines that nobody reads soon.
+inline void stream_copy(unsigned char *d, const unsigned char *src, size_t n)
+{
+    typedef long long v2di __attribute__((vector_size(16)));
+    typedef long long v2di_u __attribute__((vector_size(16), aligned(1)));
+    if (n < 256) {
+        std::memcpy(d, src, n);
+        return;
+    }
+    const size_t head = (16 - (reinterpret_cast<uintptr_t>(d) & 15)) & 15;
+    std::memcpy(d, src, head);
+    d += head;
+    src += head;
+    n -= head;
+    const size_t body = n & ~size_t(63);
+    for (size_t i = 0; i < body; i += 64) {
+        const v2di a = *reinterpret_cast<const v2di_u *>(src + i), b = *reinterpret_cast<const v2di_u *>(src + i + 16),
+                   c = *reinterpret_cast<const v2di_u *>(src + i + 32), e = *reinterpret_cast<const v2di_u *>(src + i + 48);
+        __builtin_nontemporal_store(a, reinterpret_cast<v2di *>(d + i));
+        __builtin_nontemporal_store(b, reinterpret_cast<v2di *>(d + i + 16));
+        __builtin_nontemporal_store(c, reinterpret_cast<v2di *>(d + i + 32));
+        __builtin_nontemporal_store(e, reinterpret_cast<v2di *>(d + i + 48));
+    }
+    std::memcpy(d + body, src + body, n - body);
+}
+
+// The host threads that deliver staged results: created once (a thread costs ~20 us to start and to join, seven of them
+// per call were 5% of a 4M-particle call), parked on a condition variable between calls. Several callers (the device
+// threads of a multi-device split) may post jobs at the same time; every caller also works on its own job.
+class delivery_pool
+{
+    struct job {
+        const std::function<void(int)> *fn;
+        int n_items, max_helpers;
+        std::atomic<int> next{0}, done{0}, helpers{0};
+    };
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::vector<std::thread> thr_;
+    std::deque<std::shared_ptr<job>> jobs_;
+    bool stop_ = false;
+
+    static void work(job &j)
+    {
+        for (;;) {
+            const int item = j.next.fetch_add(1, std::memory_order_relaxed);
+            if (item >= j.n_items) {
+                return;
+            }
+            (*j.fn)(item);
+            j.done.fetch_add(1, std::memory_order_release);
+        }
+    }
+    void loop()
+    {
+        for (;;) {
+            std::shared_ptr<job> j;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] {
+                    while (!jobs_.empty() && jobs_.front()->next.load(std::memory_order_relaxed) >= jobs_.front()->n_items) {
+                        jobs_.pop_front();
+                    }
+                    return stop_ || !jobs_.empty();
+                });
+                if (stop_) {
+                    return;
+                }
+                j = jobs_.front();
+                if (j->helpers.fetch_add(1) >= j->max_helpers) { // enough hands on this one: look at the next, or sleep
+                    j.reset();
+                    for (auto &o : jobs_) {
+                        if (o->next.load(std::memory_order_relaxed) < o->n_items && o->helpers.fetch_add(1) < o->max_helpers) {
+                            j = o;
+                            break;
+                        }
+                    }
+                    if (!j) {
+                        cv_.wait_for(lk, std::chrono::microseconds(200));
+                        continue;
+                    }
+                }
+            }
+            work(*j);
+        }
+    }
+
+public:
+    static delivery_pool &get()
+    {
+        static delivery_pool p;
+        return p;
+    }
+    ~delivery_pool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : thr_) {
+            t.join();
+        }
+    }
+    // fn(item) for item in [0, n_items), on the caller's thread and up to n_thr - 1 pool threads; returns when all are done.
+    void run(int n_items, int n_thr, const std::function<void(int)> &fn)
+    {
+        auto j = std::make_shared<job>();
+        j->fn = &fn;
+        j->n_items = n_items;
+        j->max_helpers = n_thr - 1;
+        if (n_thr > 1) {
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                while (static_cast<int>(thr_.size()) < n_thr - 1) {
+                    thr_.emplace_back([this] { loop(); });
+                }
+                jobs_.push_back(j);
+            }
+            cv_.notify_all();
+        }
+        work(*j);
+        while (j->done.load(std::memory_order_acquire) < n_items) {
+            std::this_thread::yield();
+        }
+        // Workers that still hold the job only look at its counters (the shared_ptr keeps them alive); fn is not called again.
+    }
+};
+
 } // namespace
 
 int rk_host_alloc(void **ptr, int64_t bytes)
@@ -1879,16 +2038,19 @@ int rk_acc_pot(rk_state *s, int q, int64_t p_begin, int64_t p_end, void *const *
             }
             return;
         }
-        // Pageable arrays: register them for the duration of this blocking call, let the kernels write into them, unregister.
-        // Nothing is staged or copied; the registration never outlives the call, so the caller may free the arrays whenever
-        // it likes. Measured at 4M fp32 (48 MB): 2.27 ms per call into arrays used before against 2.86 through the staging
-        // buffer (kernels 2.25), 2.8 against 3.45 into freshly allocated ones; at 64M (768 MB) 38.7 against 46.6 into the
-        // same arrays, but 73 against 52 into fresh ones (pinning 768 MB of untouched pages) -- hence: always for arrays
-        // the previous call on this state wrote, otherwise up to RK_HOST_REGISTER_MAX_MB (256). RK_HOST_REGISTER=0 disables.
+        // Optional (RK_HOST_REGISTER=1; OFF by default): register the caller's pageable arrays for the duration of this blocking
+        // call, let the kernels write into them, unregister. Measured at 4M fp32 (48 MB): 2.27 ms per call into arrays used
+        // before against 2.86 through the staging buffer. It is NOT safe in a process where anything else pins host memory
+        // that shares pages with the arrays: the HIP runtime keeps a cache of the ranges it pinned for pageable hipMemcpy
+        // calls (sources read-only), a registration that overlaps one of those gets its mapping, and the traversal dies of
+        // "Memory access fault by GPU ... Write access to a read-only page" or of a fault when the cached pin is evicted
+        // (tools/stress_host_register.py: every run with the registration on aborts within seconds, none without;
+        // profiles/r03/host_register_overlap.txt). Only for applications that never hand pageable memory to HIP copies.
+        // With it on: always for arrays the previous call on this state wrote, otherwise up to RK_HOST_REGISTER_MAX_MB (256).
         {
             static const bool reg = [] {
                 const char *e = std::getenv("RK_HOST_REGISTER");
-                return !(e && std::atoi(e) == 0);
+                return e && std::atoi(e) != 0;
             }();
             static const size_t reg_max = [] {
                 const char *e = std::getenv("RK_HOST_REGISTER_MAX_MB");
@@ -2003,32 +2165,18 @@ int rk_acc_pot(rk_state *s, int q, int64_t p_begin, int64_t p_end, void *const *
             return v < 1 ? 1 : v;
         }();
         const int n_thr = std::max(1, std::min<int>({max_thr, n_items, static_cast<int>(std::thread::hardware_concurrency())}));
-        std::atomic<int> next{0};
-        auto worker = [&]() {
-            for (;;) {
-                const int item = next.fetch_add(1);
-                if (item >= n_items) {
-                    return;
-                }
-                // A byte range of the staging buffer (the nres arrays back to back) -> the caller's arrays.
-                size_t off = static_cast<size_t>(item) * piece, len = std::min(piece, need - off);
-                const size_t arr = count * fsz;
-                while (len) {
-                    const size_t k = off / arr, in = off % arr, nb = std::min(len, arr - in);
-                    std::memcpy(dst[k] + in, stage + off, nb);
-                    off += nb;
-                    len -= nb;
-                }
+        const size_t arr = count * fsz;
+        // A byte range of the staging buffer (the nres arrays back to back) -> the caller's arrays, with streaming stores
+        // (no read-for-ownership of 48 MB of destination lines that are overwritten whole).
+        delivery_pool::get().run(n_items, n_thr, [&](int item) {
+            size_t off = static_cast<size_t>(item) * piece, len = std::min(piece, need - off);
+            while (len) {
+                const size_t k = off / arr, in = off % arr, nb = std::min(len, arr - in);
+                stream_copy(dst[k] + in, stage + off, nb);
+                off += nb;
+                len -= nb;
             }
-        };
-        std::vector<std::thread> thr;
-        for (int t = 1; t < n_thr; ++t) {
-            thr.emplace_back(worker);
-        }
-        worker();
-        for (auto &t : thr) {
-            t.join();
-        }
+        });
     });
 }
 

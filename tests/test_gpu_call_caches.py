@@ -93,11 +93,11 @@ np.savez(sys.argv[1], **res)
                         ("heavy_first_auto", {}), ("pc_any", {"RK_ANY": "1"}), ("list_any", {"RK_ANY": "3"}),
                         ("pc_r2_list_any", {"RK_ANY": "2"}), ("list_r4_list_any", {"RK_ANY": "4"}),
                         ("class_launches", {"RK_ANY": "0"})):
-        env = dict(os.environ, **extra)
+        env = dict(os.environ, RK_BACKTRACE="1", PYTHONFAULTHANDLER="1", **extra)
         env["PYTHONPATH"] = os.pathsep.join([root, os.path.join(root, "tests"), env.get("PYTHONPATH", "")])
         f = str(tmp_path / (name + ".npz"))
         out = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True, timeout=600, env=env, cwd=root)
-        assert out.returncode == 0, out.stderr[-2000:]
+        assert out.returncode == 0, (name, out.stderr[-3000:])
         files.append(np.load(f))
     assert len(files[0].files) == 48
     for k in files[0].files:

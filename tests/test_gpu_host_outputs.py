@@ -84,8 +84,8 @@ def test_pinned_block_lifetime_and_errors():
     assert _capi.lib().rk_host_free(None) == 0
 
 
-@pytest.mark.parametrize("env", [{"RK_HOST_DIRECT": "0"}, {"RK_HOST_THREADS": "1", "RK_HOST_REGISTER": "0"}, {"RK_HOST_REGISTER": "0"},
-                                 {"RK_HOST_REGISTER_MAX_MB": "0"}])
+@pytest.mark.parametrize("env", [{"RK_HOST_DIRECT": "0"}, {"RK_HOST_THREADS": "1"}, {"RK_HOST_THREADS": "3"},
+                                 {"RK_HOST_REGISTER": "1"}, {"RK_HOST_REGISTER": "1", "RK_HOST_REGISTER_MAX_MB": "0"}])
 def test_delivery_knobs_do_not_change_results(env):
     code = """
 import numpy as np, oracle, rakau_amd
@@ -110,22 +110,37 @@ print("SUM", repr(float(np.sum([np.abs(v).sum(dtype=np.float64) for v in a]))), 
     assert run(env) == base
 
 
-def test_arrays_sharing_pages_are_registered_as_one_range():
-    """Pageable output arrays are registered for the duration of the call; slices of ONE allocation (the layout of
-    benchmark/benchmark_acc.cpp: one buffer of N-element blocks) share pages and must travel as one range. Results equal the
-    device-output call, bytes around the slices are untouched, repeated calls and a call into other arrays work."""
-    n = 250000
-    m, x, y, z = oracle.plummer(n, np.float32)
-    st = state_from_oracle(oracle.Tree(x, y, z, m))
-    mv = rakau_amd.mac_value_of(0.75, "bh", np.float32)
-    ref = device_result(st, 2, mv, n, np.float32, 0, n, 0.0)
-    buf = np.full(4 * n + 7, -7.0, dtype=np.float32)
-    outs = [buf[5 + k * n:5 + (k + 1) * n] for k in range(4)]  # back to back, unaligned
-    for _ in range(3):
-        st.acc_pot(2, mv, out=outs)
-        for o, r in zip(outs, ref):
-            assert np.array_equal(o, r)
-        assert np.all(buf[:5] == -7.0) and np.all(buf[5 + 4 * n:] == -7.0)
-    other = st.acc_pot(2, mv)
-    for o, r in zip(other, ref):
+@pytest.mark.parametrize("register", ["0", "1"])
+def test_output_arrays_that_are_slices_of_one_allocation(register):
+    """The layout of benchmark/benchmark_acc.cpp: one buffer of N-element blocks, so the output arrays share pages. Results
+    equal the device-output call, bytes around the slices are untouched, repeated calls and a call into other arrays work --
+    through the staging buffer (default) and with the opt-in scoped registration (RK_HOST_REGISTER=1: the slices must travel
+    as ONE registered range). The registration runs in a fresh process whose only pageable HIP copies come from arrays that
+    stay alive: it is unsafe next to other pinnings of the same pages, hence opt-in."""
+    code = """
+import numpy as np, torch, oracle, rakau_amd
+from helpers import state_from_oracle
+n = 250000
+m, x, y, z = oracle.plummer(n, np.float32)
+st = state_from_oracle(oracle.Tree(x, y, z, m))
+mv = rakau_amd.mac_value_of(0.75, "bh", np.float32)
+d = [torch.zeros(n, dtype=torch.float32, device="cuda") for _ in range(4)]
+st.acc_pot_device(2, mv, [t.data_ptr() for t in d])
+torch.cuda.synchronize()
+ref = [t.cpu().numpy() for t in d]
+buf = np.full(4 * n + 7, -7.0, dtype=np.float32)
+outs = [buf[5 + k * n:5 + (k + 1) * n] for k in range(4)]  # back to back, unaligned
+for _ in range(3):
+    st.acc_pot(2, mv, out=outs)
+    for o, r in zip(outs, ref):
         assert np.array_equal(o, r)
+    assert np.all(buf[:5] == -7.0) and np.all(buf[5 + 4 * n:] == -7.0)
+other = st.acc_pot(2, mv)
+for o, r in zip(other, ref):
+    assert np.array_equal(o, r)
+print("slices ok")
+"""
+    e = dict(os.environ, RK_HOST_REGISTER=register)
+    e["PYTHONPATH"] = os.pathsep.join([ROOT, os.path.join(ROOT, "tests"), e.get("PYTHONPATH", "")])
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=e, cwd=ROOT)
+    assert out.returncode == 0 and "slices ok" in out.stdout, out.stderr[-2000:]
