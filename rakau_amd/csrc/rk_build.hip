@@ -485,7 +485,24 @@ __global__ void k_up_sums_exact(const uint4 *topo, const uint64_t *ncode, uint32
         return; // k_up_sums_exact_wave
     }
     typename vt<F>::v4 s = sums[k + 1u];
-    for (uint32_t i = start; i < end; ++i) {
+    uint32_t i = start;
+    // Eight particles are loaded together (one wait for memory per eight links of the chain instead of one per link: a
+    // thread walks up to 1023 particles, and every level of the tree is a launch of its own that ends with its slowest thread).
+    for (; i + 8u <= end; i += 8u) {
+        typename vt<F>::v4 p[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; ++u) {
+            p[u] = part4[i + u];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; ++u) {
+            s.w += p[u].w;
+            s.x = d_fma(p[u].w, p[u].x, s.x);
+            s.y = d_fma(p[u].w, p[u].y, s.y);
+            s.z = d_fma(p[u].w, p[u].z, s.z);
+        }
+    }
+    for (; i < end; ++i) {
         const typename vt<F>::v4 p = part4[i];
         s.w += p.w;
         s.x = d_fma(p.w, p.x, s.x);
@@ -509,10 +526,10 @@ __global__ void k_exact_big_list(const uint4 *topo, uint32_t n_nodes, uint32_t *
 
 // One workgroup (4 wavefronts) per listed node of level lvl. The chain itself is serial: lanes 0-3 of wave 0 carry the
 // four sums {m x, m y, m z, m}, one dependent fused multiply-add per particle and lane (the mass sum is fma(m, 1, sum) =
-// m + sum exactly). Everything else feeds it: all 256 threads load the NEXT super-chunk of 2048 particles (8 per
-// thread, coalesced) into registers while wave 0 consumes the current one from LDS (component-major rows, one 16-byte
-// LDS read per four operands), then the registers go to the other LDS buffer. The loads of 2048 particles are in
-// flight during the ~7 us the chain needs for 2048 particles, so the chain never waits for memory.
+// m + sum exactly). Everything else feeds it: waves 1-3 load the NEXT super-chunk of 2048 particles (coalesced) into
+// registers while wave 0 consumes the current one from LDS (component-major rows, one 16-byte LDS read per four
+// operands), then the registers go to the other LDS buffer. The loads of 2048 particles are in flight during the
+// microseconds the chain needs for 2048 particles, so the chain never waits for memory.
 template <typename F, int ND>
 __global__ void __launch_bounds__(256) k_up_sums_exact_wave(const uint4 *topo, const uint64_t *ncode, const uint32_t *list,
                                                             const uint32_t *count, unsigned lvl,
@@ -537,19 +554,31 @@ __global__ void __launch_bounds__(256) k_up_sums_exact_wave(const uint4 *topo, c
     const uint32_t start = topo[k + 1u].z, end = topo[k].z;
     const int comp = lane & 3;
     F sum = reinterpret_cast<const F *>(&sums[k + 1u])[comp];
-    v4 nxt[8];
+    // Wavefronts 1-3 (192 threads) move the particles; wavefront 0 has no memory loads of its own in flight, so nothing but
+    // the chain's own LDS reads ever makes it wait.
+    constexpr uint32_t NF = 192u, PER = (SC + NF - 1u) / NF; // 11 particles per fetching thread
+    const uint32_t ft = static_cast<uint32_t>(tid) - 64u;
+    v4 nxt[PER];
     auto fetch = [&](uint32_t base) {
+        if (tid >= 64) {
 #pragma unroll
-        for (uint32_t u = 0; u < 8u; ++u) {
-            const uint32_t i = base + u * 256u + static_cast<uint32_t>(tid);
-            nxt[u] = part4[i < end ? i : end - 1u];
+            for (uint32_t u = 0; u < PER; ++u) {
+                const uint32_t j = u * NF + ft, i = base + j;
+                if (j < SC) {
+                    nxt[u] = part4[i < end ? i : end - 1u];
+                }
+            }
         }
     };
     auto stash = [&](int buf) {
+        if (tid >= 64) {
 #pragma unroll
-        for (uint32_t u = 0; u < 8u; ++u) {
-            const uint32_t j = u * 256u + static_cast<uint32_t>(tid);
-            s_tile[buf][0][j] = nxt[u].x, s_tile[buf][1][j] = nxt[u].y, s_tile[buf][2][j] = nxt[u].z, s_tile[buf][3][j] = nxt[u].w;
+            for (uint32_t u = 0; u < PER; ++u) {
+                const uint32_t j = u * NF + ft;
+                if (j < SC) {
+                    s_tile[buf][0][j] = nxt[u].x, s_tile[buf][1][j] = nxt[u].y, s_tile[buf][2][j] = nxt[u].z, s_tile[buf][3][j] = nxt[u].w;
+                }
+            }
         }
     };
     fetch(start);
@@ -567,12 +596,16 @@ __global__ void __launch_bounds__(256) k_up_sums_exact_wave(const uint4 *topo, c
             // The mass chain multiplies by one: its "coordinate" row is a row of ones (re-read, never advanced).
             const F *row_c = comp == 3 ? s_ones : s_tile[buf][comp];
             const uint32_t cstep = comp == 3 ? 0u : 1u;
-            // (Reading the operands of the NEXT eight particles ahead into registers was measured twice and is slower:
-            // 98 ms instead of 58 ms for the 4M build.)
-            for (uint32_t i = 0; i < cnt8; i += 8u) {
-                const v4 m0 = *reinterpret_cast<const v4 *>(row_m + i), m1 = *reinterpret_cast<const v4 *>(row_m + i + 4u);
-                const v4 c0 = *reinterpret_cast<const v4 *>(row_c + cstep * i),
-                         c1 = *reinterpret_cast<const v4 *>(row_c + cstep * i + 4u);
+            // The operands of the NEXT eight particles are read from LDS into a second register set before the eight
+            // dependent multiply-adds of the current ones are issued (two sets, swapped by unrolling: no register moves
+            // in the chain's wave; the scheduling barriers keep the compiler from sinking the reads back to their first
+            // use, which exposes the ~100-cycle LDS latency once per eight particles: 58 ms for the 4M build).
+            auto ld = [&](uint32_t i, v4 &m0, v4 &m1, v4 &c0, v4 &c1) {
+                i = i < SC ? i : SC - 8u; // (a read past the data is never consumed; keep it inside the buffer)
+                m0 = *reinterpret_cast<const v4 *>(row_m + i), m1 = *reinterpret_cast<const v4 *>(row_m + i + 4u);
+                c0 = *reinterpret_cast<const v4 *>(row_c + cstep * i), c1 = *reinterpret_cast<const v4 *>(row_c + cstep * i + 4u);
+            };
+            auto chain8 = [&](const v4 &m0, const v4 &m1, const v4 &c0, const v4 &c1) {
                 sum = d_fma(m0.x, c0.x, sum);
                 sum = d_fma(m0.y, c0.y, sum);
                 sum = d_fma(m0.z, c0.z, sum);
@@ -581,6 +614,24 @@ __global__ void __launch_bounds__(256) k_up_sums_exact_wave(const uint4 *topo, c
                 sum = d_fma(m1.y, c1.y, sum);
                 sum = d_fma(m1.z, c1.z, sum);
                 sum = d_fma(m1.w, c1.w, sum);
+            };
+            v4 am0, am1, ac0, ac1, bm0, bm1, bc0, bc1;
+            uint32_t i = 0;
+            if (cnt8) {
+                ld(0u, am0, am1, ac0, ac1);
+            }
+            for (; i + 16u <= cnt8; i += 16u) {
+                ld(i + 8u, bm0, bm1, bc0, bc1);
+                __builtin_amdgcn_sched_barrier(0);
+                chain8(am0, am1, ac0, ac1);
+                __builtin_amdgcn_sched_barrier(0);
+                ld(i + 16u, am0, am1, ac0, ac1);
+                __builtin_amdgcn_sched_barrier(0);
+                chain8(bm0, bm1, bc0, bc1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (i < cnt8) { // one more group of eight (already in the A set)
+                chain8(am0, am1, ac0, ac1);
             }
             for (uint32_t i = cnt8; i < cnt; ++i) {
                 sum = d_fma(row_m[i], comp == 3 ? F(1) : row_c[i], sum);

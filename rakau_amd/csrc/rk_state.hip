@@ -1275,6 +1275,64 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
         if (split) {
             split_fb = prepare_split<F>(s, p, p_begin, p_end, g_lo, g_hi, mac_value, stream);
         }
+        // Variant 0 (automatic): a call over few critical nodes cannot fill the device with one wave per node, and
+        // ends with its longest serial chains running alone. Such calls hand lane-mapping classes to the producer /
+        // consumer kernel (1 + R waves per node): all of them below 5 000 critical nodes, the class with the longest
+        // chains (R = 2: 64 < T <= 128 targets on one wave) below 20 000. Both kernels give the same bits, so this is
+        // a pure scheduling decision (measured: tools/archive_r02/r02_job11.sh, r02_job12.sh).
+        static const int64_t pc_all_below = [] {
+            const char *e = std::getenv("RK_PC_ALL_BELOW");
+            return e ? std::atoll(e) : int64_t(5000);
+        }();
+        static const int64_t pc_r2_below = [] {
+            const char *e = std::getenv("RK_PC_R2_BELOW");
+            return e ? std::atoll(e) : int64_t(20000);
+        }();
+        static const int pc_mask_env = [] {
+            const char *e = std::getenv("RK_PC_MASK"); // experiment knob: bit c = class R = c + 1 on the P/C kernel
+            return e ? std::atoi(e) : -1;
+        }();
+        unsigned pc_mask = 0u;
+        if (s.variant == 3) {
+            pc_mask = pc_mask_env >= 0 ? static_cast<unsigned>(pc_mask_env) & 0xfu : 0xfu;
+        } else if (s.variant == 0) {
+            const int64_t ng = g_hi - g_lo;
+            pc_mask = ng <= pc_all_below ? 0xfu : (ng <= pc_r2_below ? 0x2u : 0u);
+        }
+        // Order in which the class kernels are handed to the GPU. The dispatcher serves the queues roughly in launch
+        // order until the device is full, so the classes launched last start late, and their longest nodes end the
+        // call: RK_CLASS_ORDER (e.g. "4312": R = 4 first) overrides the default.
+        static const std::string class_order = [] {
+            const char *e = std::getenv("RK_CLASS_ORDER");
+            return std::string(e ? e : "");
+        }();
+        // 0: per-class launches; 1: k_pc_any; 2: k_pc for R = 2 + k_list_any for the rest; 3: k_list_any (heavy-first plans
+        // only, i.e. repeated calls over at most RK_PLAN_MAX_GROUPS critical nodes; RK_ANY=0 keeps the class launches).
+        static const int any_env = [] {
+            const char *e = std::getenv("RK_ANY");
+            return e ? std::atoi(e) : -1;
+        }();
+        int any_mode = 0;
+        if (!split && s.variant == 0 && any_env != 0 && s.cur_lists == static_cast<const uint32_t *>(s.plan.d_lists)
+            && s.plan.n_all > 0 && (s.plan.all_padded || s.plan.n_all == g_hi - g_lo - (big_e - big_b))) {
+            // Measured (tools/any_probe.py, profiles/r03/one_launch_kernels.txt): k_pc_any at 2.9k nodes 0.134 ms (class
+            // launches 0.140, k_list_any 0.173); k_list_any at 9.4k nodes 0.23 (0.29-0.30; with R = 2 on k_pc 0.27), on the
+            // 13.4k-node shards of the 4M tree 0.373-0.379 (0.406-0.412; 0.40), at 26k nodes 0.62 (0.66).
+            // 4.2k nodes: class launches on the producer / consumer kernel 0.173, k_pc_any 0.196 (its five-wave workgroups
+            // are admitted four per CU), k_list_any 0.193; 5.6k nodes: k_list_any 0.205 (class launches 0.25), 6.5k: 0.215
+            // (0.27); 54k nodes (2M particles): 1.19 (1.22).
+            static const int64_t pc_any_below = [] {
+                const char *e = std::getenv("RK_PC_ANY_BELOW");
+                return e ? std::atoll(e) : int64_t(3200);
+            }();
+            any_mode = any_env > 0 ? any_env : (g_hi - g_lo <= pc_any_below ? 1 : (pc_mask == 0xfu ? 0 : 3));
+            if (s.plan.all_padded) {
+                any_mode = 3; // the merged light-tail list (RK_ANY_TAIL=1)
+            }
+        }
+        // The class kernels run on side streams, forked from and joined back to the call's stream (a single launch
+        // needs neither).
+        const bool forked = !serial && any_mode != 1 && any_mode != 3;
         auto enqueue = [&](hipStream_t st, bool capturing) {
             if (need_super) {
                 rk::launch_super<F>(s, p, sb, se, st);
@@ -1287,64 +1345,6 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
             for (int i = 0; i < rk::n_list_R; ++i) {
                 streams[i] = (serial || i == 0) ? st : s.aux_stream[i - 1];
             }
-            // Variant 0 (automatic): a call over few critical nodes cannot fill the device with one wave per node, and
-            // ends with its longest serial chains running alone. Such calls hand lane-mapping classes to the producer /
-            // consumer kernel (1 + R waves per node): all of them below 5 000 critical nodes, the class with the longest
-            // chains (R = 2: 64 < T <= 128 targets on one wave) below 20 000. Both kernels give the same bits, so this is
-            // a pure scheduling decision (measured: tools/archive_r02/r02_job11.sh, r02_job12.sh).
-            static const int64_t pc_all_below = [] {
-                const char *e = std::getenv("RK_PC_ALL_BELOW");
-                return e ? std::atoll(e) : int64_t(5000);
-            }();
-            static const int64_t pc_r2_below = [] {
-                const char *e = std::getenv("RK_PC_R2_BELOW");
-                return e ? std::atoll(e) : int64_t(20000);
-            }();
-            static const int pc_mask_env = [] {
-                const char *e = std::getenv("RK_PC_MASK"); // experiment knob: bit c = class R = c + 1 on the P/C kernel
-                return e ? std::atoi(e) : -1;
-            }();
-            unsigned pc_mask = 0u;
-            if (s.variant == 3) {
-                pc_mask = pc_mask_env >= 0 ? static_cast<unsigned>(pc_mask_env) & 0xfu : 0xfu;
-            } else if (s.variant == 0) {
-                const int64_t ng = g_hi - g_lo;
-                pc_mask = ng <= pc_all_below ? 0xfu : (ng <= pc_r2_below ? 0x2u : 0u);
-            }
-            // Order in which the class kernels are handed to the GPU. The dispatcher serves the queues roughly in launch
-            // order until the device is full, so the classes launched last start late, and their longest nodes end the
-            // call: RK_CLASS_ORDER (e.g. "4312": R = 4 first) overrides the default.
-            static const std::string class_order = [] {
-                const char *e = std::getenv("RK_CLASS_ORDER");
-                return std::string(e ? e : "");
-            }();
-            // 0: per-class launches; 1: k_pc_any; 2: k_pc for R = 2 + k_list_any for the rest; 3: k_list_any (heavy-first plans
-            // only, i.e. repeated calls over at most RK_PLAN_MAX_GROUPS critical nodes; RK_ANY=0 keeps the class launches).
-            static const int any_env = [] {
-                const char *e = std::getenv("RK_ANY");
-                return e ? std::atoi(e) : -1;
-            }();
-            int any_mode = 0;
-            if (!split && s.variant == 0 && any_env != 0 && s.cur_lists == static_cast<const uint32_t *>(s.plan.d_lists)
-                && s.plan.n_all > 0 && (s.plan.all_padded || s.plan.n_all == g_hi - g_lo - (big_e - big_b))) {
-                // Measured (tools/any_probe.py, profiles/r03/one_launch_kernels.txt): k_pc_any at 2.9k nodes 0.134 ms (class
-                // launches 0.140, k_list_any 0.173); k_list_any at 9.4k nodes 0.23 (0.29-0.30; with R = 2 on k_pc 0.27), on the
-                // 13.4k-node shards of the 4M tree 0.373-0.379 (0.406-0.412; 0.40), at 26k nodes 0.62 (0.66).
-                // 4.2k nodes: class launches on the producer / consumer kernel 0.173, k_pc_any 0.196 (its five-wave workgroups
-                // are admitted four per CU), k_list_any 0.193; 5.6k nodes: k_list_any 0.205 (class launches 0.25), 6.5k: 0.215
-                // (0.27); 54k nodes (2M particles): 1.19 (1.22).
-                static const int64_t pc_any_below = [] {
-                    const char *e = std::getenv("RK_PC_ANY_BELOW");
-                    return e ? std::atoll(e) : int64_t(3200);
-                }();
-                any_mode = any_env > 0 ? any_env : (g_hi - g_lo <= pc_any_below ? 1 : (pc_mask == 0xfu ? 0 : 3));
-                if (s.plan.all_padded) {
-                    any_mode = 3; // the merged light-tail list (RK_ANY_TAIL=1)
-                }
-            }
-            // The class kernels run on side streams, forked from and joined back to the call's stream (a single launch
-            // needs neither).
-            const bool forked = !serial && any_mode != 1 && any_mode != 3;
             if (forked) {
                 RK_HIP(hipEventRecord(s.ev_fork, st));
                 for (int i = 0; i < rk::n_list_R - 1; ++i) {
@@ -1434,9 +1434,19 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                 }
             }
         };
-        if (use_graph && allow_graph) {
+        // Forked launch sequences are never captured. A graph with parallel branches replays 1.1 % faster at 4M (2.266 against
+        // 2.291 ms), but on this runtime destroying the executable graph of one such capture makes a LATER hipGraphLaunch of
+        // another one die of a segmentation fault inside libamdhip64 (tools/stress_graph_capture.py with RK_GRAPH_FORKED=1:
+        // within 500 key changes, every run; never when the old executable graphs are leaked instead of destroyed, never with
+        // linear graphs; profiles/r03/graph_destroy_crash.txt). RK_GRAPH_FORKED=1 captures them all the same.
+        static const bool graph_forked = [] {
+            const char *e = std::getenv("RK_GRAPH_FORKED");
+            return e && std::atoi(e) != 0;
+        }();
+        if (use_graph && allow_graph && (!forked || graph_forked)) {
             // A call that repeats the previous one (same range, outputs, parameters) replays a captured graph:
-            // one hipGraphLaunch instead of ~20 runtime calls.
+            // one hipGraphLaunch instead of a handful of runtime calls (the one-launch kernels of small calls, where the
+            // launch overhead is a tenth of the call).
             rk_state::graph_key key{};
             key.q = q, key.p_begin = p_begin, key.p_end = p_end, key.mac_value = mac_value, key.G = G, key.eps2 = eps2;
             key.offset_output = offset_output, key.super_k = s.super_k, key.variant = s.variant;

@@ -97,7 +97,9 @@ np.savez(sys.argv[1], **res)
         env["PYTHONPATH"] = os.pathsep.join([root, os.path.join(root, "tests"), env.get("PYTHONPATH", "")])
         f = str(tmp_path / (name + ".npz"))
         out = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True, timeout=600, env=env, cwd=root)
-        assert out.returncode == 0, (name, out.stderr[-3000:])
+        if out.returncode != 0:
+            sys.stderr.write("env case %s:\n%s\n" % (name, out.stderr[-8000:]))  # whole native stack (RK_BACKTRACE)
+        assert out.returncode == 0, name
         files.append(np.load(f))
     assert len(files[0].files) == 48
     for k in files[0].files:
