@@ -465,185 +465,209 @@ __global__ void k_up_sums(const uint4 *topo, const uint64_t *ncode, uint32_t n_n
 }
 
 // ---- node sums in the reference's association (exact mode) ----
-// The reference sums a node's particles serially in particle order (tree.hpp:1162-1168). The first child of a node
-// starts at the node's first particle, so the node's running sum after the first child's particles IS the first
-// child's sum: a node continues from there over its remaining particles, one fused multiply-add per particle and
-// component, in order. Identical bits to the host builders, at the price of serial chains (the root's is N long).
-constexpr uint32_t EXACT_WAVE_MIN = 1024; // remaining particles from which a node gets a workgroup of its own
+// The reference sums a node's particles serially in particle order (tree.hpp:1162-1168). Nodes that start at the same
+// particle are nested -- a node, its first child, that one's first child, ... down to a leaf; consecutive in depth-first
+// order -- and the serial sum of each is a PREFIX of the serial sum of the outermost one. So one chain per distinct first
+// particle yields them all: it starts from the leaf's sum, walks on from the leaf's last particle to the last particle of
+// the outermost node ("head": a node that is not the first child of its parent), one fused multiply-add per particle and
+// component, in order, and drops a sum at the end of every node of the nest. Chains of different heads share nothing, so
+// all of them run at once; the build takes as long as the longest, the root's N links (10.5 cycles per dependent
+// v_fma_f32 of a lone wavefront, 12-14.5 when fed from LDS: tools/ubench/chain_rate.hip), instead of the sum of the longest
+// chain of every tree level (round 2: 58 ms at 4M -- in a centrally concentrated system eleven levels each own nodes whose
+// bulk sits in their LAST child, 3 ms of chain per level on top of the root's 21). Identical bits to the host builders.
+constexpr uint32_t EXACT_WAVE_MIN = 1024; // links from which a chain gets a workgroup of its own
+constexpr uint32_t EXACT_NO_ROOT = 0xffffffffu;
 
-// Nodes with fewer remaining particles: one thread per node.
-template <typename F, int ND>
-__global__ void k_up_sums_exact(const uint4 *topo, const uint64_t *ncode, uint32_t n_nodes, unsigned lvl,
-                                const typename vt<F>::v4 *part4, typename vt<F>::v4 *sums)
+__device__ inline bool exact_is_head(const uint4 *topo, uint32_t k)
 {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_nodes || topo[k].x == 0u || level_of<ND>(ncode[k]) != lvl) {
-        return;
-    }
-    const uint32_t start = topo[k + 1u].z, end = topo[k].z;
-    if (end - start >= EXACT_WAVE_MIN) {
-        return; // k_up_sums_exact_wave
-    }
-    typename vt<F>::v4 s = sums[k + 1u];
-    uint32_t i = start;
-    // Eight particles are loaded together (one wait for memory per eight links of the chain instead of one per link: a
-    // thread walks up to 1023 particles, and every level of the tree is a launch of its own that ends with its slowest thread).
-    for (; i + 8u <= end; i += 8u) {
-        typename vt<F>::v4 p[8];
-#pragma unroll
-        for (uint32_t u = 0; u < 8u; ++u) {
-            p[u] = part4[i + u];
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < 8u; ++u) {
-            s.w += p[u].w;
-            s.x = d_fma(p[u].w, p[u].x, s.x);
-            s.y = d_fma(p[u].w, p[u].y, s.y);
-            s.z = d_fma(p[u].w, p[u].z, s.z);
-        }
-    }
-    for (; i < end; ++i) {
-        const typename vt<F>::v4 p = part4[i];
-        s.w += p.w;
-        s.x = d_fma(p.w, p.x, s.x);
-        s.y = d_fma(p.w, p.y, s.y);
-        s.z = d_fma(p.w, p.z, s.z);
-    }
-    sums[k] = s;
+    return topo[k].x != 0u && (k == 0u || topo[k - 1u].y != topo[k].y);
 }
 
-// List of the nodes that need a wavefront (any level).
-__global__ void k_exact_big_list(const uint4 *topo, uint32_t n_nodes, uint32_t *list, uint32_t *count)
+// Short chains: one thread per head. Long ones are listed for k_exact_chains_wave (the root's in slot 0: it is the longest
+// and must be dispatched first).
+template <typename F>
+__global__ void k_exact_chains(const uint4 *topo, uint32_t n_nodes, const typename vt<F>::v4 *part4, typename vt<F>::v4 *sums,
+                               uint32_t *list, uint32_t *count)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_nodes || topo[k].x == 0u) {
+    if (k >= n_nodes || !exact_is_head(topo, k)) {
         return;
     }
-    if (topo[k].z - topo[k + 1u].z >= EXACT_WAVE_MIN) {
-        list[atomicAdd(count, 1u)] = k;
+    uint32_t leaf = k + 1u;
+    while (topo[leaf].x != 0u) {
+        ++leaf;
+    }
+    uint32_t i = topo[leaf].z;
+    if (topo[k].z - i >= EXACT_WAVE_MIN) {
+        list[k == 0u ? 0u : atomicAdd(count, 1u)] = k;
+        return;
+    }
+    typename vt<F>::v4 s = sums[leaf];
+    for (uint32_t j = leaf; j-- > k;) {
+        const uint32_t end = topo[j].z;
+        // Eight particles are loaded together: one wait for memory per eight links.
+        for (; i + 8u <= end; i += 8u) {
+            typename vt<F>::v4 p[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; ++u) {
+                p[u] = part4[i + u];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; ++u) {
+                s.w += p[u].w;
+                s.x = d_fma(p[u].w, p[u].x, s.x);
+                s.y = d_fma(p[u].w, p[u].y, s.y);
+                s.z = d_fma(p[u].w, p[u].z, s.z);
+            }
+        }
+        for (; i < end; ++i) {
+            const typename vt<F>::v4 p = part4[i];
+            s.w += p.w;
+            s.x = d_fma(p.w, p.x, s.x);
+            s.y = d_fma(p.w, p.y, s.y);
+            s.z = d_fma(p.w, p.z, s.z);
+        }
+        sums[j] = s;
     }
 }
 
-// One workgroup (4 wavefronts) per listed node of level lvl. The chain itself is serial: lanes 0-3 of wave 0 carry the
-// four sums {m x, m y, m z, m}, one dependent fused multiply-add per particle and lane (the mass sum is fma(m, 1, sum) =
-// m + sum exactly). Everything else feeds it: waves 1-3 load the NEXT super-chunk of 2048 particles (coalesced) into
-// registers while wave 0 consumes the current one from LDS (component-major rows, one 16-byte LDS read per four
-// operands), then the registers go to the other LDS buffer. The loads of 2048 particles are in flight during the
-// microseconds the chain needs for 2048 particles, so the chain never waits for memory.
-template <typename F, int ND>
-__global__ void __launch_bounds__(256) k_up_sums_exact_wave(const uint4 *topo, const uint64_t *ncode, const uint32_t *list,
-                                                            const uint32_t *count, unsigned lvl,
-                                                            const typename vt<F>::v4 *part4, typename vt<F>::v4 *sums)
+// One workgroup (4 wavefronts) per listed head. The chain itself is serial: lanes 0-3 of wave 0 carry the four sums
+// {m x, m y, m z, m}, one dependent fused multiply-add per particle and lane (the mass sum is fma(m, 1, sum) = m + sum
+// exactly). Everything else feeds it: waves 1-3 load the NEXT super-chunk of 2048 particles (coalesced) into registers
+// while wave 0 consumes the current one from LDS (component-major rows, one 16-byte LDS read per four operands), then the
+// registers go to the other LDS buffer. The loads of 2048 particles are in flight during the microseconds the chain needs
+// for 2048 particles, so the chain never waits for memory.
+template <typename F>
+__global__ void __launch_bounds__(256) k_exact_chains_wave(const uint4 *topo, const uint32_t *list, const uint32_t *count,
+                                                           const typename vt<F>::v4 *part4, typename vt<F>::v4 *sums)
 {
     using v4 = typename vt<F>::v4;
     constexpr uint32_t SC = 2048; // particles per super-chunk
-    __shared__ __attribute__((aligned(32))) F s_tile[2][4][SC]; // per buffer: rows x, y, z, m
+    constexpr uint32_t CG = sizeof(F) == 4 ? 8 : 4, CL = 4 * CG; // a burst of the chain: CG four-operand LDS reads per row, CL links
+    __shared__ __attribute__((aligned(32))) F s_tile[2][4][SC + CL]; // per buffer: rows x, y, z, m (+ CL: read-ahead past the end)
     __shared__ __attribute__((aligned(32))) F s_ones[8];
     const uint32_t e = blockIdx.x;
     if (e >= *count) {
         return;
     }
     const uint32_t k = list[e];
-    if (level_of<ND>(ncode[k]) != lvl) {
+    if (k == EXACT_NO_ROOT) {
         return;
     }
     const int tid = static_cast<int>(threadIdx.x), lane = tid & 63;
     if (tid < 8) {
         s_ones[tid] = F(1);
     }
-    const uint32_t start = topo[k + 1u].z, end = topo[k].z;
+    uint32_t leaf = k + 1u;
+    while (topo[leaf].x != 0u) {
+        ++leaf;
+    }
     const int comp = lane & 3;
-    F sum = reinterpret_cast<const F *>(&sums[k + 1u])[comp];
+    F sum = reinterpret_cast<const F *>(&sums[leaf])[comp];
     // Wavefronts 1-3 (192 threads) move the particles; wavefront 0 has no memory loads of its own in flight, so nothing but
     // the chain's own LDS reads ever makes it wait.
     constexpr uint32_t NF = 192u, PER = (SC + NF - 1u) / NF; // 11 particles per fetching thread
     const uint32_t ft = static_cast<uint32_t>(tid) - 64u;
     v4 nxt[PER];
-    auto fetch = [&](uint32_t base) {
-        if (tid >= 64) {
+    uint32_t start = topo[leaf].z;
+    for (uint32_t j = leaf; j-- > k;) {
+        const uint32_t end = topo[j].z;
+        if (end > start) {
+            auto fetch = [&](uint32_t base) {
+                if (tid >= 64) {
 #pragma unroll
-            for (uint32_t u = 0; u < PER; ++u) {
-                const uint32_t j = u * NF + ft, i = base + j;
-                if (j < SC) {
-                    nxt[u] = part4[i < end ? i : end - 1u];
+                    for (uint32_t u = 0; u < PER; ++u) {
+                        const uint32_t jj = u * NF + ft, i = base + jj;
+                        if (jj < SC) {
+                            nxt[u] = part4[i < end ? i : end - 1u];
+                        }
+                    }
                 }
-            }
-        }
-    };
-    auto stash = [&](int buf) {
-        if (tid >= 64) {
+            };
+            auto stash = [&](int buf) {
+                if (tid >= 64) {
 #pragma unroll
-            for (uint32_t u = 0; u < PER; ++u) {
-                const uint32_t j = u * NF + ft;
-                if (j < SC) {
-                    s_tile[buf][0][j] = nxt[u].x, s_tile[buf][1][j] = nxt[u].y, s_tile[buf][2][j] = nxt[u].z, s_tile[buf][3][j] = nxt[u].w;
+                    for (uint32_t u = 0; u < PER; ++u) {
+                        const uint32_t jj = u * NF + ft;
+                        if (jj < SC) {
+                            s_tile[buf][0][jj] = nxt[u].x, s_tile[buf][1][jj] = nxt[u].y, s_tile[buf][2][jj] = nxt[u].z,
+                            s_tile[buf][3][jj] = nxt[u].w;
+                        }
+                    }
                 }
-            }
-        }
-    };
-    fetch(start);
-    stash(0);
-    __syncthreads();
-    int buf = 0;
-    for (uint32_t base = start; base < end; base += SC, buf ^= 1) {
-        const bool more = base + SC < end;
-        if (more) {
-            fetch(base + SC); // in flight while wave 0 walks the chain
-        }
-        if (tid < 64) {
-            const uint32_t cnt = end - base < SC ? end - base : SC, cnt8 = cnt & ~7u;
-            const F *row_m = s_tile[buf][3];
-            // The mass chain multiplies by one: its "coordinate" row is a row of ones (re-read, never advanced).
-            const F *row_c = comp == 3 ? s_ones : s_tile[buf][comp];
-            const uint32_t cstep = comp == 3 ? 0u : 1u;
-            // The operands of the NEXT eight particles are read from LDS into a second register set before the eight
-            // dependent multiply-adds of the current ones are issued (two sets, swapped by unrolling: no register moves
-            // in the chain's wave; the scheduling barriers keep the compiler from sinking the reads back to their first
-            // use, which exposes the ~100-cycle LDS latency once per eight particles: 58 ms for the 4M build).
-            auto ld = [&](uint32_t i, v4 &m0, v4 &m1, v4 &c0, v4 &c1) {
-                i = i < SC ? i : SC - 8u; // (a read past the data is never consumed; keep it inside the buffer)
-                m0 = *reinterpret_cast<const v4 *>(row_m + i), m1 = *reinterpret_cast<const v4 *>(row_m + i + 4u);
-                c0 = *reinterpret_cast<const v4 *>(row_c + cstep * i), c1 = *reinterpret_cast<const v4 *>(row_c + cstep * i + 4u);
             };
-            auto chain8 = [&](const v4 &m0, const v4 &m1, const v4 &c0, const v4 &c1) {
-                sum = d_fma(m0.x, c0.x, sum);
-                sum = d_fma(m0.y, c0.y, sum);
-                sum = d_fma(m0.z, c0.z, sum);
-                sum = d_fma(m0.w, c0.w, sum);
-                sum = d_fma(m1.x, c1.x, sum);
-                sum = d_fma(m1.y, c1.y, sum);
-                sum = d_fma(m1.z, c1.z, sum);
-                sum = d_fma(m1.w, c1.w, sum);
-            };
-            v4 am0, am1, ac0, ac1, bm0, bm1, bc0, bc1;
-            uint32_t i = 0;
-            if (cnt8) {
-                ld(0u, am0, am1, ac0, ac1);
-            }
-            for (; i + 16u <= cnt8; i += 16u) {
-                ld(i + 8u, bm0, bm1, bc0, bc1);
-                __builtin_amdgcn_sched_barrier(0);
-                chain8(am0, am1, ac0, ac1);
-                __builtin_amdgcn_sched_barrier(0);
-                ld(i + 16u, am0, am1, ac0, ac1);
-                __builtin_amdgcn_sched_barrier(0);
-                chain8(bm0, bm1, bc0, bc1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (i < cnt8) { // one more group of eight (already in the A set)
-                chain8(am0, am1, ac0, ac1);
-            }
-            for (uint32_t i = cnt8; i < cnt; ++i) {
-                sum = d_fma(row_m[i], comp == 3 ? F(1) : row_c[i], sum);
+            fetch(start);
+            stash(0);
+            __syncthreads();
+            int buf = 0;
+            for (uint32_t base = start; base < end; base += SC, buf ^= 1) {
+                const bool more = base + SC < end;
+                if (more) {
+                    fetch(base + SC); // in flight while wave 0 walks the chain
+                }
+                if (tid < 64) {
+                    const uint32_t cnt = end - base < SC ? end - base : SC;
+                    const F *row_m = s_tile[buf][3];
+                    // The mass chain multiplies by one: its "coordinate" row is a row of ones (re-read, never advanced).
+                    const F *row_c = comp == 3 ? s_ones : s_tile[buf][comp];
+                    const uint32_t cstep = comp == 3 ? 0u : 1u;
+                    // The operands of the NEXT burst are read from LDS into a second register set before the dependent
+                    // multiply-adds of the current one are issued (two sets, swapped by unrolling; the scheduling barriers
+                    // keep the compiler from sinking the reads back to their first use). A lone wavefront starts a dependent
+                    // v_fma_f32 every 10.5 cycles, but only while the multiply-adds follow each other directly
+                    // (tools/ubench/chain_rate.hip): interleaving the reads and address updates with them measured slower
+                    // twice (sched_group_barrier {fma, read} x 4: the root's chain at 4M takes 32 ms; hand-written assembly:
+                    // 30 ms; reads in a block of their own between bursts of 8: 22 ms), so the bursts are long: 32 links.
+                    auto ld = [&](uint32_t i, v4 (&m)[CG], v4 (&c)[CG]) { // (rows are padded: i <= SC stays inside)
+#pragma unroll
+                        for (uint32_t g = 0; g < CG; ++g) {
+                            m[g] = *reinterpret_cast<const v4 *>(row_m + i + 4u * g);
+                            c[g] = *reinterpret_cast<const v4 *>(row_c + cstep * (i + 4u * g));
+                        }
+                    };
+                    auto chain = [&](const v4 (&m)[CG], const v4 (&c)[CG]) {
+#pragma unroll
+                        for (uint32_t g = 0; g < CG; ++g) {
+                            sum = d_fma(m[g].x, c[g].x, sum);
+                            sum = d_fma(m[g].y, c[g].y, sum);
+                            sum = d_fma(m[g].z, c[g].z, sum);
+                            sum = d_fma(m[g].w, c[g].w, sum);
+                        }
+                    };
+                    v4 am[CG], ac[CG], bm[CG], bc[CG];
+                    const uint32_t cntb = cnt / CL * CL;
+                    uint32_t i = 0;
+                    if (cntb) {
+                        ld(0u, am, ac);
+                    }
+                    for (; i + 2u * CL <= cntb; i += 2u * CL) {
+                        ld(i + CL, bm, bc);
+                        __builtin_amdgcn_sched_barrier(0);
+                        chain(am, ac);
+                        __builtin_amdgcn_sched_barrier(0);
+                        ld(i + 2u * CL, am, ac);
+                        __builtin_amdgcn_sched_barrier(0);
+                        chain(bm, bc);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (i < cntb) { // one more burst (already in the A set)
+                        chain(am, ac);
+                        i += CL;
+                    }
+                    for (; i < cnt; ++i) { // fewer than a burst left in this super-chunk
+                        sum = d_fma(row_m[i], comp == 3 ? F(1) : row_c[i], sum);
+                    }
+                }
+                if (more) {
+                    stash(buf ^ 1); // the other buffer was consumed one iteration ago
+                }
+                __syncthreads();
             }
         }
-        if (more) {
-            stash(buf ^ 1); // the other buffer was consumed one iteration ago
+        if (tid < 4) {
+            reinterpret_cast<F *>(&sums[j])[tid] = sum;
         }
-        __syncthreads();
-    }
-    if (tid < 4) {
-        reinterpret_cast<F *>(&sums[k])[tid] = sum;
+        start = end;
     }
 }
 
@@ -1099,20 +1123,18 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     hipLaunchKernelGGL((k_leaf_sums<F>), dim3(nblk(nn)), dim3(256), 0, st, topo, static_cast<uint32_t>(nn),
                        static_cast<const v4 *>(p4), sums.get());
     if (exact_node_sums()) {
-        // The reference's association (bit-identical node properties; serial chains: ~12 ms more at 4M particles).
-        auto big = dalloc<uint32_t>(nn + 1);
-        RK_HIP(hipMemsetAsync(big.get() + nn, 0, sizeof(uint32_t), st));
-        hipLaunchKernelGGL(k_exact_big_list, dim3(nblk(nn)), dim3(256), 0, st, topo, static_cast<uint32_t>(nn), big.get(),
-                           big.get() + nn);
-        const auto max_big = static_cast<unsigned>(static_cast<size_t>(n) / EXACT_WAVE_MIN * (CBITS + 1u) + 1u);
-        for (int lvl = static_cast<int>(CBITS) - 1; lvl >= 0; --lvl) {
-            hipLaunchKernelGGL((k_up_sums_exact<F, ND>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode,
-                               static_cast<uint32_t>(nn), static_cast<unsigned>(lvl), static_cast<const v4 *>(p4), sums.get());
-            // Per level the listed nodes are disjoint in particles: at most n / EXACT_WAVE_MIN of them exist.
-            hipLaunchKernelGGL((k_up_sums_exact_wave<F, ND>), dim3(std::min<unsigned>(max_big, static_cast<unsigned>(nn))),
-                               dim3(256), 0, st, topo, ncode, big.get(), big.get() + nn, static_cast<unsigned>(lvl),
-                               static_cast<const v4 *>(p4), sums.get());
-        }
+        // The reference's association (bit-identical node properties): one serial chain per distinct first particle, all
+        // at once; the root's N links set the time (~25 ms at 4M particles).
+        const auto max_big = static_cast<unsigned>(static_cast<size_t>(n) / EXACT_WAVE_MIN * (CBITS + 1u) + 2u);
+        auto big = dalloc<uint32_t>(static_cast<size_t>(max_big) + 1u);
+        // Slot 0 is the root's; the counter starts behind it.
+        RK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(big.get()), static_cast<int>(EXACT_NO_ROOT), 1, st));
+        RK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(big.get() + max_big), 1, 1, st));
+        hipLaunchKernelGGL((k_exact_chains<F>), dim3(nblk(nn)), dim3(256), 0, st, topo, static_cast<uint32_t>(nn),
+                           static_cast<const v4 *>(p4), sums.get(), big.get(), big.get() + max_big);
+        // (Chains of one tree level are disjoint in particles: at most n / EXACT_WAVE_MIN long ones per level exist.)
+        hipLaunchKernelGGL((k_exact_chains_wave<F>), dim3(std::min<unsigned>(max_big, static_cast<unsigned>(nn))), dim3(256), 0, st,
+                           topo, big.get(), big.get() + max_big, static_cast<const v4 *>(p4), sums.get());
     } else {
         for (int lvl = static_cast<int>(CBITS) - 1; lvl >= 0; --lvl) {
             hipLaunchKernelGGL((k_up_sums<F, ND>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, static_cast<uint32_t>(nn),
