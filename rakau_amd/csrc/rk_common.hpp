@@ -173,6 +173,7 @@ struct kparams {
     const uint32_t *perm; // non-null: original-order output, results of Morton particle i go to out[perm[i]]
     unsigned long long *dbg; // diagnostic builds only (RK_STAMPS): per-section cycle totals
     int xcd_mode;            // block -> group-list mapping (see xcd_map_block)
+    int any_rev;             // one-launch kernels: block i serves list entry n - 1 - i (class lists read backwards: R = 4 first)
     // Supergroup pre-pass (k_super): K consecutive target groups share the upper part of list building.
     // super_k == 0 disables it. Per supergroup S: sup_common[S * SUP_CAPC ...] = sources {x, y, z, m} accepted for every
     // member group; sup_resid[S * SUP_CAPR ...] = node records every member still has to test itself;

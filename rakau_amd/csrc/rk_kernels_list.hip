@@ -603,7 +603,7 @@ __global__ void __launch_bounds__(64, sizeof(F) == 4 ? (RMAX >= 4 ? RK_W4 : RK_W
     if (static_cast<int>(blk) >= n_list) {
         return;
     }
-    const uint32_t g = __builtin_amdgcn_readfirstlane(list[blk]);
+    const uint32_t g = __builtin_amdgcn_readfirstlane(list[P.any_rev ? static_cast<unsigned>(n_list) - 1u - blk : blk]);
     if (g == RK_PLAN_PAD_VALUE) {
         return;
     }

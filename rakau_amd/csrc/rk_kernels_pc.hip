@@ -575,7 +575,7 @@ __global__ void __launch_bounds__(64 * 5, (sizeof(F) == 4 ? RK_PC_W : RK_PC_W64)
     if (static_cast<int>(blk) >= n_list) {
         return;
     }
-    const uint32_t g = __builtin_amdgcn_readfirstlane(list[blk]);
+    const uint32_t g = __builtin_amdgcn_readfirstlane(list[P.any_rev ? static_cast<unsigned>(n_list) - 1u - blk : blk]);
     if (g == RK_PLAN_PAD_VALUE) {
         return;
     }

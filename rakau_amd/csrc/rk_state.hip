@@ -1129,6 +1129,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
             return e ? std::atoi(e) : 1;
         }();
         p.xcd_mode = xcd_mode;
+        p.any_rev = 0;
     }
 #ifdef RK_STAMPS
     {
@@ -1323,11 +1324,42 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
             // (0.27); 54k nodes (2M particles): 1.19 (1.22).
             static const int64_t pc_any_below = [] {
                 const char *e = std::getenv("RK_PC_ANY_BELOW");
-                return e ? std::atoll(e) : int64_t(3200);
+                return e ? std::atoll(e) : int64_t(4000);
             }();
-            any_mode = any_env > 0 ? any_env : (g_hi - g_lo <= pc_any_below ? 1 : (pc_mask == 0xfu ? 0 : 3));
+            // (Since forked launch sequences are no longer replayed from a graph, the class launches of 3.2k-5k nodes lost
+            // their place -- queued calls, ms: 3.6k nodes 0.167, k_pc_any 0.155, k_list_any 0.177; 3.9k: 0.275 / 0.178 / 0.181;
+            // 4.5k: 0.202 / 0.202 / 0.186; 5.1k: 0.335 / 0.230 / 0.192 -- tools/any_probe3.py.)
+            any_mode = any_env > 0 ? any_env : (g_hi - g_lo <= pc_any_below ? 1 : 3);
             if (s.plan.all_padded) {
                 any_mode = 3; // the merged light-tail list (RK_ANY_TAIL=1)
+            }
+        }
+        // A small call WITHOUT a plan (the first call on a tree: every step of a time-stepping loop) that covers all critical
+        // nodes: one launch too, over the state's own class lists read backwards -- R = 4 first, the lightest class last, which
+        // is most of what the heavy-first plan buys -- instead of four class kernels forked onto side streams.
+        const uint32_t *first_list = nullptr;
+        int64_t first_n = 0;
+        {
+            static const bool any_first = [] {
+                const char *e = std::getenv("RK_ANY_FIRST"); // 0: class launches for calls without a plan
+                return !(e && std::atoi(e) == 0);
+            }();
+            static const int64_t any_first_max = [] {
+                // First calls, ms (tools/first_call_probe.py, Plummer; class launches -> this): 100k 0.191 -> 0.178, 350k
+                // 0.488 -> 0.360, 1M 0.83 -> 0.76, 1.8M (47.6k nodes) 1.51 -> 1.25; leapfrog harness 100k 0.187 -> 0.166,
+                // 2M (~50k nodes) 1.082 -> 1.069; beyond, the class kernels with a Morton slice per XCD win: 4M 1.97 vs 2.05.
+                const char *e = std::getenv("RK_ANY_FIRST_MAX");
+                return e ? std::atoll(e) : int64_t(60000);
+            }();
+            const int64_t n_wave = s.class2_off[RK_MAX_R] - s.class2_off[0];
+            if (any_first && any_mode == 0 && !split && s.variant == 0 && any_env != 0
+                && s.cur_lists == static_cast<const uint32_t *>(s.buf[RK_BUF_CLASS]) && g_lo == 0 && g_hi == s.n_crit
+                && g_hi <= any_first_max && n_wave > 0 && n_wave == g_hi - (big_e - big_b)) {
+                first_list = s.cur_lists + s.class2_off[0];
+                first_n = n_wave;
+                any_mode = (any_env == 1 || any_env == 3) ? any_env : (g_hi <= 4000 ? 1 : 3);
+                p.any_rev = 1;
+                p.xcd_mode = 0; // chunks of consecutive entries dealt round-robin to the XCDs, as for a heavy-first plan
             }
         }
         // The class kernels run on side streams, forked from and joined back to the call's stream (a single launch
@@ -1363,7 +1395,13 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                 // A small repeated call: one launch over the heavy-first list of ALL classes (or two: the R = 2 class on its
                 // producer / consumer kernel, everything else on k_list_any) instead of four that start 25-45 us apart.
                 const auto *pl = static_cast<const uint32_t *>(s.plan.d_lists);
-                if (any_mode == 1) {
+                if (first_list) {
+                    if (any_mode == 1) {
+                        rk::launch_pc_any<F>(s, q, p, first_list, first_n, streams[0]);
+                    } else {
+                        rk::launch_list_any<F>(s, q, p, first_list, first_n, streams[0]);
+                    }
+                } else if (any_mode == 1) {
                     rk::launch_pc_any<F>(s, q, p, pl + s.plan.off_all, s.plan.n_all, streams[0]);
                 } else if (any_mode == 2) {
                     rk::launch_pc<F>(s, q, p, cb, ce, streams, 0x2u);

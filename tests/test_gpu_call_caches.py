@@ -86,13 +86,16 @@ for variant in (0, 2, 3, 4):
 np.savez(sys.argv[1], **res)
 """
     files = []
-    # plain: no plan; tail / tail_chunks: the light-tail plan; the rest: the heavy-first plan of small calls with its
+    # plain: no plan (full-range calls: one launch over the reversed class lists); tail / tail_chunks: the light-tail plan; the rest: the heavy-first plan of small calls with its
     # one-launch kernels (k_pc_any below 3200 critical nodes, k_list_any above; forced both ways, and the mixed forms).
     for name, extra in (("plain", {"RK_PLAN": "0"}), ("tail", {"RK_PLAN_MAX_GROUPS": "64"}),
                         ("tail_chunks", {"RK_PLAN_MAX_GROUPS": "64", "RK_PLAN_REGIONS": "0"}),
                         ("heavy_first_auto", {}), ("pc_any", {"RK_ANY": "1"}), ("list_any", {"RK_ANY": "3"}),
                         ("pc_r2_list_any", {"RK_ANY": "2"}), ("list_r4_list_any", {"RK_ANY": "4"}),
-                        ("class_launches", {"RK_ANY": "0"})):
+                        ("class_launches", {"RK_ANY": "0"}),
+                        # calls without a plan: one launch over the class lists read backwards (full range), forced both ways, off
+                        ("first_pc_any", {"RK_PLAN": "0", "RK_ANY": "1"}), ("first_list_any", {"RK_PLAN": "0", "RK_ANY": "3"}),
+                        ("first_class_launches", {"RK_PLAN": "0", "RK_ANY_FIRST": "0"})):
         env = dict(os.environ, RK_BACKTRACE="1", PYTHONFAULTHANDLER="1", **extra)
         env["PYTHONPATH"] = os.pathsep.join([root, os.path.join(root, "tests"), env.get("PYTHONPATH", "")])
         f = str(tmp_path / (name + ".npz"))
