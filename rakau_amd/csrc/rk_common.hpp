@@ -282,6 +282,7 @@ struct rk_state {
     graph_key last_key{}; // key of the previous call: a graph is only captured when a call repeats
     bool have_last_key = false;
     hipGraphExec_t graph_exec = nullptr;
+    bool graph_exec_forked = false; // the captured sequence has parallel branches (such executable graphs are never destroyed)
     hipStream_t cap_stream = nullptr;
     bool timed = false;  // the last call recorded ev0 / ev1
     bool timing = true;  // rk_state_set_timing

@@ -49,6 +49,33 @@ const bool g_crash_handler_installed = [] {
     return false;
 }();
 
+// Executable graphs of launch sequences with parallel branches (class kernels forked onto side streams) are never destroyed:
+// on this runtime hipGraphExecDestroy of one makes a LATER hipGraphLaunch of another such graph die of a segmentation fault
+// inside libamdhip64 (tools/stress_graph_capture.py: within 500 key changes in every run, also with the device idle at the
+// destroy; never when they are kept; never with linear graphs -- profiles/r03/graph_destroy_crash.txt). They are parked until
+// the process ends instead, and only RK_GRAPH_FORKED_MAX (64) of them are ever made per process: after that, forked
+// sequences are launched directly (1-4 % slower between 2M and 6M particles). RK_GRAPH_FORKED=0: never capture them.
+std::atomic<int> g_forked_execs{0};
+bool forked_capture_allowed()
+{
+    static const int cap = [] {
+        const char *e = std::getenv("RK_GRAPH_FORKED"), *m = std::getenv("RK_GRAPH_FORKED_MAX");
+        if (e && std::atoi(e) == 0) {
+            return 0;
+        }
+        return m ? std::max(std::atoi(m), 0) : 64;
+    }();
+    return g_forked_execs.load(std::memory_order_relaxed) < cap;
+}
+void drop_graph_exec(rk_state &s)
+{
+    if (s.graph_exec && !s.graph_exec_forked) {
+        (void)hipGraphExecDestroy(s.graph_exec);
+    }
+    s.graph_exec = nullptr;
+    s.graph_exec_forked = false;
+}
+
 // -1: not set (the environment variable RK_BUILD_EXACT decides, default off).
 std::atomic<int> g_build_exact{-1};
 
@@ -148,10 +175,7 @@ void release_tree(rk_state *s)
     s->plan = rk_state::launch_plan{};
     s->work_cache.clear();
     s->sup_b = s->sup_e = 0;
-    if (s->graph_exec) {
-        (void)hipGraphExecDestroy(s->graph_exec);
-        s->graph_exec = nullptr;
-    }
+    drop_graph_exec(*s);
     s->have_last_key = false;
     s->have_plan_key = false;
     s->sl_rep_pending = false; // the device was synchronised above
@@ -709,8 +733,11 @@ bool plan_regions_enabled()
 }
 
 template <typename F>
-void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64_t g_hi, double mac_value, bool lpt)
+void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64_t g_hi, double mac_value, int mode)
 {
+    // mode 1: heavy-first (sorted by decreasing work); 2: class lists in Morton order + ONE merged list that reads them
+    // backwards, R = 4 first (heavy-first by class, neighbours stay together); 0: light-tail arrangement per class.
+    const bool lpt = mode == 1, rev = mode == 2;
     ensure_mirrors(s);
     // Weight of a node = its number of particles: as good a predictor of a wave's duration as the interaction census
     // (4M: 2.24-2.26 ms either way; tools/archive_r02/r02_job54.sh) and free, where the census is a traversal of its own (13 ms at 4M).
@@ -803,14 +830,23 @@ void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64
         if (lpt) {
             std::stable_sort(lists.begin() + first, lists.end(),
                              [&](uint32_t a, uint32_t b2) { return s.work_cache[a] > s.work_cache[b2]; });
-        } else if (lists.size() - static_cast<size_t>(first) > 1u) {
+        } else if (!rev && lists.size() - static_cast<size_t>(first) > 1u) {
             arrange_light_tail(first);
         }
     }
     s.plan.off[rk::n_classes] = static_cast<int64_t>(lists.size());
     s.plan.off_all = s.plan.n_all = s.plan.off_oth = s.plan.n_oth = s.plan.off_123 = s.plan.n_123 = 0;
-    s.plan.all_padded = !lpt;
-    if (!lpt) {
+    s.plan.all_padded = !lpt && !rev;
+    if (rev) {
+        const auto first = static_cast<std::ptrdiff_t>(lists.size());
+        for (int c = RK_MAX_R - 1; c >= 0; --c) {
+            const std::vector<uint32_t> part(lists.begin() + s.plan.off[c], lists.begin() + s.plan.off[c + 1]);
+            lists.insert(lists.end(), part.rbegin(), part.rend());
+        }
+        s.plan.off_all = first;
+        s.plan.n_all = static_cast<int64_t>(lists.size()) - first;
+    }
+    if (!lpt && !rev) {
         // One list of all wave-kernel classes in the light-tail arrangement (experiment: RK_ANY_TAIL=1 runs k_list_any on it.
         // Measured: 4M 2.288 instead of 2.238 ms, 2M equal -- on a full device the occupancy the single kernel gives up
         // (5 waves per SIMD for every class) costs more than the staggered starts of four class kernels; off by default).
@@ -869,10 +905,7 @@ void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64
     }
     s.plan.p_begin = p_begin, s.plan.p_end = p_end, s.plan.mac_value = mac_value;
     // A captured launch sequence may hold the plan buffer with its previous contents.
-    if (s.graph_exec) {
-        (void)hipGraphExecDestroy(s.graph_exec);
-        s.graph_exec = nullptr;
-    }
+    drop_graph_exec(s);
 }
 
 bool super_cache_enabled()
@@ -974,10 +1007,7 @@ bool prepare_split(rk_state &s, rk::kparams<F> &p, int64_t p_begin, int64_t p_en
     }
     if (s.sl_nseg < nseg || s.sl_ncnt < s.n_crit || !s.sl_ctl || s.sl_npart < npart) {
         RK_HIP(hipDeviceSynchronize());
-        if (s.graph_exec) {
-            (void)hipGraphExecDestroy(s.graph_exec); // it holds the old addresses
-            s.graph_exec = nullptr;
-        }
+        drop_graph_exec(s); // it holds the old addresses
         if (s.sl_nseg < nseg) {
             for (void **b : {&s.sl_idx, &s.sl_next}) {
                 rk::pool_free(*b);
@@ -1219,6 +1249,11 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                 // tree 1.34-1.37 instead of 1.25-1.28: the heavy-first order gives up the L2 locality of neighbouring nodes.)
                 return e ? std::atoll(e) : int64_t(30000);
             }();
+            // Between RK_PLAN_MAX_GROUPS and this many nodes: the class-reversed plan for k_list_any (0 = never).
+            static const int64_t plan_rev_max_groups = [] {
+                const char *e = std::getenv("RK_PLAN_REV_MAX_GROUPS");
+                return e ? std::atoll(e) : int64_t(60000);
+            }();
             const bool cached = s.plan.d_lists && s.plan.p_begin == p_begin && s.plan.p_end == p_end
                                 && s.plan.mac_value == mac_value;
             // (tracked for every call, also on the host-output path and with RK_GRAPH=0, where no graph key is kept.)
@@ -1237,7 +1272,8 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                                   || (plan_mode == 1 && g_hi - g_lo <= plan_tail_max_groups && (cached || repeats)));
             if (want) {
                 if (!cached) {
-                    build_plan<F>(s, p_begin, p_end, g_lo, g_hi, mac_value, g_hi - g_lo <= plan_max_groups);
+                    build_plan<F>(s, p_begin, p_end, g_lo, g_hi, mac_value,
+                                  g_hi - g_lo <= plan_max_groups ? 1 : (g_hi - g_lo <= plan_rev_max_groups ? 2 : 0));
                 }
                 s.cur_lists = static_cast<const uint32_t *>(s.plan.d_lists);
                 std::copy(s.plan.off, s.plan.off + rk::n_classes + 1, s.cur_off);
@@ -1248,7 +1284,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                 // Heavy-first order: deal chunks of consecutive list entries round-robin to the XCDs.
                 p.xcd_mode = 0;
                 // Light-tail order: the plan list interleaves the per-XCD queues itself (block i serves entry i).
-                if (g_hi - g_lo > plan_max_groups && plan_regions_enabled()) {
+                if (g_hi - g_lo > std::max(plan_max_groups, plan_rev_max_groups) && plan_regions_enabled()) {
                     p.xcd_mode = 2;
                 }
             }
@@ -1472,16 +1508,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                 }
             }
         };
-        // Forked launch sequences are never captured. A graph with parallel branches replays 1.1 % faster at 4M (2.266 against
-        // 2.291 ms), but on this runtime destroying the executable graph of one such capture makes a LATER hipGraphLaunch of
-        // another one die of a segmentation fault inside libamdhip64 (tools/stress_graph_capture.py with RK_GRAPH_FORKED=1:
-        // within 500 key changes, every run; never when the old executable graphs are leaked instead of destroyed, never with
-        // linear graphs; profiles/r03/graph_destroy_crash.txt). RK_GRAPH_FORKED=1 captures them all the same.
-        static const bool graph_forked = [] {
-            const char *e = std::getenv("RK_GRAPH_FORKED");
-            return e && std::atoi(e) != 0;
-        }();
-        if (use_graph && allow_graph && (!forked || graph_forked)) {
+        if (use_graph && allow_graph) {
             // A call that repeats the previous one (same range, outputs, parameters) replays a captured graph:
             // one hipGraphLaunch instead of a handful of runtime calls (the one-launch kernels of small calls, where the
             // launch overhead is a tenth of the call).
@@ -1498,16 +1525,14 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
             const bool repeats = s.have_last_key && std::memcmp(&key, &s.last_key, sizeof(key)) == 0;
             s.last_key = key;
             s.have_last_key = true;
-            if (!replay && !repeats) {
+            if (!replay && (!repeats || (forked && !forked_capture_allowed()))) {
                 // First call of its kind (e.g. once per rebuilt tree in a time-stepping loop): launch directly,
-                // a capture + instantiation would cost more than it saves.
+                // a capture + instantiation would cost more than it saves. So are forked sequences once the process has
+                // made its share of executable graphs with parallel branches (they are parked, never destroyed).
                 enqueue(stream, false);
             } else {
             if (!replay) {
-                if (s.graph_exec) {
-                    RK_HIP(hipGraphExecDestroy(s.graph_exec));
-                    s.graph_exec = nullptr;
-                }
+                drop_graph_exec(s);
                 hipGraph_t graph = nullptr;
                 RK_HIP(hipStreamBeginCapture(s.cap_stream, hipStreamCaptureModeThreadLocal));
                 try {
@@ -1524,6 +1549,10 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                 (void)hipGraphDestroy(graph);
                 RK_HIP(ie);
                 s.gkey = key;
+                s.graph_exec_forked = forked;
+                if (forked) {
+                    g_forked_execs.fetch_add(1, std::memory_order_relaxed);
+                }
             }
             RK_HIP(hipGraphLaunch(s.graph_exec, stream));
             }
@@ -2786,10 +2815,7 @@ int rk_state_set_perm(rk_state *s, const uint64_t *perm)
         // A traversal still in flight (any stream) may be reading the old permutation, and a captured launch sequence
         // must not outlive the buffer it was recorded with.
         RK_HIP(hipDeviceSynchronize());
-        if (s->graph_exec) {
-            (void)hipGraphExecDestroy(s->graph_exec);
-            s->graph_exec = nullptr;
-        }
+        drop_graph_exec(*s);
         s->have_last_key = false;
         std::vector<uint32_t> p32(static_cast<size_t>(s->nparts));
         for (size_t i = 0; i < p32.size(); ++i) {
