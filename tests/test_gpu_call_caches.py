@@ -95,7 +95,11 @@ np.savez(sys.argv[1], **res)
                         ("class_launches", {"RK_ANY": "0"}),
                         # calls without a plan: one launch over the class lists read backwards (full range), forced both ways, off
                         ("first_pc_any", {"RK_PLAN": "0", "RK_ANY": "1"}), ("first_list_any", {"RK_PLAN": "0", "RK_ANY": "3"}),
-                        ("first_class_launches", {"RK_PLAN": "0", "RK_ANY_FIRST": "0"})):
+                        ("first_class_launches", {"RK_PLAN": "0", "RK_ANY_FIRST": "0"}),
+                        # graphs of forked sequences: parked, only the first two captured, never captured
+                        ("forked_graphs_cap2", {"RK_PLAN": "0", "RK_ANY_FIRST": "0", "RK_GRAPH_FORKED_MAX": "2"}),
+                        ("forked_graphs_off", {"RK_PLAN_MAX_GROUPS": "64", "RK_PLAN_REV_MAX_GROUPS": "0", "RK_GRAPH_FORKED": "0"}),
+                        ("no_graphs", {"RK_GRAPH": "0"})):
         env = dict(os.environ, RK_BACKTRACE="1", PYTHONFAULTHANDLER="1", **extra)
         env["PYTHONPATH"] = os.pathsep.join([root, os.path.join(root, "tests"), env.get("PYTHONPATH", "")])
         f = str(tmp_path / (name + ".npz"))
