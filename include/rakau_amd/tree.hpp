@@ -1376,13 +1376,18 @@ private:
     // of device d. Every cut sits on a critical-node boundary (the snapping rule of tree.hpp:3053-3063 applied to every
     // boundary: this engine's unit of work is the critical node on the devices too).
     // An EMPTY split means "everything on device 0" here (the reference's default is the CPU; this library exists to
-    // offload), a split of size one is the reference's "CPU only".
+    // offload), a split of size one is the reference's "CPU only". Compile with -DRAKAU_AMD_EMPTY_SPLIT_IS_CPU for the
+    // reference's meaning of the empty split (tree.hpp:3114-3117 of the reference: no accelerator share, CPU engine).
     std::vector<size_type> split_cuts(const std::vector<double> &split) const
     {
         check_split(split);
         const size_type np = nparts();
         if (split.empty()) {
+#if defined(RAKAU_AMD_EMPTY_SPLIT_IS_CPU)
+            return {size_type(0), np};
+#else
             return {size_type(0), size_type(0), np};
+#endif
         }
         if (split.size() == 1u) {
             return {size_type(0), np};

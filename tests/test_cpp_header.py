@@ -32,3 +32,15 @@ def test_header_on_gpu():
     out = subprocess.run([EXE, "gpu"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "gpu+host checks: 0 failure(s)" in out.stdout
+
+
+def test_empty_split_can_mean_cpu_like_the_reference(tmp_path):
+    """-DRAKAU_AMD_EMPTY_SPLIT_IS_CPU restores the reference's meaning of a call without `split` (CPU engine; VERDICT r02
+    item 12): compiled and run without a GPU, bit-identical to split = {1}."""
+    exe = str(tmp_path / "empty_split_cpu")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-DRAKAU_AMD_EMPTY_SPLIT_IS_CPU", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "test_empty_split_cpu.cpp"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "rakau_amd", "lib"), "-lrakau_amd",
+                           "-Wl,-rpath," + os.path.join(ROOT, "rakau_amd", "lib")])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "yes" in out.stdout, out.stdout + out.stderr
