@@ -113,7 +113,8 @@ struct ctrl_block {
     unsigned n_crit, n_int, n_children; // critical nodes, internal nodes, sum of child counts
     unsigned max_group;         // particles in the largest critical node
     unsigned class2_count[8];   // critical nodes per lane-mapping class (list kernel binning)
-    unsigned pad[5];
+    unsigned max_level;         // deepest leaf level of the tree (levels below it have no nodes: their passes are not launched)
+    unsigned pad[4];
 };
 enum { ERR_COORD = 1u, ERR_COM = 2u, ERR_DIM = 4u, ERR_BOX = 8u };
 
@@ -319,19 +320,29 @@ __global__ void k_leaf_levels_windows(const uint8_t *win, uint32_t n, uint32_t m
 
 // ldiv[i] = first level at which c[i] leaves the cell of c[i-1]; cnt[i] = number of nodes whose first particle is i.
 template <int ND>
-__global__ void k_node_counts(const uint64_t *codes, uint32_t n, const uint8_t *leaf, uint8_t *ldiv, uint32_t *cnt)
+__global__ void k_node_counts(const uint64_t *codes, uint32_t n, const uint8_t *leaf, uint8_t *ldiv, uint32_t *cnt,
+                              ctrl_block *ctrl)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) {
-        return;
+    __shared__ unsigned s_max;
+    if (threadIdx.x == 0u) {
+        s_max = 0u;
     }
-    // Identical codes never start a node.
-    const unsigned dv = i > 0 ? common_levels<ND>(codes[i - 1], codes[i]) + 1u : 1u;
-    const unsigned lvl = leaf[i];
-    ldiv[i] = static_cast<uint8_t>(dv);
-    cnt[i] = dv <= lvl ? lvl - dv + 1u : 0u;
-    if (i == 0u) {
-        cnt[n] = 0u; // the scan runs over n + 1 values so that off[n] is the total
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        // Identical codes never start a node.
+        const unsigned dv = i > 0 ? common_levels<ND>(codes[i - 1], codes[i]) + 1u : 1u;
+        const unsigned lvl = leaf[i];
+        ldiv[i] = static_cast<uint8_t>(dv);
+        cnt[i] = dv <= lvl ? lvl - dv + 1u : 0u;
+        if (i == 0u) {
+            cnt[n] = 0u; // the scan runs over n + 1 values so that off[n] is the total
+        }
+        atomicMax(&s_max, lvl);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        atomicMax(&ctrl->max_level, s_max);
     }
 }
 
@@ -1050,7 +1061,7 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     } else {
         hipLaunchKernelGGL(k_leaf_levels_search<ND>, dim3(nblk(n)), dim3(256), 0, st, codes, n, mln, leaf.get());
     }
-    hipLaunchKernelGGL(k_node_counts<ND>, dim3(nblk(n)), dim3(256), 0, st, codes, n, leaf.get(), ldiv.get(), cnt.get());
+    hipLaunchKernelGGL(k_node_counts<ND>, dim3(nblk(n)), dim3(256), 0, st, codes, n, leaf.get(), ldiv.get(), cnt.get(), ctrl.get());
     exclusive_scan(cnt.get(), off.get(), n, st);
     hipLaunchKernelGGL(k_pack_nodes, dim3(1), dim3(1), 0, st, ctrl.get(), off.get() + n);
 
@@ -1136,7 +1147,10 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
         hipLaunchKernelGGL((k_exact_chains_wave<F>), dim3(std::min<unsigned>(max_big, static_cast<unsigned>(nn))), dim3(256), 0, st,
                            topo, big.get(), big.get() + max_big, static_cast<const v4 *>(p4), sums.get());
     } else {
-        for (int lvl = static_cast<int>(CBITS) - 1; lvl >= 0; --lvl) {
+        // Internal nodes live above the deepest leaf level: the passes of the levels below it (a third to a half of the CBITS
+        // launches, ~4 us each: a sixth of a 100k-particle rebuild) are not launched.
+        const int top = std::min(static_cast<int>(CBITS), static_cast<int>(hc.max_level)) - 1;
+        for (int lvl = top; lvl >= 0; --lvl) {
             hipLaunchKernelGGL((k_up_sums<F, ND>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, static_cast<uint32_t>(nn),
                                static_cast<unsigned>(lvl), sums.get());
         }
