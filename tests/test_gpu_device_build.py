@@ -197,6 +197,21 @@ def test_exact_build_is_bit_identical_to_the_host_builders(dtype, mac):
             for a, b in zip(sb.acc_pot(2, mv, eps2=1e-6), hs.acc_pot(2, mv, eps2=1e-6)):
                 assert np.array_equal(a, b)
             assert sb.count_interactions(mv) == hs.count_interactions(mv)
+        # Deep nests: two tight clumps (thousands of particles within 1e-4 of a point, one of them coincident) in a sparse
+        # background -- long chains that start deep in the tree, heads with many nested first children, empty segments.
+        rs = np.random.RandomState(3)
+        nb, nc = 40000, 6000
+        bg = rs.uniform(-1.0, 1.0, size=(nb, 3))
+        c1 = np.array([0.31, -0.27, 0.11]) + 1e-4 * rs.standard_normal((nc, 3))
+        c2 = np.tile(np.array([[-0.52, 0.44, -0.38]]), (nc // 4, 1))
+        c2[nc // 8:] += 1e-6 * rs.standard_normal((nc // 4 - nc // 8, 3))
+        pts = np.concatenate([bg, c1, c2]).astype(dtype)
+        rs.shuffle(pts)
+        mm = rs.uniform(0.5, 1.5, size=len(pts)).astype(dtype)
+        xx, yy, zz = (np.ascontiguousarray(pts[:, k]) for k in range(3))
+        ot = oracle.Tree(xx, yy, zz, mm, mac=mac, box_size=2.5)
+        sb = rakau_amd.State.build(xx, yy, zz, mm, mac=mac, box_size=2.5)
+        assert sb.download("nodes").tobytes() == oracle_nodes_aos(ot).tobytes()
         # Quadtree.
         rng = oracle.Rng(5)
         m, x, y = rng.uniform_particles(20000, 2.0, dtype, ndim=2)
