@@ -1312,7 +1312,8 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
         if (split) {
             split_fb = prepare_split<F>(s, p, p_begin, p_end, g_lo, g_hi, mac_value, stream);
         }
-        // Variant 0 (automatic): a call over few critical nodes cannot fill the device with one wave per node, and
+        // Class launches (what remains for calls that have no one-launch form: sub-ranges without a plan, trees beyond the
+        // limits). Variant 0 (automatic): a call over few critical nodes cannot fill the device with one wave per node, and
         // ends with its longest serial chains running alone. Such calls hand lane-mapping classes to the producer /
         // consumer kernel (1 + R waves per node): all of them below 5 000 critical nodes, the class with the longest
         // chains (R = 2: 64 < T <= 128 targets on one wave) below 20 000. Both kernels give the same bits, so this is
