@@ -14,7 +14,11 @@
  *                               (tree::rocm_reset_state(), include/rakau/tree.hpp:1511-1519)
  *   rk_acc_pot()             <- rocm_state<..>::acc_pot<Q>  include/rakau/detail/rocm_fwd.hpp:41-42
  *                               (called from tree::acc_pot_impl(), include/rakau/tree.hpp:3078-3094)
- *                               cuda_acc_pot_impl<Q,..>     include/rakau/detail/cuda_fwd.hpp:25-27
+ *                               cuda_acc_pot_impl<Q,..>     include/rakau/detail/cuda_fwd.hpp:25-29 (one rk_acc_pot per
+ *                               device share on replicas made by rk_state_clone_all: integration/rakau_amd_cuda_bridge.cpp)
+ *
+ * The two reference-side bindings are real translation units: integration/rakau_amd_bridge.cpp (ROCm seam) and
+ * integration/rakau_amd_cuda_bridge.cpp (CUDA seam, the reference's multi-GPU dispatch of tree.hpp:3131-3257).
  *
  *   rk_state_create_nd()     <- the same seam for NDim = 2 (quadtrees), src/rakau_rocm.cpp:333-345
  *

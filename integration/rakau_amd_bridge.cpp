@@ -18,6 +18,7 @@
 #include <rakau/detail/rocm_fwd.hpp>
 
 #include "rakau_amd_bridge.hpp"
+#include "rakau_amd_bridge_common.hpp"
 #include <rakau_amd.h>
 
 namespace rakau
@@ -28,44 +29,10 @@ inline namespace detail
 namespace
 {
 
-// rakau's default_ncrit (tree.hpp:584-595 of the reference): 256 when the library is built for AVX-512, 128 otherwise.
-// The reference tests xsimd's macros; a translation unit that has not seen xsimd (this one normally has not) gets the
-// same answer from the compiler's own macro, because xsimd derives XSIMD_X86_INSTR_SET >= XSIMD_X86_AVX512_VERSION from
-// __AVX512F__ and this file is compiled with the flags of the rest of the reference's library.
-constexpr std::size_t default_ncrit_of_this_build =
-#if defined(XSIMD_X86_INSTR_SET) && defined(XSIMD_X86_AVX512_VERSION)
-#if XSIMD_X86_INSTR_SET >= XSIMD_X86_AVX512_VERSION
-    256
-#else
-    128
-#endif
-#elif defined(__AVX512F__)
-    256
-#else
-    128
-#endif
-    ;
+using rakau_amd_bridge::default_ncrit_of_this_build;
+using rakau_amd_bridge::rk_throw;
 // Value announced by rakau_amd_set_ncrit() for the NEXT rocm_state constructed on this thread (0: none announced).
 thread_local std::size_t t_next_ncrit = 0;
-
-// Status code -> the exception type the reference throws for that class of error ("Errors").
-void rk_throw(int rc)
-{
-    switch (rc) {
-        case RK_OK:
-            return;
-        case RK_EINVAL:
-            throw std::invalid_argument(rk_last_error());
-        case RK_EDOMAIN:
-            throw std::domain_error(rk_last_error());
-        case RK_EOVERFLOW:
-            throw std::overflow_error(rk_last_error());
-        case RK_ENOMEM:
-            throw std::bad_alloc();
-        default:
-            throw std::runtime_error(rk_last_error());
-    }
-}
 
 } // namespace
 
@@ -98,29 +65,8 @@ rocm_state<NDim, F, UInt, MAC>::rocm_state(const std::array<const F *, NDim + 1u
     for (std::size_t j = 0; j < NDim + 1u; ++j) {
         p[j] = parts[j];
     }
-    // The C ABI takes the node records with 64-bit code / level fields (tree_node_t<NDim, F, std::uint64_t, MAC>); trees
-    // with 32-bit codes hand over a widened copy. The engine never looks at the codes: it uses the topology and the
-    // node properties only, and sorted codes are not needed with critical-node grouping.
-    using wide_node = tree_node_t<NDim, F, std::uint64_t, MAC>;
-    std::vector<wide_node> widened;
-    const void *nodes = tree;
-    if constexpr (!std::is_same_v<UInt, std::uint64_t>) {
-        widened.resize(static_cast<std::size_t>(tree_size));
-        for (std::size_t i = 0; i < widened.size(); ++i) {
-            const auto &n = tree[i];
-            auto &w = widened[i];
-            w.begin = n.begin, w.end = n.end, w.n_children = n.n_children, w.code = n.code, w.level = n.level;
-            for (std::size_t j = 0; j < NDim + 1u; ++j) {
-                w.props[j] = n.props[j];
-            }
-            if constexpr (MAC == mac::bh) {
-                w.dim2 = n.dim2;
-            } else {
-                w.dim = n.dim, w.delta = n.delta;
-            }
-        }
-        nodes = widened.data();
-    }
+    // Trees with 32-bit codes hand over widened node records (rakau_amd_bridge_common.hpp).
+    const rakau_amd_bridge::wide_nodes<NDim, F, UInt, MAC> wn(tree, static_cast<std::size_t>(tree_size));
     (void)codes;
     // The announcement is consumed by the constructor it was made for: a later tree on this thread that announces
     // nothing gets the build's default again, not the previous tree's value.
@@ -128,8 +74,8 @@ rocm_state<NDim, F, UInt, MAC>::rocm_state(const std::array<const F *, NDim + 1u
     t_next_ncrit = 0;
     rk_state *s = nullptr;
     rk_throw(rk_state_create_nd(&s, static_cast<int>(NDim), std::is_same_v<F, float> ? RK_F32 : RK_F64,
-                                MAC == mac::bh ? RK_MAC_BH : RK_MAC_BH_GEOM, /* device */ 0, p, nullptr, nparts, nodes,
-                                tree_size, static_cast<std::int64_t>(sizeof(wide_node)), ncrit));
+                                MAC == mac::bh ? RK_MAC_BH : RK_MAC_BH_GEOM, /* device */ 0, p, nullptr, nparts, wn.data,
+                                tree_size, wn.stride, ncrit));
     m_state = s;
 }
 

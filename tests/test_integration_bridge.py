@@ -14,6 +14,8 @@ REF_INC = "/root/reference/include"
 BUILD = os.path.join(ROOT, "tests", "build")
 LIB = os.path.join(BUILD, "librakau_rocm_bridge.so")
 DRIVER = os.path.join(BUILD, "bridge_driver")
+CUDA_LIB = os.path.join(BUILD, "librakau_cuda_bridge.so")
+CUDA_DRIVER = os.path.join(BUILD, "cuda_bridge_driver")
 RK_LIBDIR = os.path.join(ROOT, "rakau_amd", "lib")
 
 
@@ -24,6 +26,12 @@ def build():
                                     "-lrakau_amd", "-Wl,-rpath," + RK_LIBDIR, "-o", LIB])
     subprocess.check_call(common + ["-pthread", os.path.join(ROOT, "tests", "cpp", "bridge_driver.cpp"), "-L" + BUILD, "-lrakau_rocm_bridge",
                                     "-L" + RK_LIBDIR, "-lrakau_amd", "-Wl,-rpath," + BUILD, "-Wl,-rpath," + RK_LIBDIR, "-o", DRIVER])
+    # The CUDA seam (include/rakau/detail/cuda_fwd.hpp:23-30): the reference's multi-GPU entry.
+    subprocess.check_call(common + ["-shared", "-pthread", os.path.join(ROOT, "integration", "rakau_amd_cuda_bridge.cpp"), "-L" + RK_LIBDIR,
+                                    "-lrakau_amd", "-Wl,-rpath," + RK_LIBDIR, "-o", CUDA_LIB])
+    subprocess.check_call(common + ["-pthread", os.path.join(ROOT, "tests", "cpp", "cuda_bridge_driver.cpp"), "-L" + BUILD,
+                                    "-lrakau_cuda_bridge", "-L" + RK_LIBDIR, "-lrakau_amd", "-Wl,-rpath," + BUILD, "-Wl,-rpath," + RK_LIBDIR,
+                                    "-o", CUDA_DRIVER])
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_INC), reason="no checkout of the reference: the bridge cannot be compiled")
@@ -50,3 +58,39 @@ def test_bridge_driver_on_gpu():
         build()
     out = subprocess.run([DRIVER], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "bridge checks: 0 failure(s)" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_INC), reason="no checkout of the reference: the bridge cannot be compiled")
+def test_cuda_bridge_compiles_against_the_reference_headers():
+    """Every symbol of the CUDA seam the reference instantiates (src/rakau_cuda.cu:536-568: NDim {2,3} x F x UInt x Q x MAC =
+    48 cuda_acc_pot_impl functions), cuda_min_size / cuda_device_count, and the two life-time hooks."""
+    if not os.path.exists(CUDA_LIB):
+        build()
+    syms = subprocess.run(["nm", "-DC", "--defined-only", CUDA_LIB], capture_output=True, text=True, check=True).stdout
+    for f in ("rakau::detail::cuda_min_size()", "rakau::detail::cuda_device_count()", "rakau::detail::rakau_amd_tree_ready(",
+              "rakau::detail::rakau_amd_invalidate("):
+        assert f in syms
+    n = 0
+    for nd in (2, 3):
+        for fp in ("float", "double"):
+            for ui in ("unsigned int", "unsigned long"):
+                for mac in ("0", "1"):
+                    for q in (0, 1, 2):
+                        pat = r"void rakau::detail::cuda_acc_pot_impl<%du, %dul, %s, %s, \(rakau::mac\)%s>\(" % (q, nd, fp, ui, mac)
+                        assert re.search(pat, syms), pat
+                        n += 1
+    assert n == 48
+
+
+@pytest.mark.gpu
+def test_cuda_bridge_driver_on_gpu():
+    """cuda_acc_pot_impl over four logical devices (RK_ALIAS_DEVICES=4 on the 1-GPU box): every device share bit-identical
+    to the one-device call, compact and offset outputs, announced (resident replicas, invalidated by a mass update) and
+    unannounced (state per call) trees, 32-bit codes, the reference's error for too many accelerators."""
+    if not os.path.exists(CUDA_DRIVER):
+        if not os.path.isdir(REF_INC):
+            pytest.skip("cuda bridge driver not built (no checkout of the reference where this tree was built)")
+        build()
+    env = dict(os.environ, RK_ALIAS_DEVICES="4")
+    out = subprocess.run([CUDA_DRIVER], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "cuda bridge checks: 0 failure(s)" in out.stdout, out.stdout + out.stderr
