@@ -63,6 +63,10 @@ __device__ __forceinline__ void list_node(const kparams<F> &P, lk_wave_lds<F> &L
 #pragma unroll
             for (int k = 0; k < NR; ++k) {
                 acc[r][k] = F(0);
+                // The supergroup's common sources were summed by the pre-pass (k_common): split 0 starts from there.
+                if (P.sup_part && sp_raw == 0 && valid) {
+                    acc[r][k] = P.sup_part[static_cast<size_t>(k) * P.sup_part_stride + tb + static_cast<uint32_t>(ts + r * TP)];
+                }
             }
         }
 
@@ -84,7 +88,7 @@ __device__ __forceinline__ void list_node(const kparams<F> &P, lk_wave_lds<F> &L
             const uint2 cnt = P.sup_cnt[sup_S];
             if ((cnt.y >> 31) == 0u) {
                 from_root = false;
-                sup_ncommon = cnt.x;
+                sup_ncommon = P.sup_part ? 0u : cnt.x;
                 sup_nresid = cnt.y;
             }
         }

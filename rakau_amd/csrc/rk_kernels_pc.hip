@@ -91,6 +91,10 @@ __device__ __forceinline__ void pc_node(const kparams<F> &P, pc_lds<F> &L, const
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
             acc[0][k] = F(0);
+            // The supergroup's common sources were summed by the pre-pass (k_common): split 0 starts from there.
+            if (P.sup_part && sp_raw == 0 && tidx[0] >= 0) {
+                acc[0][k] = P.sup_part[static_cast<size_t>(k) * P.sup_part_stride + tb + static_cast<uint32_t>(tidx[0])];
+            }
         }
         // n / NS for n <= SRC_CAP without a division per tile: exact for n * NS < 2^16.
         const int inv_ns = (65536 + NS - 1) / NS;
@@ -203,7 +207,7 @@ __device__ __forceinline__ void pc_node(const kparams<F> &P, pc_lds<F> &L, const
         const uint2 cnt = P.sup_cnt[sup_S];
         if ((cnt.y >> 31) == 0u) {
             from_root = false;
-            sup_ncommon = cnt.x;
+            sup_ncommon = P.sup_part ? 0u : cnt.x;
             sup_nresid = cnt.y;
         }
     }

@@ -14,7 +14,7 @@ for line in open(sys.argv[1]):
 tot = {}
 print("%-52s %10s %9s %9s %8s %8s %8s %7s %7s %9s" % ("kernel", "VALU inst", "trans", "LDS inst", "active%", "istall%", "waitcnt%", "ldsbc%", "L2hit%", "GRBM cyc"))
 for k, d in data.items():
-    if not any(t in k for t in ("k_list<", "k_pc<", "k_super", "k_lists<", "k_dense<", "k_combine<")):
+    if not any(t in k for t in ("k_list<", "k_pc<", "k_super", "k_common<", "k_lists<", "k_dense<", "k_combine<")):
         continue
     wc = d.get("SQ_WAVE_CYCLES", 0) or 1
     row = (k[:52].replace("void rk::", "").replace("(rk::kparams<float>", ""), d.get("SQ_INSTS_VALU", 0), d.get("SQ_INSTS_VALU_TRANS", 0), d.get("SQ_INSTS_LDS", 0),
