@@ -3,8 +3,13 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one accs_u() call (one traversal of the resident tree for all target particles) with the
-tree and the particles already in HBM and the accelerations left in HBM. For N > 1 there is one rank per GPU:
+A "step" is one accs_u() call through the accelerator seam's own signature -- rk_acc_pot(): one traversal of the resident
+tree for all target particles of the rank, tree and particles already in HBM, the results delivered into the CALLER'S HOST
+arrays (t = wall time of one accs_u() with the tree resident and the outputs landing in host memory). The
+output arrays are allocated in pinned memory through the `Allocator` parameter the reference's own overloads have
+(tree.hpp:3406-3412; rakau_amd::pinned_allocator / rk_host_alloc). The same K steps with the results left in HBM
+(a device-resident caller, rk_acc_pot_device) and into pageable arrays are timed next to it and reported as
+`value_device_resident` / `value_host_outputs_pageable`. For N > 1 there is one rank per GPU:
 either launched by torch.distributed.run (the driver's form) or -- when WORLD_SIZE is not set -- spawned by this
 script itself as N child processes before anything touches a GPU (the reference needs no launcher either,
 tree.hpp:3150-3240). Rank 0 builds the tree and uploads it, the device buffers are replicated with RCCL
@@ -119,6 +124,9 @@ def self_launch(world):
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        # The GPU pool's host driver only supports dmabuf IPC (its own documentation: without this setting RCCL and the
+        # sharing of device memory across processes fail with `hipIpcGetMemHandle: invalid argument`); the pool exports it
+        # already, a copy of the script run elsewhere gets it here. Never overrides a value the caller chose.
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
@@ -207,12 +215,22 @@ def main():
     t_init = time.perf_counter() - t0
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    # RK_BENCH_FORCE_COMM=1 (test knob, world == 1 only): take the multi-rank replicate branch with a communicator of one rank --
+    # torch's own nccl process group, Comm.unique_id -> broadcast_object_list -> rk_comm_init -> rk_state_broadcast ->
+    # close, in the order an 8-GPU run uses them -- on a 1-GPU box (RCCL refuses two ranks on one GPU).
+    force_comm = world == 1 and os.environ.get("RK_BENCH_FORCE_COMM", "0") == "1"
+    if world > 1 or force_comm:
         import torch.distributed as dist
+        if force_comm and "MASTER_ADDR" not in os.environ:
+            import socket
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]), RANK="0", WORLD_SIZE="1")
+            sk.close()
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev), rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     lib = _capi.lib()
     mac = "bh"
@@ -257,31 +275,27 @@ def main():
             rakau_amd.set_build_exact(args.builder == "device")
     replicate_via = None
     lib_comm = None
-    if world > 1 and backend == "nccl":
+    lib_comm_used = False
+    if (world > 1 or force_comm) and backend == "nccl":
         # The replicate step lives in the library: rk_comm_* + rk_state_broadcast (ncclBroadcast of the meta block and of
-        # every buffer of the state, RCCL over xGMI). torch.distributed only ships the 128-byte communicator id -- and
-        # remains the fallback (same buffers through dist.broadcast) should the library's communicator not come up on
-        # every rank (all ranks take the same branch: the outcome is all-reduced).
+        # every buffer of the state, RCCL over xGMI). torch.distributed only ships the 128-byte communicator id -- and is
+        # the fallback (same buffers through dist.broadcast) if RCCL cannot be bound by the library on SOME rank. That is
+        # agreed on BEFORE the collective ncclCommInitRank: every rank probes with rk_comm_unique_id (dlopen + a local RCCL
+        # call, not collective) and the outcomes are all-reduced, so all ranks take the same branch. A failure inside the
+        # collective init itself is not recoverable (the other ranks are inside it) and ends the run.
         from rakau_amd.state import Comm
-        ok = 1
+        ok, my_id = 1, None
         try:
-            payload = [Comm.unique_id() if rank == 0 else None]
-        except Exception as e:  # pragma: no cover
-            payload, ok = [None], 0
-            print("rank %d: rk_comm_unique_id failed: %s" % (rank, e), file=sys.stderr)
-        dist.broadcast_object_list(payload, src=0)
-        try:
-            if payload[0] is None:
-                raise RuntimeError("no communicator id")
-            lib_comm = Comm(world, payload[0], rank, dev) if ok else None
+            my_id = Comm.unique_id()
         except Exception as e:  # pragma: no cover
             ok = 0
-            print("rank %d: rk_comm_init failed: %s" % (rank, e), file=sys.stderr)
+            print("rank %d: RCCL not usable from the library (rk_comm_unique_id: %s)" % (rank, e), file=sys.stderr)
         flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0 and lib_comm is not None:
-            lib_comm.close()
-            lib_comm = None
+        if int(flag.item()) == 1:
+            payload = [my_id if rank == 0 else None]
+            dist.broadcast_object_list(payload, src=0)
+            lib_comm = Comm(world, payload[0], rank, dev)
     if lib_comm is not None:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -289,8 +303,9 @@ def main():
         torch.cuda.synchronize()
         t_replicate = time.perf_counter() - t0
         lib_comm.close()
+        lib_comm_used = True
         replicate_via = "rk_state_broadcast (RCCL, inside the library)"
-    elif world > 1:
+    elif world > 1 or force_comm:
         # rk_state_export -> torch.distributed broadcast -> rk_state_import: the one-GPU rehearsal of the multi-rank path
         # (gloo: the buffers travel through host memory) and the fallback of the branch above (nccl: device to device).
         payload = [None]
@@ -335,8 +350,15 @@ def main():
     outs = [torch.zeros(max(n_local, 1), dtype=tdt, device="cuda") for _ in range(nres)]
     d_ptrs = [o.data_ptr() for o in outs]
     stream = torch.cuda.current_stream().cuda_stream
+    # Host output arrays of the timed call, allocated the way the reference's `Allocator` overloads allow (pinned).
+    pin_out = [rakau_amd.pinned_empty(max(n_local, 1), dtype) for _ in range(nres)]
 
     def step():
+        """One accs_u() through the seam: rk_acc_pot() for this rank's Morton range, results into host arrays. Blocking."""
+        state.acc_pot(q, mac_value, eps2=eps2, p_begin=p_begin, p_end=p_end, out=pin_out, offset_output=False)
+
+    def step_dev():
+        """The same traversal for a device-resident caller: results left in HBM, enqueued on the stream."""
         state.acc_pot_device(q, mac_value, d_ptrs, G=1.0, eps2=eps2, p_begin=p_begin, p_end=p_end,
                              offset_output=False, stream=stream)
 
@@ -356,29 +378,46 @@ def main():
     # The very first traversal call on this state (launch-path set-up, scratch allocation, the supergroup pre-pass).
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    step()
+    step_dev()
     torch.cuda.synchronize()
     first_call_ms = (time.perf_counter() - t0) * 1e3
     census = state.count_interactions(mac_value, p_begin, p_end)
     inter_local = census["com"] + census["pp"] + census["self"]
-    kms, busy_ms = [], 0.0
-    while len(kms) < 5 or (busy_ms < 80.0 and len(kms) < 1000):
-        step()
-        kms.append(state.last_kernel_ms())
-        busy_ms += kms[-1] if len(kms) > 2 else 0.0  # the first calls carry one-off initialisation
-    kernel_ms = float(np.median(kms[-min(10, len(kms) - 2):]))
-    if os.environ.get("RK_BENCH_DEBUG"):
-        print("kernel ms of the pre-loop:", " ".join("%.3f" % v for v in kms), file=sys.stderr)
+
+    def settle(fn):
+        kms, busy_ms = [], 0.0
+        while len(kms) < 5 or (busy_ms < 80.0 and len(kms) < 1000):
+            fn()
+            kms.append(state.last_kernel_ms())
+            busy_ms += kms[-1] if len(kms) > 2 else 0.0  # the first calls carry one-off initialisation
+        if os.environ.get("RK_BENCH_DEBUG"):
+            print("kernel ms of a pre-loop:", " ".join("%.3f" % v for v in kms), file=sys.stderr)
+        return float(np.median(kms[-min(10, len(kms) - 2):]))
+
+    kernel_ms_dev = settle(step_dev)
     # One burst of K calls without synchronisation in between: the first time K launches are in flight the HIP runtime
     # grows its signal / command pools (+0.05 ms per step on the first burst of 20, none afterwards; irrelevant, and
     # skipped, when a call takes longer than 5 ms).
-    if kernel_ms < 5.0:
+    if kernel_ms_dev < 5.0:
         for _ in range(args.steps):
-            step()
+            step_dev()
     barrier()
-
-    # The timed calls are those of a device-resident caller that issues them back to back and does not ask for kernel
-    # timings: without the library's two timing events per call (barrier packets between consecutive calls).
+    # (1) The device-resident caller: K calls back to back, results left in HBM, without the library's two timing events
+    # per call (barrier packets between consecutive calls). Reported as `value_device_resident`.
+    state.set_timing(False)
+    for _ in range(args.warmup):
+        step_dev()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step_dev()
+    barrier()
+    elapsed_dev = time.perf_counter() - t0
+    state.set_timing(True)
+    # (2) The seam's own call, results into (pinned) host arrays: kernel time of that form (the epilogue stores cross
+    # PCIe), then THE timed region of the contract: W warmup steps, K timed steps, barrier + synchronize on both sides.
+    kernel_ms = settle(step)
+    barrier()
     state.set_timing(False)
     for _ in range(args.warmup):
         step()
@@ -390,11 +429,6 @@ def main():
     elapsed = time.perf_counter() - t0
     state.set_timing(True)
     if os.environ.get("RK_BENCH_DEBUG"):
-        post = []
-        for _ in range(10):
-            step()
-            post.append(state.last_kernel_ms())
-        print("kernel ms after the timed loop:", " ".join("%.3f" % v for v in post), file=sys.stderr)
         for _ in range(4):
             barrier()
             t1 = time.perf_counter()
@@ -405,14 +439,15 @@ def main():
 
     if dist is not None:
         rdev = "cuda" if backend == "nccl" else "cpu"
-        red = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=rdev)
+        red = torch.tensor([elapsed, kernel_ms, elapsed_dev, kernel_ms_dev], dtype=torch.float64, device=rdev)
         dist.all_reduce(red, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms_max = float(red[0]), float(red[1])
+        elapsed, kernel_ms_max, elapsed_dev, kernel_ms_dev_max = (float(v) for v in red)
         tot = torch.tensor([float(inter_local), float(census["mac"])], dtype=torch.float64, device=rdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         inter_total, mac_total = float(tot[0]), float(tot[1])
     else:
-        kernel_ms_max, inter_total, mac_total = kernel_ms, float(inter_local), float(census["mac"])
+        kernel_ms_max, kernel_ms_dev_max = kernel_ms, kernel_ms_dev
+        inter_total, mac_total = float(inter_local), float(census["mac"])
 
     if rank != 0:
         if dist is not None:
@@ -447,9 +482,16 @@ def main():
     what = "%s %s Plummer %s theta=%g%s" % (call, count_str(n), fp_name, theta, " with softening" if eps else "")
     workload = "3D %s, %s-particle Plummer, theta=%g, %s%s" % (fp_name, count_str(n), theta, call,
                                                              " with softening" if eps else "")
+    # How the replicas were really made in THIS run (the library's RCCL broadcast, or the export / torch.distributed / import
+    # path with the transport that carried it).
+    if lib_comm_used:
+        transport = "tree replicated by RCCL broadcast (rk_state_broadcast)"
+    else:
+        transport = "tree replicated through torch.distributed broadcast (%s%s)" % (
+            backend, " = RCCL" if backend == "nccl" else ": host memory, rehearsal on shared GPU(s)")
     if world > 1:
-        workload += (", Morton-sharded across %d GPUs (%s targets per GPU), tree replicated by RCCL broadcast"
-                     % (world, count_str(n // world) if n % world == 0 else "~%d" % (n // world)))
+        workload += (", Morton-sharded across %d GPUs (%s targets per GPU), %s"
+                     % (world, count_str(n // world) if n % world == 0 else "~%d" % (n // world), transport))
     line = {
         "metric": "Mparticles/s, " + what,
         "value": round(value, 2),
@@ -462,16 +504,22 @@ def main():
         "scaling": scaling,
         "vs_baseline": None,
         "dtype": "f32" if dtype == "float32" else "f64",
-        "data": "synthetic Plummer sphere (numpy PCG64 seed 20261002), tree built on %s, resident in HBM; `value` = "
-                "results left in HBM (device-resident caller), `value_host_outputs` = the seam's own signature "
-                "(rk_acc_pot() into host arrays, SURVEY 8(d) t)" % args.builder,
+        "data": "synthetic Plummer sphere (numpy PCG64 seed 20261002), tree built on %s, resident in HBM; `value` = the "
+                "seam's own call, rk_acc_pot() into the caller's host arrays (SURVEY 8(d) t), arrays allocated with the "
+                "reference's Allocator overload in pinned memory (rakau_amd::pinned_allocator / rk_host_alloc); "
+                "`value_device_resident` = results left in HBM (rk_acc_pot_device), `value_host_outputs_pageable` = "
+                "plain pageable arrays" % args.builder,
         "config": {"workload": workload, "workload_key": args.workload,
                    "nparts": n, "nparts_per_gpu": n // world, "theta": theta, "q": q, "eps": eps, "max_leaf_n": 16,
                    "ncrit": 128, "mac": mac, "nodes": n_nodes, "critical_nodes": int(state.n_crit),
-                   "sharding": ("contiguous Morton range per GPU (equal %s), tree replicated by RCCL broadcast" % ("interaction counts" if work is not None else "particle counts")) if world > 1
+                   "sharding": ("contiguous Morton range per GPU (equal %s), %s" % ("interaction counts" if work is not None else "particle counts", transport)) if world > 1
                    else "single GPU", "kernel_variant": args.variant,
                    "prepass_reused_across_steps": bool(args.reuse_prepass)},
         "kernel_ms": round(kernel_ms_max, 4),
+        # The same K steps for a device-resident caller (results left in HBM; rk_acc_pot_device, calls enqueued back to back).
+        "value_device_resident": round(n / (elapsed_dev / args.steps) / 1e6, 2),
+        "ms_per_step_device_resident": round(elapsed_dev / args.steps * 1e3, 4),
+        "kernel_ms_device_resident": round(kernel_ms_dev_max, 4),
         "interactions_per_particle": round(inter_total / n, 2),
         "mac_evals_per_particle": round(mac_total / n, 2),
         "roofline": {
@@ -501,13 +549,11 @@ def main():
                                 "note": "README.md:42-49 of the reference, single cold calls on other hardware"},
     }
 
-    # PCIe-inclusive rate (never `value`): the seam's own call, rk_acc_pot() with host output arrays (what a tree.hpp
-    # user pays per accs_u() on a resident tree). Second call into the same, already touched, arrays.
+    # The same call into plain pageable arrays (what a tree.hpp user with std::vector<F> outputs pays per accs_u() on a
+    # resident tree: the results go through the library's pinned staging buffer and are delivered by host threads).
     try:
         if world == 1:
             host_out = [np.zeros(n, dtype=dtype) for _ in range(nres)]
-            # The GPU has idled through the CPU baseline above: like the device-output loop this one first runs until the
-            # clocks have settled (at least 7 calls and 80 ms), then takes the median of the last calls.
             def settle_and_time(arrays):
                 ts, busy = [], 0.0
                 while len(ts) < 7 or (busy < 0.08 and len(ts) < 200):
@@ -517,19 +563,11 @@ def main():
                     busy += ts[-1] if len(ts) > 2 else 0.0
                 return float(np.median(ts[-min(10, len(ts) - 2):]))
             t_host = settle_and_time(host_out)
-            line["host"]["kernel_ms_host_outputs"] = round(state.last_kernel_ms(), 4)
-            line["host"]["acc_pot_host_outputs_ms"] = round(t_host * 1e3, 3)
-            line["value_host_outputs"] = round(n / t_host / 1e6, 2)
-            line["ms_per_call_host_outputs"] = round(t_host * 1e3, 4)
-            # Same call, output arrays in pinned host memory (rk_host_alloc / rakau_amd::pinned_allocator): the kernels
-            # write the results into the caller's arrays themselves.
-            pin_out = [rakau_amd.pinned_empty(n, dtype) for _ in range(nres)]
-            t_pin = settle_and_time(pin_out)
-            line["host"]["kernel_ms_pinned_outputs"] = round(state.last_kernel_ms(), 4)
-            line["value_host_outputs_pinned"] = round(n / t_pin / 1e6, 2)
-            line["ms_per_call_host_outputs_pinned"] = round(t_pin * 1e3, 4)
+            line["host"]["kernel_ms_host_outputs_pageable"] = round(state.last_kernel_ms(), 4)
+            line["value_host_outputs_pageable"] = round(n / t_host / 1e6, 2)
+            line["ms_per_call_host_outputs_pageable"] = round(t_host * 1e3, 4)
             line["host"]["pinned_equals_pageable"] = bool(all(np.array_equal(a, b) for a, b in zip(host_out, pin_out)))
-            del pin_out
+            line["host"]["pinned_equals_device_resident"] = bool(all(np.array_equal(a, b.cpu().numpy()) for a, b in zip(pin_out, outs)))
     except Exception as e:  # pragma: no cover
         line["host"]["acc_pot_host_outputs_error"] = str(e)
 

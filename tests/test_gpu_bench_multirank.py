@@ -56,6 +56,11 @@ def test_two_ranks_one_gpu(launcher, scaling):
         assert 1218.45 < d["interactions_per_particle"] < 1500
         assert "200k Plummer" in d["metric"] and "200k-particle" in d["config"]["workload"]
     assert "across 2 GPUs" in d["config"]["workload"]
+    # The labels name the transport that really carried the replicas in this run (gloo through host memory), not RCCL.
+    assert "torch.distributed broadcast (gloo" in d["config"]["workload"] and "RCCL" not in d["config"]["workload"]
+    assert "gloo" in d["host"]["replicate_via"] and "gloo" in d["config"]["sharding"]
+    # `value` is the seam's own call (results into host arrays); the device-resident rate rides along.
+    assert d["value_device_resident"] > 0 and d["kernel_ms_device_resident"] > 0
 
 
 def test_shard_union_through_the_product():
@@ -74,3 +79,20 @@ def test_shard_union_through_the_product():
     outs = [p.communicate(timeout=600) for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(o[1][-1500:] for o in outs)
     assert "SHARD_UNION_EQUALS_FULL True ORDERED True" in outs[0][0], outs[0][0]
+
+
+def test_bench_one_rank_takes_the_library_rccl_branch():
+    """RK_BENCH_FORCE_COMM=1: `bench.py --gpus 1` runs the replicate step of the 8-GPU run with a communicator of one rank, in
+    the order the 8-GPU run uses -- torch's own nccl process group, the RCCL probe agreed by all-reduce, Comm.unique_id ->
+    broadcast_object_list -> rk_comm_init -> rk_state_broadcast -> close -- next to each other in one process."""
+    env = dict(os.environ, RK_BENCH_FORCE_COMM="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RK_BENCH_BACKEND", "RK_BENCH_SINGLE_DEVICE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--workload",
+           "plummer100k_f32", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["host"]["replicate_via"].startswith("rk_state_broadcast (RCCL")
+    assert d["n_gpus"] == 1 and d["value"] > 0 and abs(d["interactions_per_particle"] - 1218.45) < 1.0
+    assert d["host"]["pinned_equals_pageable"] and d["host"]["pinned_equals_device_resident"]
