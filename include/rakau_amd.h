@@ -342,14 +342,6 @@ RK_EXPORT int rk_cpu_engine_run(const rk_cpu_job *job);
  * the launch either. For tests and benchmarks. */
 RK_EXPORT int rk_set_kernel_variant(rk_state *s, int variant);
 
-/* Where the sources that ALL critical nodes of a supergroup (16 consecutive critical nodes) accept are evaluated:
- * 0 = by every member node in its own lane mapping (default), 1 = once per supergroup by a kernel of its own (k_common: 4
- * targets per lane on full lanes; the members start from its per-particle sums), -1 = as the environment says (RK_COMMON;
- * unset: 0). Mode 1 is slower on MI355X at every size and kept as a cross-check: the interaction
- * set is the same, the order in which a particle receives its contributions differs, so the mode belongs to the STATE, not to
- * a call -- every call on a state (full range, shards, either kernel) agrees bit for bit with every other. */
-RK_EXPORT int rk_set_common_eval(rk_state *s, int mode);
-
 #ifdef __cplusplus
 }
 #endif

@@ -65,6 +65,7 @@ def lib():
         L.orc_tree_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                       C.c_double, C.c_uint64, C.c_uint64, C.POINTER(C.c_int)]
         L.orc_tree_destroy.argtypes = [C.c_void_p]
+        L.orc_set_simd_width.argtypes = [C.c_int]
         L.orc_tree_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
         L.orc_tree_get_parts.argtypes = [C.c_void_p] + [C.c_void_p] * 8
         L.orc_tree_get_nodes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -104,6 +105,12 @@ class Rng:
         out = np.empty((ndim + 1) * n, dtype=dtype)
         _check(lib().orc_uniform_nd(ndim, _FP[np.dtype(dtype)], out.ctypes.data, n, float(size), self._h))
         return tuple(out[k * n:(k + 1) * n] for k in range(ndim + 1))
+
+
+def set_simd_width(w):
+    """Association of the node sums of octrees built from now on: 1 = the reference's scalar build (default), 4 / 8 / 16 = its
+    SIMD build with that batch size (tree.hpp:1134-1161: interleaved partial sums + horizontal add + scalar tail)."""
+    lib().orc_set_simd_width(int(w))
 
 
 class Tree:

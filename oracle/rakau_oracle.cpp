@@ -46,6 +46,8 @@ namespace
 {
 
 using u64 = std::uint64_t;
+// Width of the interleaved partial sums in compute_node_properties (orc_set_simd_width); 1 = scalar association.
+unsigned g_simd_width = 1;
 
 thread_local std::string g_last_error;
 
@@ -204,12 +206,41 @@ struct tree_t {
         }
     }
 
-    // Reference: tree.hpp:1116-1237 (compute_node_properties, scalar branch 1162-1168).
+    // Reference: tree.hpp:1116-1237 (compute_node_properties, scalar branch 1162-1168). With orc_set_simd_width(W > 1) the
+    // octree sums follow the association of the reference's SIMD branch (tree.hpp:1134-1161): W interleaved partial sums
+    // over the first size - size % W particles, added horizontally (pairwise, as xsimd::hadd does on AVX), then the scalar
+    // tail -- the node properties a default (SIMD-enabled) build of the reference produces for batch_size = W.
     void compute_node_properties(node_t<F, ND> &node) const
     {
         const auto begin = node.begin, end = node.end;
         F tot_mass(0), com[ND] = {};
-        for (u64 i = begin; i < end; ++i) {
+        u64 i = begin;
+        const unsigned W = g_simd_width;
+        if (W > 1 && ND == 3) {
+            const u64 size = end - begin, vec_end = begin + (size - size % W);
+            F acc[ND + 1][16] = {};
+            for (; i < vec_end; i += W) {
+                for (unsigned l = 0; l < W; ++l) {
+                    const F mass = parts[ND][i + l];
+                    acc[ND][l] += mass;
+                    for (unsigned j = 0; j < ND; ++j) {
+                        acc[j][l] = std::fma(mass, parts[j][i + l], acc[j][l]);
+                    }
+                }
+            }
+            for (unsigned j = 0; j <= ND; ++j) {
+                for (unsigned w = 1; w < W; w <<= 1) {
+                    for (unsigned l = 0; l + w < W; l += 2 * w) {
+                        acc[j][l] += acc[j][l + w];
+                    }
+                }
+            }
+            tot_mass = acc[ND][0];
+            for (unsigned j = 0; j < ND; ++j) {
+                com[j] = acc[j][0];
+            }
+        }
+        for (; i < end; ++i) {
             const F mass = parts[ND][i];
             tot_mass += mass;
             for (unsigned j = 0; j < ND; ++j) {
@@ -991,6 +1022,13 @@ int orc_uniform_nd(int ndim, int fp, void *out, u64 n, double size, void *rng)
 int orc_uniform(int fp, void *out, u64 n, double size, void *rng)
 {
     return orc_uniform_nd(3, fp, out, n, size, rng);
+}
+
+// Association of the octree node sums of trees built from now on: 1 = the reference's scalar build (default), 4 / 8 / 16 =
+// its SIMD build with that batch size (see compute_node_properties). Process-wide; for the envelope test of the device builder.
+void orc_set_simd_width(int w)
+{
+    g_simd_width = (w == 4 || w == 8 || w == 16) ? static_cast<unsigned>(w) : 1u;
 }
 
 // mac: 0 = bh, 1 = bh_geom. box_size == 0 -> deduced. src: the ndim coordinate arrays followed by the masses.

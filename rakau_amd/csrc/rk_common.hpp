@@ -172,6 +172,7 @@ struct kparams {
     uint32_t out_sub; // value subtracted from the particle index when writing (compact output)
     const uint32_t *perm; // non-null: original-order output, results of Morton particle i go to out[perm[i]]
     unsigned long long *dbg; // diagnostic builds only (RK_STAMPS): per-section cycle totals
+    int mac;                 // RK_MAC_BH | RK_MAC_BH_GEOM (the list kernels read it at run time: one code object for both)
     int xcd_mode;            // block -> group-list mapping (see xcd_map_block)
     int any_rev;             // one-launch kernels: block i serves list entry n - 1 - i (class lists read backwards: R = 4 first)
     // Supergroup pre-pass (k_super): K consecutive target groups share the upper part of list building.
@@ -182,11 +183,6 @@ struct kparams {
     typename vt<F>::v4 *sup_common;
     uint32_t *sup_resid;
     uint2 *sup_cnt;
-    // Common lists evaluated once per supergroup (k_common, rk_kernels_common.hip; opt-in): sup_part[k * sup_part_stride + i]
-    // = sum over the supergroup's common sources for result k of Morton particle i (unscaled). Non-null: the members start
-    // the accumulators of their split 0 from it and ignore sup_common.
-    F *sup_part;
-    uint32_t sup_part_stride;
     // Split traversal (variant 4), see SL_SEG above.
     uint32_t *sl_idx;    // list segments
     uint32_t *sl_next;   // sl_next[s] = segment that continues segment s
@@ -320,13 +316,6 @@ struct rk_state {
     int64_t sup_b = 0, sup_e = 0; // supergroups [sup_b, sup_e) are valid for sup_mac (empty: nothing cached)
     hipEvent_t sup_ev = nullptr;  // recorded after the last k_super
     hipStream_t sup_stream = nullptr; // stream of the call that wrote / last used the cached lists
-    // Common lists evaluated once per supergroup (k_common, opt-in): per-particle partial sums, 4 x nparts values.
-    void *sup_part = nullptr;
-    int64_t sup_part_n = 0;  // particles the buffer was sized for
-    int common_mode = -1;    // rk_set_common_eval: -1 = environment (default: members), 0 = members, 1 = k_common
-    int sup_kind = 0;        // what the cached pre-pass output is: 0 = lists (k_super), 1 = residual lists + sums (k_common)
-    int sup_q = -1;          // ... and, for kind 1, the q and eps2 the sums were formed with
-    double sup_eps2 = 0.;
     int super_k = -1;      // -1 = not initialised (read RK_SUPER_K, default 8)
     // Split traversal (variant 4): list pool and control words, sized per call (grown, never shrunk, until the state goes).
     void *sl_idx = nullptr, *sl_next = nullptr, *sl_cnt = nullptr, *sl_ctl = nullptr, *sl_fb = nullptr;
@@ -383,9 +372,6 @@ void launch_pc(const rk_state &s, int q, const kparams<F> &p, const int64_t cls_
                const int64_t cls_end[n_classes], hipStream_t const streams[n_list_R], unsigned class_mask = ~0u);
 template <typename F>
 void launch_super(const rk_state &s, const kparams<F> &p, int64_t s_begin, int64_t s_end, hipStream_t stream);
-// The pre-pass that also evaluates the common list for all targets of the supergroup (rk_kernels_common.hip).
-template <typename F>
-void launch_common(const rk_state &s, int q, const kparams<F> &p, int64_t s_begin, int64_t s_end, hipStream_t stream);
 // Split traversal (rk_kernels_split.hip): list building for the critical nodes [g_begin, g_end), dense evaluation per class.
 template <typename F>
 void launch_lists(const rk_state &s, const kparams<F> &p, int64_t g_begin, int64_t g_end, hipStream_t stream);
@@ -403,7 +389,6 @@ bool exact_node_sums();
 void touch_kernels();
 void touch_list();
 void touch_pc();
-void touch_common();
 void touch_split();
 void touch_build();
 template <typename F>

@@ -63,10 +63,6 @@ __device__ __forceinline__ void list_node(const kparams<F> &P, lk_wave_lds<F> &L
 #pragma unroll
             for (int k = 0; k < NR; ++k) {
                 acc[r][k] = F(0);
-                // The supergroup's common sources were summed by the pre-pass (k_common): split 0 starts from there.
-                if (P.sup_part && sp_raw == 0 && valid) {
-                    acc[r][k] = P.sup_part[static_cast<size_t>(k) * P.sup_part_stride + tb + static_cast<uint32_t>(ts + r * TP)];
-                }
             }
         }
 
@@ -88,7 +84,7 @@ __device__ __forceinline__ void list_node(const kparams<F> &P, lk_wave_lds<F> &L
             const uint2 cnt = P.sup_cnt[sup_S];
             if ((cnt.y >> 31) == 0u) {
                 from_root = false;
-                sup_ncommon = P.sup_part ? 0u : cnt.x;
+                sup_ncommon = cnt.x;
                 sup_nresid = cnt.y;
             }
         }
@@ -301,7 +297,7 @@ __device__ __forceinline__ void list_node(const kparams<F> &P, lk_wave_lds<F> &L
             const bool anc = bt.active && bt.node <= cnode && cnode <= bt.node + bt.nch;
             const bool self = anc && bt.node == cnode;
             const bool test = bt.active && !anc;
-            const F mac_lh = mac_lhs<F>(MAC, bt.mp, mac_value);
+            const F mac_lh = mac_lhs<F>(MAC == RK_MAC_RT ? P.mac : MAC, bt.mp, mac_value);
 #ifdef RK_STAMPS
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             st_acc[6] += 1;
@@ -344,7 +340,7 @@ __device__ __forceinline__ void list_node(const kparams<F> &P, lk_wave_lds<F> &L
             bt.ra = rec->a;
             bt.rb = rec->b;
             const v4 com = bt.com;
-            const F mac_lh = mac_lhs<F>(MAC, bt.mp, mac_value);
+            const F mac_lh = mac_lhs<F>(MAC == RK_MAC_RT ? P.mac : MAC, bt.mp, mac_value);
             bool fail;
 #if RK_EXACT_TRANSPOSED
             if (!BIG && k * (7 * R + 3) < T * 7) {
@@ -710,7 +706,7 @@ __global__ void __launch_bounds__(256) k_super(const kparams<F> P, uint32_t s_be
         const v4 com = rec->com;
         const v2 mp = rec->mac;
         const uint32_t dfs = rec->dfs, nch = rec->nch, ra = rec->a, rb = rec->b;
-        const F mac_lh = mac_lhs<F>(MAC, mp, mac_value);
+        const F mac_lh = mac_lhs<F>(MAC == RK_MAC_RT ? P.mac : MAC, mp, mac_value);
         // Relation of the node's subtree [dfs, dfs + nch] to the members' span [c_first, c_last_end].
         const bool touches = dfs <= c_last_end && dfs + nch >= c_first;
         const bool common_anc = dfs < c_first && dfs + nch >= c_last_end;
@@ -754,11 +750,11 @@ void launch_super(const rk_state &s, const kparams<F> &p, int64_t s_begin, int64
         return;
     }
     const auto grid = static_cast<unsigned>((n + 3) / 4);
-    if (s.mac == RK_MAC_BH) {
-        hipLaunchKernelGGL((k_super<F, 0>), dim3(grid), dim3(256), 0, stream, p, static_cast<uint32_t>(s_begin),
+    if (RK_MAC_RUNTIME || s.mac == RK_MAC_BH) {
+        hipLaunchKernelGGL((k_super<F, mac_targ(0)>), dim3(grid), dim3(256), 0, stream, p, static_cast<uint32_t>(s_begin),
                            static_cast<uint32_t>(s_end));
     } else {
-        hipLaunchKernelGGL((k_super<F, 1>), dim3(grid), dim3(256), 0, stream, p, static_cast<uint32_t>(s_begin),
+        hipLaunchKernelGGL((k_super<F, mac_targ(1)>), dim3(grid), dim3(256), 0, stream, p, static_cast<uint32_t>(s_begin),
                            static_cast<uint32_t>(s_end));
     }
     RK_HIP(hipGetLastError());
@@ -792,12 +788,21 @@ static void launch_list_qm(const rk_state &s, const kparams<F> &p, const int64_t
             throw error(RK_ERUNTIME, "internal error: quadtree group in a lane-mapping class beyond RK_MAX_R");
         }
     };
-    go(std::integral_constant<int, 5>{}, 4);
+#if RK_MAX_R >= 5
+    go(std::integral_constant<int, 5>{}, 4); // (R = 5, 6: measured slower, only built when RK_MAX_R asks for them)
+#endif
     go(std::integral_constant<int, 3>{}, 2);
     go(std::integral_constant<int, 1>{}, 0);
     go(std::integral_constant<int, 2>{}, 1);
+#if RK_MAX_R >= 6
     go(std::integral_constant<int, 6>{}, 5);
+#endif
     go(std::integral_constant<int, 4>{}, 3);
+    for (int c = RK_MAX_R; c < big_class; ++c) {
+        if (ce[c] != cb[c] && ((class_mask >> c) & 1u)) {
+            throw error(RK_ERUNTIME, "internal error: target group in a lane-mapping class beyond RK_MAX_R");
+        }
+    }
 }
 
 template <typename F>
@@ -805,12 +810,12 @@ void launch_list(const rk_state &s, int q, const kparams<F> &p, const int64_t cb
                  const int64_t ce[n_classes], hipStream_t const streams[n_list_R], unsigned class_mask)
 {
     switch (q * 2 + s.mac) {
-        case 0: launch_list_qm<F, 0, 0>(s, p, cb, ce, streams, class_mask); break;
-        case 1: launch_list_qm<F, 0, 1>(s, p, cb, ce, streams, class_mask); break;
-        case 2: launch_list_qm<F, 1, 0>(s, p, cb, ce, streams, class_mask); break;
-        case 3: launch_list_qm<F, 1, 1>(s, p, cb, ce, streams, class_mask); break;
-        case 4: launch_list_qm<F, 2, 0>(s, p, cb, ce, streams, class_mask); break;
-        case 5: launch_list_qm<F, 2, 1>(s, p, cb, ce, streams, class_mask); break;
+        case 0: launch_list_qm<F, 0, mac_targ(0)>(s, p, cb, ce, streams, class_mask); break;
+        case 1: launch_list_qm<F, 0, mac_targ(1)>(s, p, cb, ce, streams, class_mask); break;
+        case 2: launch_list_qm<F, 1, mac_targ(0)>(s, p, cb, ce, streams, class_mask); break;
+        case 3: launch_list_qm<F, 1, mac_targ(1)>(s, p, cb, ce, streams, class_mask); break;
+        case 4: launch_list_qm<F, 2, mac_targ(0)>(s, p, cb, ce, streams, class_mask); break;
+        case 5: launch_list_qm<F, 2, mac_targ(1)>(s, p, cb, ce, streams, class_mask); break;
         default: throw error(RK_EINVAL, "invalid q / mac combination");
     }
     RK_HIP(hipGetLastError());
@@ -826,17 +831,25 @@ void launch_list_any(const rk_state &s, int q, const kparams<F> &p, const uint32
     const dim3 grid(static_cast<unsigned>(n)), block(64);
     const int cnt = static_cast<int>(n);
     auto go = [&](auto Qt, auto Mt) {
-        constexpr int Q = decltype(Qt)::value, M = decltype(Mt)::value;
+        constexpr int Q = decltype(Qt)::value, M = mac_targ(decltype(Mt)::value);
         if (s.ndim == 3 || !RK_QUAD_BODY) {
             if (rmax >= 4) {
                 hipLaunchKernelGGL((k_list_any<F, Q, M, 3, 4>), grid, block, 0, stream, p, list, cnt);
             } else {
+#ifdef RK_ANY_RMAX3
                 hipLaunchKernelGGL((k_list_any<F, Q, M, 3, 3>), grid, block, 0, stream, p, list, cnt);
+#else
+                throw error(RK_EINVAL, "k_list_any for R <= 3 (RK_ANY=4, an experiment of round 3) is only in builds with -DRK_ANY_RMAX3");
+#endif
             }
         } else if (rmax >= 4) {
             hipLaunchKernelGGL((k_list_any<F, Q, M, 2, 4>), grid, block, 0, stream, p, list, cnt);
         } else {
+#ifdef RK_ANY_RMAX3
             hipLaunchKernelGGL((k_list_any<F, Q, M, 2, 3>), grid, block, 0, stream, p, list, cnt);
+#else
+            throw error(RK_EINVAL, "k_list_any for R <= 3 (RK_ANY=4, an experiment of round 3) is only in builds with -DRK_ANY_RMAX3");
+#endif
         }
     };
     using i0 = std::integral_constant<int, 0>;
@@ -867,7 +880,7 @@ void launch_list_big(const rk_state &s, int q, const kparams<F> &p, const uint32
     const dim3 grid(static_cast<unsigned>(n)), block(64 * LK_BIG_WPB);
     const int cnt = static_cast<int>(n);
     auto go = [&](auto Qt, auto Mt) {
-        constexpr int Q = decltype(Qt)::value, M = decltype(Mt)::value;
+        constexpr int Q = decltype(Qt)::value, M = mac_targ(decltype(Mt)::value);
         if (s.ndim == 3 || !RK_QUAD_BODY) {
             hipLaunchKernelGGL((k_list<F, Q, M, 2, 3, true>), grid, block, 0, stream, p, list, cnt, n_dev);
         } else {
@@ -902,7 +915,7 @@ template void launch_list<double>(const rk_state &, int, const kparams<double> &
 void touch_list()
 {
     hipFuncAttributes attr{};
-    RK_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_super<float, 0>)));
+    RK_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_super<float, mac_targ(0)>)));
 }
 
 } // namespace rk

@@ -91,10 +91,6 @@ __device__ __forceinline__ void pc_node(const kparams<F> &P, pc_lds<F> &L, const
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
             acc[0][k] = F(0);
-            // The supergroup's common sources were summed by the pre-pass (k_common): split 0 starts from there.
-            if (P.sup_part && sp_raw == 0 && tidx[0] >= 0) {
-                acc[0][k] = P.sup_part[static_cast<size_t>(k) * P.sup_part_stride + tb + static_cast<uint32_t>(tidx[0])];
-            }
         }
         // n / NS for n <= SRC_CAP without a division per tile: exact for n * NS < 2^16.
         const int inv_ns = (65536 + NS - 1) / NS;
@@ -207,7 +203,7 @@ __device__ __forceinline__ void pc_node(const kparams<F> &P, pc_lds<F> &L, const
         const uint2 cnt = P.sup_cnt[sup_S];
         if ((cnt.y >> 31) == 0u) {
             from_root = false;
-            sup_ncommon = P.sup_part ? 0u : cnt.x;
+            sup_ncommon = cnt.x;
             sup_nresid = cnt.y;
         }
     }
@@ -402,7 +398,7 @@ __device__ __forceinline__ void pc_node(const kparams<F> &P, pc_lds<F> &L, const
         const bool anc = bt.active && bt.node <= cnode && cnode <= bt.node + bt.nch;
         const bool self = anc && bt.node == cnode;
         const bool test = bt.active && !anc;
-        const F mac_lh = mac_lhs<F>(MAC, bt.mp, mac_value);
+        const F mac_lh = mac_lhs<F>(MAC == RK_MAC_RT ? P.mac : MAC, bt.mp, mac_value);
         const F bx = rk_max3(blo.x - com.x, com.x - bhi.x, F(0)), by = rk_max3(blo.y - com.y, com.y - bhi.y, F(0)),
                 bz = rk_max3(blo.z - com.z, com.z - bhi.z, F(0));
         const F dbox2 = rk_fma(bz, bz, rk_fma(by, by, bx * bx));
@@ -426,7 +422,7 @@ __device__ __forceinline__ void pc_node(const kparams<F> &P, pc_lds<F> &L, const
         n_uq -= k;
         load_rec(bt);
         const v4 com = bt.com;
-        const F mac_lh = mac_lhs<F>(MAC, bt.mp, mac_value);
+        const F mac_lh = mac_lhs<F>(MAC == RK_MAC_RT ? P.mac : MAC, bt.mp, mac_value);
         bool fail;
         if (k * (7 * R + 3) < T * 7) {
             // Few candidates: lane = target (every lane keeps R targets of the group in registers; unused slots repeat
@@ -635,7 +631,7 @@ void launch_pc_any(const rk_state &s, int q, const kparams<F> &p, const uint32_t
     const dim3 grid(static_cast<unsigned>(n)), block(64 * 5);
     const int cnt = static_cast<int>(n);
     auto go = [&](auto Qt, auto Mt) {
-        constexpr int Q = decltype(Qt)::value, M = decltype(Mt)::value;
+        constexpr int Q = decltype(Qt)::value, M = mac_targ(decltype(Mt)::value);
         if (s.ndim == 3 || !RK_QUAD_BODY) {
             hipLaunchKernelGGL((k_pc_any<F, Q, M, 3>), grid, block, 0, stream, p, list, cnt);
         } else {
@@ -669,12 +665,12 @@ void launch_pc(const rk_state &s, int q, const kparams<F> &p, const int64_t cb[n
         }
     }
     switch (q * 2 + s.mac) {
-        case 0: launch_pc_qm<F, 0, 0>(s, p, cb, ce, streams, class_mask); break;
-        case 1: launch_pc_qm<F, 0, 1>(s, p, cb, ce, streams, class_mask); break;
-        case 2: launch_pc_qm<F, 1, 0>(s, p, cb, ce, streams, class_mask); break;
-        case 3: launch_pc_qm<F, 1, 1>(s, p, cb, ce, streams, class_mask); break;
-        case 4: launch_pc_qm<F, 2, 0>(s, p, cb, ce, streams, class_mask); break;
-        case 5: launch_pc_qm<F, 2, 1>(s, p, cb, ce, streams, class_mask); break;
+        case 0: launch_pc_qm<F, 0, mac_targ(0)>(s, p, cb, ce, streams, class_mask); break;
+        case 1: launch_pc_qm<F, 0, mac_targ(1)>(s, p, cb, ce, streams, class_mask); break;
+        case 2: launch_pc_qm<F, 1, mac_targ(0)>(s, p, cb, ce, streams, class_mask); break;
+        case 3: launch_pc_qm<F, 1, mac_targ(1)>(s, p, cb, ce, streams, class_mask); break;
+        case 4: launch_pc_qm<F, 2, mac_targ(0)>(s, p, cb, ce, streams, class_mask); break;
+        case 5: launch_pc_qm<F, 2, mac_targ(1)>(s, p, cb, ce, streams, class_mask); break;
         default: throw error(RK_EINVAL, "invalid q / mac combination");
     }
     RK_HIP(hipGetLastError());
@@ -689,7 +685,7 @@ template void launch_pc<double>(const rk_state &, int, const kparams<double> &, 
 void touch_pc()
 {
     hipFuncAttributes attr{};
-    RK_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_pc<float, 0, 0, 2, 3>)));
+    RK_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_pc<float, 0, mac_targ(0), 2, 3>)));
 }
 
 } // namespace rk

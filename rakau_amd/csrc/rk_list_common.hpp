@@ -57,8 +57,25 @@
 #endif
 
 
+// RK_MAC_RUNTIME=1 instantiates the list and producer / consumer kernels once, with RK_MAC_RT: the criterion is then read
+// from kparams::mac at run time (a wave-uniform select in mac_lhs(), twice per batch of 64 candidates). Same arithmetic per
+// criterion, hence the same bits, and half the code objects (-4 MB of library) -- but NOT the default: the R = 1 and R = 3 list
+// kernels then spill 8 more bytes per lane (28 / 32 instead of 20 / 24; they are compiled at the 72 / 80-register cliff), which
+// leaves results-in-HBM calls unchanged and makes calls whose epilogue stores cross PCIe (host outputs) 1.5-2 % slower
+// (4M: 2.36-2.39 against 2.32-2.33 ms, same box, tools/jobs_r04/r04_job7.sh, r04_job11.sh).
+#ifndef RK_MAC_RUNTIME
+#define RK_MAC_RUNTIME 0
+#endif
+
 namespace rk
 {
+
+constexpr int RK_MAC_RT = -1;
+// Template argument the launchers instantiate for a state's criterion.
+constexpr int mac_targ(int mac)
+{
+    return RK_MAC_RUNTIME ? RK_MAC_RT : mac;
+}
 
 #ifdef RK_STAMPS
 // Diagnostic build: wave-lifetime cycles per section (s_memtime), summed over waves into P.dbg[].

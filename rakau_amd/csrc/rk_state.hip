@@ -1,5 +1,6 @@
 // Host side of the rakau_amd C ABI: state creation / replication and the acc_pot entry points.
 #include "rk_common.hpp"
+#include "rk_xcheck.hpp"
 
 #include <dlfcn.h>
 #include <functional>
@@ -191,7 +192,7 @@ void free_state(rk_state *s)
     (void)hipGetDevice(&prev);
     (void)hipSetDevice(phys(s->device));
     release_tree(s);
-    for (void *b : {s->d_out, s->sup_common, s->sup_resid, s->sup_cnt, s->sup_part, s->z_scratch, s->sl_idx, s->sl_next,
+    for (void *b : {s->d_out, s->sup_common, s->sup_resid, s->sup_cnt, s->z_scratch, s->sl_idx, s->sl_next,
                     s->sl_cnt, s->sl_ctl, s->sl_fb, s->sl_pbase, s->sl_part}) {
         rk::pool_free(b);
     }
@@ -685,6 +686,7 @@ rk::kparams<F> base_params(const rk_state &s, double mac_value, double G, double
     p.mac_value = static_cast<F>(mac_value);
     p.eps2 = static_cast<F>(eps2);
     p.G = static_cast<F>(G);
+    p.mac = s.mac;
     return p;
 }
 
@@ -1057,28 +1059,6 @@ bool prepare_split(rk_state &s, rk::kparams<F> &p, int64_t p_begin, int64_t p_en
     return !(s.sl_clean_valid && s.sl_clean_key == key);
 }
 
-// Whether the common lists of this tree's supergroups are evaluated once per supergroup (k_common) instead of by every
-// member. A property of the STATE, never of a call: the sums are formed in a different (fixed) order, so every call on a
-// state -- full range, shards, either kernel -- must take the same path for their results to agree bit for bit. Off unless
-// rk_set_common_eval(state, 1) or RK_COMMON=1 asks for it (RK_COMMON_MIN_GROUPS=<n>: for trees of at least n critical
-// nodes): measured slower at every size.
-bool common_eval(const rk_state &s)
-{
-    static const int env_mode = [] {
-        const char *e = std::getenv("RK_COMMON");
-        return e ? std::atoi(e) : -1;
-    }();
-    static const int64_t min_groups = [] {
-        const char *e = std::getenv("RK_COMMON_MIN_GROUPS");
-        return e ? std::atoll(e) : int64_t(-1);
-    }();
-    if (s.super_k <= 0 || s.n_crit <= 0) {
-        return false;
-    }
-    const int mode = s.common_mode >= 0 ? s.common_mode : env_mode;
-    return mode >= 0 ? mode != 0 : (min_groups >= 0 && s.n_crit >= min_groups);
-}
-
 // Streams, events and the supergroup scratch a traversal call needs. Created with the state (so that the first call does not
 // pay for them: 166 MB of scratch at 4M) and checked again by every call (a rebuilt tree may have more critical nodes).
 template <typename F>
@@ -1109,15 +1089,6 @@ void ensure_call_resources(rk_state &s)
             s.sup_resid = rk::pool_alloc(static_cast<size_t>(n_super) * rk::SUP_CAPR * sizeof(uint32_t));
             s.sup_cnt = rk::pool_alloc(static_cast<size_t>(n_super) * sizeof(uint2));
             s.sup_alloc = n_super;
-        }
-        if (common_eval(s) && s.sup_part_n < s.nparts) {
-            RK_HIP(hipDeviceSynchronize());
-            rk::pool_free(s.sup_part);
-            s.sup_part = nullptr;
-            s.sup_part_n = 0;
-            s.sup_b = s.sup_e = 0;
-            s.sup_part = rk::pool_alloc(static_cast<size_t>(s.nparts) * 4 * sizeof(F));
-            s.sup_part_n = s.nparts;
         }
     }
     // Side streams / events of the fork-join (created once, outside any capture).
@@ -1246,8 +1217,6 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
     p.sup_common = nullptr;
     p.sup_resid = nullptr;
     p.sup_cnt = nullptr;
-    p.sup_part = nullptr;
-    p.sup_part_stride = 0;
     if (v2) {
         // Supergroup pre-pass: K consecutive groups share the upper part of list building (RK_SUPER_K=0 disables).
         if (s.super_k > 0 && s.n_crit > 0) {
@@ -1338,23 +1307,10 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
         }
         // Variant 4 (and the automatic variant unless RK_SPLIT=0): list building and dense evaluation as two kernels.
         const bool split = g_hi > g_lo && (s.variant == 4 || (s.variant == 0 && split_default()));
-        // The pre-pass evaluates the common lists itself (a property of the tree, see common_eval()); the split traversal
-        // reads the lists, so it keeps the plain pre-pass.
-        const bool eval = p.super_k != 0u && !split && s.variant != 4 && common_eval(s) && s.sup_part;
-        if (eval) {
-            p.sup_part = static_cast<F *>(s.sup_part);
-            p.sup_part_stride = static_cast<uint32_t>(s.sup_part_n);
-        }
-        // What the scratch holds is reusable if it is of the same kind -- and, for sums, formed with the same q and eps2.
-        const bool same_kind = eval ? (s.sup_kind == 1 && s.sup_q == q && s.sup_eps2 == eps2) : s.sup_kind == 0;
-        const bool need_super
-            = se > sb && !(sup_cache && same_kind && s.sup_mac == mac_value && s.sup_b <= sb && se <= s.sup_e);
+        const bool need_super = se > sb && !(sup_cache && s.sup_mac == mac_value && s.sup_b <= sb && se <= s.sup_e);
         ran_super = need_super;
         if (se > sb) {
             s.sup_stream = stream;
-        }
-        if (need_super && !same_kind) {
-            s.sup_b = s.sup_e = 0; // nothing of the other kind survives
         }
         bool split_fb = false;
         if (split) {
@@ -1453,9 +1409,6 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
         auto enqueue = [&](hipStream_t st, bool capturing) {
             if (need_super) {
                 rk::launch_super<F>(s, p, sb, se, st);
-                if (eval) {
-                    rk::launch_common<F>(s, q, p, sb, se, st);
-                }
             }
             if (split) {
                 RK_HIP(hipMemsetAsync(s.sl_ctl, 0, 8 * sizeof(uint32_t), st));
@@ -1567,7 +1520,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
             rk_state::graph_key key{};
             key.q = q, key.p_begin = p_begin, key.p_end = p_end, key.mac_value = mac_value, key.G = G, key.eps2 = eps2;
             key.offset_output = offset_output, key.super_k = s.super_k, key.variant = s.variant;
-            key.with_super = (need_super ? 1 : 0) | (eval ? 2 : 0);
+            key.with_super = need_super ? 1 : 0;
             key.pad = split ? (split_fb ? 2 : 1) : 0;
             for (int k = 0; k < rk::nres_of(q); ++k) {
                 key.out[k] = d_out[k];
@@ -1621,7 +1574,6 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
         } else if (!(s.sup_mac == mac_value && s.sup_b <= sb2 && se2 <= s.sup_e)) {
             s.sup_mac = mac_value, s.sup_b = sb2, s.sup_e = se2;
         }
-        s.sup_kind = p.sup_part ? 1 : 0, s.sup_q = q, s.sup_eps2 = eps2;
         (void)ran_super; // (a call on another stream synchronises with sup_stream before it reuses or extends the lists)
     }
     // Every event record is a barrier packet between this call and the next one on the stream (~10 us each on the GPU):
@@ -1782,7 +1734,6 @@ int rk_init(int device)
         rk::touch_kernels();
         rk::touch_list();
         rk::touch_pc();
-        rk::touch_common();
         rk::touch_split();
         rk::touch_build();
         rk::pool_free(rk::pool_alloc(size_t(1) << 20));
@@ -3074,23 +3025,10 @@ int rk_set_kernel_variant(rk_state *s, int variant)
         if (!s || variant < 0 || variant > 4) {
             throw rk::error(RK_EINVAL, "invalid kernel variant");
         }
+        if (variant == 1 || variant == 4) {
+            (void)rk::xcheck(); // the cross-check kernels live in librakau_amd_xcheck.so: load it now, or say why not
+        }
         s->variant = variant;
-    });
-}
-
-int rk_set_common_eval(rk_state *s, int mode)
-{
-    return guard([&] {
-        if (!s || mode < -1 || mode > 1) {
-            throw rk::error(RK_EINVAL, "invalid mode: -1 (automatic), 0 (members evaluate the common lists) or 1 (pre-pass)");
-        }
-        if (s->common_mode != mode) {
-            device_guard dg(s->device);
-            RK_HIP(hipDeviceSynchronize());
-            s->common_mode = mode;
-            s->sup_b = s->sup_e = 0;
-            ensure_call_resources_any(*s);
-        }
     });
 }
 

@@ -207,10 +207,6 @@ class State:
     def set_variant(self, v):
         _capi.check(_capi.lib().rk_set_kernel_variant(self._h, v))
 
-    def set_common_eval(self, mode):
-        """rk_set_common_eval: -1 automatic, 0 the member nodes evaluate their supergroup's common sources, 1 the pre-pass."""
-        _capi.check(_capi.lib().rk_set_common_eval(self._h, mode))
-
     def acc_pot(self, q, mac_value, G=1.0, eps2=0.0, p_begin=0, p_end=None, out=None, offset_output=True):
         """rocm_state::acc_pot<Q>: host outputs (numpy). Returns the list of output arrays. Arrays in pinned memory
         (pinned_empty()) are written by the kernels directly."""

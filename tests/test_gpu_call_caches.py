@@ -91,7 +91,7 @@ np.savez(sys.argv[1], **res)
     for name, extra in (("plain", {"RK_PLAN": "0"}), ("tail", {"RK_PLAN_MAX_GROUPS": "64"}),
                         ("tail_chunks", {"RK_PLAN_MAX_GROUPS": "64", "RK_PLAN_REGIONS": "0"}),
                         ("heavy_first_auto", {}), ("pc_any", {"RK_ANY": "1"}), ("list_any", {"RK_ANY": "3"}),
-                        ("pc_r2_list_any", {"RK_ANY": "2"}), ("list_r4_list_any", {"RK_ANY": "4"}),
+                        ("pc_r2_list_any", {"RK_ANY": "2"}),
                         ("class_launches", {"RK_ANY": "0"}),
                         # calls without a plan: one launch over the class lists read backwards (full range), forced both ways, off
                         ("first_pc_any", {"RK_PLAN": "0", "RK_ANY": "1"}), ("first_list_any", {"RK_PLAN": "0", "RK_ANY": "3"}),

@@ -133,8 +133,40 @@ def test_build_time_4m():
     # (fp32 coordinates of magnitude ~2000 carry ~1e-4 of absolute rounding in a centre of mass, whichever order the
     # particles are summed in: near-field monopoles move by ~1e-4 relative.)
     # Measured envelope of the DEFAULT (child -> parent) sums: max 2.7e-3, 515 particles above 1e-4; rk_set_build_exact(1)
-    # removes the difference altogether (test_exact_build_4m_census_and_time).
+    # removes the difference altogether (test_exact_build_4m_census_and_time). The bound is the envelope the reference's own
+    # two builds show against each other on the same inputs: test_reference_simd_build_vs_scalar_build_envelope_4m below.
     assert np.median(e) < 1e-5 and e.max() < 5e-3 and n_off < 1000
+
+
+def test_reference_simd_build_vs_scalar_build_envelope_4m():
+    """The other half of the argument for the bound above. The reference's DEFAULT build sums a node's particles as
+    batch_size interleaved partial sums, added horizontally, plus a scalar tail (tree.hpp:1134-1161); its scalar build
+    (RAKAU_DISABLE_SIMD, the flavour the oracle restates and the host builder reproduces bit for bit) adds them one after the
+    other (1162-1168). The two give centres of mass that differ by rounding, which flips a handful of the 1.5e8 MAC decisions
+    of the 4M step -- exactly what the device builder's child -> parent sums do. Here the SAME 4M inputs are built with both
+    associations (oracle.set_simd_width(8) = AVX2, 16 = AVX-512) and traversed on the GPU: the SIMD-flavoured trees sit in
+    the same envelope against the scalar-flavoured one as the device-built tree does (max < 5e-3, fewer than 1000 of 4M
+    particles above 1e-4, median at rounding level), so no bound tighter than that separates "built differently" from
+    "built wrongly" -- and rk_set_build_exact(1) exists for callers who need the scalar flavour's bits."""
+    from bench import plummer_numpy
+    m, x, y, z = plummer_numpy(4_000_000, "float32")
+    mv = rakau_amd.mac_value_of(0.75, "bh", np.float32)
+    res = {}
+    try:
+        for w in (1, 8, 16):
+            oracle.set_simd_width(w)
+            ot = oracle.Tree(x, y, z, m)
+            st = state_from_oracle(ot)
+            res[w] = (st.acc_pot(0, mv), ot.n_nodes, st.n_crit)
+            del st, ot
+    finally:
+        oracle.set_simd_width(1)
+    for w in (8, 16):
+        assert res[w][1:] == res[1][1:]  # same topology, same critical nodes: only node properties differ
+        e = rel_err_vec(res[w][0], res[1][0])
+        n_off = int((e > 1e-4).sum())
+        print("reference association, batch size %d vs scalar: median %.2e, max %.2e, particles above 1e-4: %d" % (w, np.median(e), e.max(), n_off))
+        assert 0 < e.max() < 5e-3 and np.median(e) < 1e-5 and n_off < 1000
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
