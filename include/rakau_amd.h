@@ -339,8 +339,16 @@ RK_EXPORT int rk_cpu_engine_run(const rk_cpu_job *job);
  * node), 3 = producer / consumer waves per critical node, 4 = split traversal (list building and dense evaluation as two
  * kernels, the lists in HBM; slower, kept as a cross-check). 2 and 3 give bit-identical results (same interaction lists,
  * same summation order); 1 sums in the CPU engine's order, 4 in a breadth-first order of its own that does not depend on
- * the launch either. For tests and benchmarks. */
+ * the launch either. Variants 1 and 4 are not part of librakau_amd.so: selecting one loads librakau_amd_xcheck.so from the
+ * same directory (RK_ERUNTIME if it is not there). For tests and benchmarks. */
 RK_EXPORT int rk_set_kernel_variant(rk_state *s, int variant);
+
+/* Diagnostics of the hipGraph replay of repeated rk_acc_pot_device() calls: stats[0] = calls replayed from a cached executable
+ * graph, [1] = calls that captured their launch sequence (a signature seen before), [2] = calls launched directly, [3] = captures
+ * that re-targeted a parked executable (hipGraphExecUpdate) instead of instantiating a new one, [4] = executable graphs the state
+ * holds now (at most RK_GRAPH_CACHE = 8, least recently used evicted), [5] = executables with parallel branches alive in the
+ * process (never destroyed; at most RK_GRAPH_FORKED_MAX = 64). */
+RK_EXPORT int rk_state_graph_stats(const rk_state *s, int64_t stats[6]);
 
 #ifdef __cplusplus
 }

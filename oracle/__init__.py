@@ -141,7 +141,10 @@ class Tree:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().orc_tree_destroy(self._h)
+            try:
+                lib().orc_tree_destroy(self._h)
+            except TypeError:  # interpreter shutdown: the module globals are gone already
+                pass
             self._h = None
 
     def parts_u(self):

@@ -27,7 +27,7 @@ SYMBOLS = [
     "rk_state_tree_info", "rk_state_download", "rk_state_build_device", "rk_state_set_perm", "rk_state_device_ptr",
     "rk_state_rebuild_device", "rk_pool_trim", "rk_set_build_exact", "rk_cpu_engine_run", "rk_group_work", "rk_state_create_nd", "rk_state_build_nd",
     "rk_state_ndim", "rk_host_alloc", "rk_host_free", "rk_state_set_timing", "rk_state_clone_all", "rk_comm_unique_id",
-    "rk_comm_init", "rk_comm_destroy", "rk_state_broadcast", "rk_init",
+    "rk_comm_init", "rk_comm_destroy", "rk_state_broadcast", "rk_init", "rk_state_graph_stats",
     # host-side tree builder (include/rakau_amd_tree.h)
     "rk_tree_create", "rk_tree_create_nd", "rk_tree_destroy", "rk_tree_info", "rk_tree_get", "rk_tree_nodes", "rk_tree_state",
     "rk_tree_acc_pot", "rk_tree_exact", "rk_tree_update_particles", "rk_tree_cpu_acc_pot",
@@ -94,6 +94,7 @@ def lib():
     L.rk_comm_destroy.argtypes = [vp]
     L.rk_state_broadcast.argtypes = [C.POINTER(vp), ci, ci, ci, vp, vp]
     L.rk_set_kernel_variant.argtypes = [vp, ci]
+    L.rk_state_graph_stats.argtypes = [vp, C.POINTER(i64)]
     L.rk_device_memcpy.argtypes = [vp, vp, i64, ci]
     L.rk_count_interactions.argtypes = [vp, i64, i64, dbl, C.POINTER(u64)]
     L.rk_state_build.argtypes = [C.POINTER(vp), ci, ci, ci, C.POINTER(vp), i64, dbl, u64, u64]

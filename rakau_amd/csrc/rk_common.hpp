@@ -279,11 +279,18 @@ struct rk_state {
         void *out[4];
         const void *perm; // permutation buffer the ordered epilogue reads (null: Morton-order output)
     };
-    graph_key gkey{};
-    graph_key last_key{}; // key of the previous call: a graph is only captured when a call repeats
-    bool have_last_key = false;
-    hipGraphExec_t graph_exec = nullptr;
-    bool graph_exec_forked = false; // the captured sequence has parallel branches (such executable graphs are never destroyed)
+    // Executable graphs of the launch sequences this state has been asked for more than once, most recently used last
+    // (at most RK_GRAPH_CACHE = 8): a caller that alternates among a few signatures -- accs_u then pots_u, several ranges --
+    // keeps replaying all of them. Every entry holds the launch plan its sequence was captured with (the kernels of a planned
+    // call read the plan's list buffer, so that buffer lives as long as the graph).
+    struct graph_entry {
+        graph_key key;
+        hipGraphExec_t exec;
+        bool forked; // the captured sequence has parallel branches (such executables are never destroyed, see rk_state.hip)
+    };
+    std::vector<graph_entry> gcache;
+    std::vector<graph_key> seen_keys; // signatures of the last calls (a graph is captured when one recurs)
+    uint64_t graph_stats[4] = {};     // replays, captures (instantiated or re-targeted), direct launches, re-targeted executables
     hipStream_t cap_stream = nullptr;
     bool timed = false;  // the last call recorded ev0 / ev1
     bool timing = true;  // rk_state_set_timing
@@ -299,6 +306,7 @@ struct rk_state {
         int64_t p_begin = -1, p_end = -1;
         double mac_value = 0.;
         void *d_lists = nullptr;
+        std::shared_ptr<void> hold; // owns d_lists (shared with the cached graphs captured on this plan; never rewritten while shared)
         int64_t alloc = 0; // entries allocated
         int64_t off[rk::n_classes + 1] = {};
         // Heavy-first plans also carry merged lists for the one-launch kernels (k_pc_any / k_list_any): the wave-kernel
@@ -306,6 +314,7 @@ struct rk_state {
         int64_t off_all = 0, n_all = 0, off_oth = 0, n_oth = 0, off_123 = 0, n_123 = 0;
         bool all_padded = false; // the merged list is a light-tail arrangement (interleaved per-XCD queues with padding)
     } plan;
+    std::vector<launch_plan> gcache_plan; // gcache_plan[i]: the plan gcache[i] was captured with (d_lists null: none)
     std::vector<uint64_t> work_cache; // launch-plan weight of every critical node (its size; empty: not computed)
     // Scratch of the supergroup pre-pass (allocated on first use).
     void *sup_common = nullptr, *sup_resid = nullptr, *sup_cnt = nullptr;
@@ -337,8 +346,11 @@ struct rk_state {
     };
     sl_key sl_rep_key, sl_clean_key;    // call whose report is in flight / call known to need no fallback launch
     bool sl_rep_pending = false, sl_clean_valid = false;
-    sl_key plan_key;                    // (range, MAC value) of the previous call: a launch plan is built when a call repeats
-    bool have_plan_key = false;
+    // ... and the form that call ran in (one wave per node / per part, pool sizes): a clean report only vouches for calls in
+    // the same form with pools at least as large.
+    int sl_rep_mode = 0, sl_clean_mode = 0;
+    int64_t sl_rep_npart = 0, sl_rep_nseg = 0, sl_clean_npart = 0, sl_clean_nseg = 0;
+    std::vector<sl_key> plan_keys;      // (range, MAC value) of the last calls: a launch plan is built when one recurs
     // Filled by the device-side tree build (rk_state_build); null for states created from a host tree.
     void *bld_codes = nullptr;     // uint64 sorted Morton codes [nparts]
     void *bld_perm = nullptr;      // uint32 original index of the particle at Morton position i [nparts]

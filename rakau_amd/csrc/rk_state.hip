@@ -18,6 +18,7 @@
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <atomic>
@@ -56,8 +57,9 @@ const bool g_crash_handler_installed = [] {
 // destroy; never when they are kept; never with linear graphs -- profiles/r03/graph_destroy_crash.txt). They are parked until
 // the process ends instead, and only RK_GRAPH_FORKED_MAX (64) of them are ever made per process: after that, forked
 // sequences are launched directly (1-4 % slower between 2M and 6M particles). RK_GRAPH_FORKED=0: never capture them.
+int phys(int device);
 std::atomic<int> g_forked_execs{0};
-bool forked_capture_allowed()
+int forked_cap()
 {
     static const int cap = [] {
         const char *e = std::getenv("RK_GRAPH_FORKED"), *m = std::getenv("RK_GRAPH_FORKED_MAX");
@@ -66,15 +68,60 @@ bool forked_capture_allowed()
         }
         return m ? std::max(std::atoi(m), 0) : 64;
     }();
-    return g_forked_execs.load(std::memory_order_relaxed) < cap;
+    return cap;
 }
+// Forked executables nobody uses any more (their state went away, its tree was rebuilt, the cache evicted them), per
+// physical device. They are not destroyed -- see above -- but RE-TARGETED: a new forked capture first tries
+// hipGraphExecUpdate() on one of them (same topology -- pre-pass, fork, the class kernels, join -- with other kernel
+// arguments), so a long-lived process that keeps meeting new signatures keeps replaying graphs without the number of
+// executables growing (RK_GRAPH_UPDATE=0: never re-target; the cap then ends replay as in round 3).
+std::mutex g_parked_mtx;
+std::map<int, std::vector<hipGraphExec_t>> g_parked;
+bool graph_update_enabled()
+{
+    static const bool on = [] {
+        const char *e = std::getenv("RK_GRAPH_UPDATE");
+        return !(e && std::atoi(e) == 0);
+    }();
+    return on;
+}
+bool forked_capture_allowed(int phys_dev)
+{
+    if (forked_cap() == 0) {
+        return false;
+    }
+    if (g_forked_execs.load(std::memory_order_relaxed) < forked_cap()) {
+        return true;
+    }
+    if (!graph_update_enabled()) {
+        return false;
+    }
+    std::lock_guard<std::mutex> lk(g_parked_mtx);
+    const auto it = g_parked.find(phys_dev);
+    return it != g_parked.end() && !it->second.empty();
+}
+void retire_graph_exec(int phys_dev, hipGraphExec_t exec, bool forked)
+{
+    if (!exec) {
+        return;
+    }
+    if (!forked) {
+        (void)hipGraphExecDestroy(exec);
+        return;
+    }
+    std::lock_guard<std::mutex> lk(g_parked_mtx);
+    g_parked[phys_dev].push_back(exec);
+}
+// Forget every cached graph of the state (its buffers are about to change or go away). The caller has synchronised the
+// device if a replay may still be in flight.
 void drop_graph_exec(rk_state &s)
 {
-    if (s.graph_exec && !s.graph_exec_forked) {
-        (void)hipGraphExecDestroy(s.graph_exec);
+    for (auto &e : s.gcache) {
+        retire_graph_exec(phys(s.device), e.exec, e.forked);
     }
-    s.graph_exec = nullptr;
-    s.graph_exec_forked = false;
+    s.gcache.clear();
+    s.gcache_plan.clear();
+    s.seen_keys.clear();
 }
 
 // -1: not set (the environment variable RK_BUILD_EXACT decides, default off).
@@ -169,16 +216,15 @@ void release_tree(rk_state *s)
         s->buf[i] = nullptr;
         s->buf_bytes[i] = 0;
     }
-    for (void **b : {&s->bld_codes, &s->bld_perm, &s->bld_node_code, &s->plan.d_lists}) {
+    for (void **b : {&s->bld_codes, &s->bld_perm, &s->bld_node_code}) {
         rk::pool_free(*b);
         *b = nullptr;
     }
-    s->plan = rk_state::launch_plan{};
+    drop_graph_exec(*s);                 // (releases the plans the cached graphs hold)
+    s->plan = rk_state::launch_plan{}; // the device was synchronised above: the buffer goes back to the pool
     s->work_cache.clear();
     s->sup_b = s->sup_e = 0;
-    drop_graph_exec(*s);
-    s->have_last_key = false;
-    s->have_plan_key = false;
+    s->plan_keys.clear();
     s->sl_rep_pending = false; // the device was synchronised above
     s->sl_clean_valid = false;
 }
@@ -892,12 +938,15 @@ void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64
             (pass == 0 ? s.plan.n_all : (pass == 1 ? s.plan.n_oth : s.plan.n_123)) = static_cast<int64_t>(lists.size()) - first;
         }
     }
-    if (s.plan.alloc < static_cast<int64_t>(lists.size())) {
-        RK_HIP(hipDeviceSynchronize());
-        rk::pool_free(s.plan.d_lists);
-        s.plan.d_lists = nullptr;
-        s.plan.alloc = 0;
-        s.plan.d_lists = rk::pool_alloc(std::max<size_t>(lists.size(), 1) * sizeof(uint32_t));
+    // The list buffer: a fresh one whenever the current one is too small or is shared with a cached graph (whose kernels
+    // read it on every replay: it is never rewritten); otherwise the current one, once nothing in flight reads it.
+    if (!s.plan.hold || s.plan.hold.use_count() > 1 || s.plan.alloc < static_cast<int64_t>(lists.size())) {
+        void *buf = rk::pool_alloc(std::max<size_t>(lists.size(), 1) * sizeof(uint32_t));
+        s.plan.hold = std::shared_ptr<void>(buf, [](void *b) {
+            (void)hipDeviceSynchronize(); // a launch still in flight may be reading it
+            rk::pool_free(b);
+        });
+        s.plan.d_lists = buf;
         s.plan.alloc = static_cast<int64_t>(lists.size());
     } else {
         RK_HIP(hipDeviceSynchronize()); // a previous call may still be reading the old plan
@@ -906,8 +955,6 @@ void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64
         RK_HIP(hipMemcpy(s.plan.d_lists, lists.data(), lists.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     s.plan.p_begin = p_begin, s.plan.p_end = p_end, s.plan.mac_value = mac_value;
-    // A captured launch sequence may hold the plan buffer with its previous contents.
-    drop_graph_exec(s);
 }
 
 bool super_cache_enabled()
@@ -965,6 +1012,7 @@ bool prepare_split(rk_state &s, rk::kparams<F> &p, int64_t p_begin, int64_t p_en
         s.sl_rep_pending = false;
         const uint32_t used = s.sl_host[0], fallback = s.sl_host[1], exhausted = s.sl_host[3];
         s.sl_clean_key = s.sl_rep_key;
+        s.sl_clean_mode = s.sl_rep_mode, s.sl_clean_npart = s.sl_rep_npart, s.sl_clean_nseg = s.sl_rep_nseg;
         s.sl_clean_valid = fallback == 0u;
         // Keep a quarter of the pool in reserve; double what a call that ran out of segments had.
         int64_t want = static_cast<int64_t>(used) + static_cast<int64_t>(used) / 4 + 1024;
@@ -1056,7 +1104,10 @@ bool prepare_split(rk_state &s, rk::kparams<F> &p, int64_t p_begin, int64_t p_en
     p.sl_npart = static_cast<uint32_t>(parts_mode ? s.sl_npart : 0);
     p.sl_pbase = static_cast<uint32_t *>(s.sl_pbase);
     p.sl_part = s.sl_part;
-    return !(s.sl_clean_valid && s.sl_clean_key == key);
+    // The fallback launch is skipped only if a call of this very kind -- range, MAC value, one wave per node or per part, pools
+    // at least as large -- has reported an empty fallback list.
+    return !(s.sl_clean_valid && s.sl_clean_key == key && s.sl_clean_mode == p.sl_parts_mode
+             && s.sl_clean_npart <= static_cast<int64_t>(p.sl_npart) && s.sl_clean_nseg <= static_cast<int64_t>(p.sl_nseg));
 }
 
 // Streams, events and the supergroup scratch a traversal call needs. Created with the state (so that the first call does not
@@ -1256,13 +1307,32 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                 const char *e = std::getenv("RK_PLAN_REV_MAX_GROUPS");
                 return e ? std::atoll(e) : int64_t(60000);
             }();
-            const bool cached = s.plan.d_lists && s.plan.p_begin == p_begin && s.plan.p_end == p_end
-                                && s.plan.mac_value == mac_value;
+            bool cached = s.plan.d_lists && s.plan.p_begin == p_begin && s.plan.p_end == p_end
+                          && s.plan.mac_value == mac_value;
+            if (!cached) {
+                // A plan that one of the cached graphs was captured with serves this range too (a caller alternating among a
+                // few ranges gets its plans back together with its graphs).
+                for (const auto &pl : s.gcache_plan) {
+                    if (pl.d_lists && pl.p_begin == p_begin && pl.p_end == p_end && pl.mac_value == mac_value) {
+                        s.plan = pl;
+                        cached = true;
+                        break;
+                    }
+                }
+            }
             // (tracked for every call, also on the host-output path and with RK_GRAPH=0, where no graph key is kept.)
+            // A (range, MAC value) seen among the last calls gets a plan: also a caller that alternates among a few ranges.
             const rk_state::sl_key this_call{p_begin, p_end, mac_value};
-            const bool repeats = s.have_plan_key && s.plan_key == this_call;
-            s.plan_key = this_call;
-            s.have_plan_key = true;
+            bool repeats = false;
+            for (const auto &k : s.plan_keys) {
+                repeats = repeats || k == this_call;
+            }
+            if (!repeats) {
+                if (s.plan_keys.size() >= 8) {
+                    s.plan_keys.erase(s.plan_keys.begin());
+                }
+                s.plan_keys.push_back(this_call);
+            }
             // Beyond this many nodes the launch is so many rounds of waves deep that its tail no longer matters, and the
             // contiguous slice of the Morton order per XCD (xcd_mode 1) wins: 16M fp64 +0.6 %, 64M +1.5 % with a plan.
             static const int64_t plan_tail_max_groups = [] {
@@ -1509,6 +1579,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                     RK_HIP(hipMemcpyAsync(s.sl_host, s.sl_ctl, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
                     RK_HIP(hipEventRecord(s.sl_rep_ev, st));
                     s.sl_rep_key = rk_state::sl_key{p_begin, p_end, mac_value};
+                    s.sl_rep_mode = p.sl_parts_mode, s.sl_rep_npart = p.sl_npart, s.sl_rep_nseg = p.sl_nseg;
                     s.sl_rep_pending = true;
                 }
             }
@@ -1526,18 +1597,54 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                 key.out[k] = d_out[k];
             }
             key.perm = p.perm;
-            const bool replay = s.graph_exec && std::memcmp(&key, &s.gkey, sizeof(key)) == 0;
-            const bool repeats = s.have_last_key && std::memcmp(&key, &s.last_key, sizeof(key)) == 0;
-            s.last_key = key;
-            s.have_last_key = true;
-            if (!replay && (!repeats || (forked && !forked_capture_allowed()))) {
-                // First call of its kind (e.g. once per rebuilt tree in a time-stepping loop): launch directly,
-                // a capture + instantiation would cost more than it saves. So are forked sequences once the process has
-                // made its share of executable graphs with parallel branches (they are parked, never destroyed).
+            static const size_t cache_cap = [] {
+                const char *e = std::getenv("RK_GRAPH_CACHE");
+                return static_cast<size_t>(e ? std::max(std::atoi(e), 1) : 8);
+            }();
+            const int pdev = phys(s.device);
+            size_t hit = s.gcache.size();
+            for (size_t i = 0; i < s.gcache.size(); ++i) {
+                if (std::memcmp(&key, &s.gcache[i].key, sizeof(key)) == 0) {
+                    hit = i;
+                    break;
+                }
+            }
+            bool seen = false;
+            for (const auto &k : s.seen_keys) {
+                seen = seen || std::memcmp(&key, &k, sizeof(key)) == 0;
+            }
+            if (!seen) {
+                if (s.seen_keys.size() >= 2 * cache_cap) {
+                    s.seen_keys.erase(s.seen_keys.begin());
+                }
+                s.seen_keys.push_back(key);
+            }
+            // What the captured sequence reads besides the state's own buffers: the launch plan (if this call uses one).
+            const bool uses_plan = s.cur_lists == static_cast<const uint32_t *>(s.plan.d_lists) && s.plan.d_lists;
+            if (hit < s.gcache.size()) {
+                // Seen and captured before: replay, and move the entry to the most-recently-used end.
+                if (hit + 1 != s.gcache.size()) {
+                    std::rotate(s.gcache.begin() + static_cast<std::ptrdiff_t>(hit), s.gcache.begin() + static_cast<std::ptrdiff_t>(hit) + 1,
+                                s.gcache.end());
+                    std::rotate(s.gcache_plan.begin() + static_cast<std::ptrdiff_t>(hit),
+                                s.gcache_plan.begin() + static_cast<std::ptrdiff_t>(hit) + 1, s.gcache_plan.end());
+                }
+                RK_HIP(hipGraphLaunch(s.gcache.back().exec, stream));
+                ++s.graph_stats[0];
+            } else if (!seen || (forked && !forked_capture_allowed(pdev) && !(graph_update_enabled() && forked_cap() > 0 && [&] {
+                           for (const auto &e : s.gcache) {
+                               if (e.forked) {
+                                   return true; // one of this state's own forked executables can be re-targeted
+                               }
+                           }
+                           return false;
+                       }()))) {
+                // First call of its kind (e.g. once per rebuilt tree in a time-stepping loop): launch directly, a capture +
+                // instantiation would cost more than it saves. So are forked sequences when the process has made its share of
+                // executable graphs with parallel branches and none is free to be re-targeted.
                 enqueue(stream, false);
+                ++s.graph_stats[2];
             } else {
-            if (!replay) {
-                drop_graph_exec(s);
                 hipGraph_t graph = nullptr;
                 RK_HIP(hipStreamBeginCapture(s.cap_stream, hipStreamCaptureModeThreadLocal));
                 try {
@@ -1550,16 +1657,79 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                     throw;
                 }
                 RK_HIP(hipStreamEndCapture(s.cap_stream, &graph));
-                const hipError_t ie = hipGraphInstantiate(&s.graph_exec, graph, nullptr, nullptr, 0);
-                (void)hipGraphDestroy(graph);
-                RK_HIP(ie);
-                s.gkey = key;
-                s.graph_exec_forked = forked;
-                if (forked) {
-                    g_forked_execs.fetch_add(1, std::memory_order_relaxed);
+                hipGraphExec_t exec = nullptr;
+                bool updated = false;
+                if (forked && graph_update_enabled() && g_forked_execs.load(std::memory_order_relaxed) >= forked_cap()) {
+                    // No new forked executable may be made: if none is parked either, give up this state's least recently
+                    // used one (after a device synchronisation: it may be in flight) so that it can be re-targeted below.
+                    bool parked;
+                    {
+                        std::lock_guard<std::mutex> lk(g_parked_mtx);
+                        parked = !g_parked[pdev].empty();
+                    }
+                    for (size_t i = 0; !parked && i < s.gcache.size(); ++i) {
+                        if (s.gcache[i].forked) {
+                            RK_HIP(hipDeviceSynchronize());
+                            retire_graph_exec(pdev, s.gcache[i].exec, true);
+                            s.gcache.erase(s.gcache.begin() + static_cast<std::ptrdiff_t>(i));
+                            s.gcache_plan.erase(s.gcache_plan.begin() + static_cast<std::ptrdiff_t>(i));
+                            parked = true;
+                        }
+                    }
                 }
-            }
-            RK_HIP(hipGraphLaunch(s.graph_exec, stream));
+                if (forked && graph_update_enabled()) {
+                    // Re-target a parked executable of this device whose topology matches (it was retired after a device
+                    // synchronisation, so it is not in flight).
+                    std::vector<hipGraphExec_t> cand;
+                    {
+                        std::lock_guard<std::mutex> lk(g_parked_mtx);
+                        cand.swap(g_parked[pdev]);
+                    }
+                    for (size_t i = cand.size(); i-- > 0 && !exec;) {
+                        hipGraphNode_t err_node = nullptr;
+                        hipGraphExecUpdateResult res{};
+                        if (hipGraphExecUpdate(cand[i], graph, &err_node, &res) == hipSuccess) {
+                            exec = cand[i];
+                            cand.erase(cand.begin() + static_cast<std::ptrdiff_t>(i));
+                            updated = true;
+                        } else {
+                            (void)hipGetLastError();
+                        }
+                    }
+                    std::lock_guard<std::mutex> lk(g_parked_mtx);
+                    auto &v = g_parked[pdev];
+                    v.insert(v.end(), cand.begin(), cand.end());
+                }
+                if (!exec && forked && g_forked_execs.load(std::memory_order_relaxed) >= forked_cap()) {
+                    // No parked executable took the new topology and no new one may be made: direct launch.
+                    (void)hipGraphDestroy(graph);
+                    enqueue(stream, false);
+                    ++s.graph_stats[2];
+                } else {
+                    if (!exec) {
+                        const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+                        (void)hipGraphDestroy(graph);
+                        RK_HIP(ie);
+                        if (forked) {
+                            g_forked_execs.fetch_add(1, std::memory_order_relaxed);
+                        }
+                    } else {
+                        (void)hipGraphDestroy(graph);
+                    }
+                    if (s.gcache.size() >= cache_cap) {
+                        // Evict the least recently used entry. It may still be in flight on some stream: wait, then destroy
+                        // (linear) or park it for re-targeting (forked).
+                        RK_HIP(hipDeviceSynchronize());
+                        retire_graph_exec(pdev, s.gcache.front().exec, s.gcache.front().forked);
+                        s.gcache.erase(s.gcache.begin());
+                        s.gcache_plan.erase(s.gcache_plan.begin());
+                    }
+                    s.gcache.push_back(rk_state::graph_entry{key, exec, forked});
+                    s.gcache_plan.push_back(uses_plan ? s.plan : rk_state::launch_plan{});
+                    RK_HIP(hipGraphLaunch(exec, stream));
+                    ++s.graph_stats[1];
+                    s.graph_stats[3] += updated ? 1u : 0u;
+                }
             }
         } else {
             enqueue(stream, false);
@@ -2821,7 +2991,6 @@ int rk_state_set_perm(rk_state *s, const uint64_t *perm)
         // must not outlive the buffer it was recorded with.
         RK_HIP(hipDeviceSynchronize());
         drop_graph_exec(*s);
-        s->have_last_key = false;
         std::vector<uint32_t> p32(static_cast<size_t>(s->nparts));
         for (size_t i = 0; i < p32.size(); ++i) {
             if (perm[i] >= static_cast<uint64_t>(s->nparts)) {
@@ -3016,6 +3185,20 @@ int rk_device_memcpy(void *dst, const void *src, int64_t bytes, int device)
         if (bytes) {
             RK_HIP(hipMemcpy(dst, src, static_cast<size_t>(bytes), hipMemcpyDeviceToDevice));
         }
+    });
+}
+
+int rk_state_graph_stats(const rk_state *s, int64_t stats[6])
+{
+    return guard([&] {
+        if (!s || !stats) {
+            throw rk::error(RK_EINVAL, "null argument");
+        }
+        for (int i = 0; i < 4; ++i) {
+            stats[i] = static_cast<int64_t>(s->graph_stats[i]);
+        }
+        stats[4] = static_cast<int64_t>(s->gcache.size());
+        stats[5] = g_forked_execs.load(std::memory_order_relaxed);
     });
 }
 

@@ -207,6 +207,12 @@ class State:
     def set_variant(self, v):
         _capi.check(_capi.lib().rk_set_kernel_variant(self._h, v))
 
+    def graph_stats(self):
+        """rk_state_graph_stats: dict(replays, captures, direct, retargeted, cached, forked_alive)."""
+        a = (C.c_int64 * 6)()
+        _capi.check(_capi.lib().rk_state_graph_stats(self._h, a))
+        return dict(zip(("replays", "captures", "direct", "retargeted", "cached", "forked_alive"), (int(v) for v in a)))
+
     def acc_pot(self, q, mac_value, G=1.0, eps2=0.0, p_begin=0, p_end=None, out=None, offset_output=True):
         """rocm_state::acc_pot<Q>: host outputs (numpy). Returns the list of output arrays. Arrays in pinned memory
         (pinned_empty()) are written by the kernels directly."""

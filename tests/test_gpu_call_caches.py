@@ -113,3 +113,21 @@ np.savez(sys.argv[1], **res)
         assert np.isfinite(files[0][k]).all()
         for other in files[1:]:
             assert np.array_equal(files[0][k], other[k]), k
+
+
+@pytest.mark.parametrize("name,extra,nsig", [("one_launch_8", {}, 8), ("forked_8", {"RK_PLAN": "0", "RK_ANY_FIRST": "0"}, 8),
+                                             ("forked_20_cap4", {"RK_PLAN": "0", "RK_ANY_FIRST": "0", "RK_GRAPH_FORKED_MAX": "4"}, 20)])
+def test_graph_cache_keeps_replay_for_recurring_signatures(name, extra, nsig):
+    """tools/stress_graph_recurring.py: a caller alternating among `nsig` recurring signatures. Up to 8 (RK_GRAPH_CACHE) every
+    signature is captured once and replayed ever after -- linear graphs (one-launch kernels) and forked ones (class kernels on
+    side streams) alike; beyond, least-recently-used executables are evicted, the forked ones parked and re-targeted
+    (hipGraphExecUpdate) instead of destroyed, and no more than RK_GRAPH_FORKED_MAX of them ever exist. Results bit-identical
+    to the first result of every signature throughout."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RK_BACKTRACE="1", PYTHONFAULTHANDLER="1", **extra)
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_graph_recurring.py"), "1500", str(nsig)],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0 and "graph cache stress ok" in out.stdout, name + "\n" + out.stdout[-2000:] + out.stderr[-6000:]
