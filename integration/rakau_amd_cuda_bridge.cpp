@@ -79,12 +79,12 @@ struct announced {
 };
 
 std::mutex g_mtx;
-// Keyed by m_tree.data(). Function-local statics would do; a plain map keeps destruction order simple (states die with
-// the process' static destructors at the latest, after which no call can be in flight).
+// Keyed by m_tree.data(). Never destroyed: a tree that is still announced when the process exits (a static tree) must not
+// have its device states torn down from a static destructor, after the HIP runtime may have gone.
 std::map<const void *, announced> &registry()
 {
-    static std::map<const void *, announced> r;
-    return r;
+    static auto *r = new std::map<const void *, announced>;
+    return *r;
 }
 
 template <std::size_t NDim, typename F, typename UInt, mac MAC>

@@ -7,7 +7,7 @@
 #  * PMC passes (separate --pmc runs, no tracing domains) and the HBM traffic of one step.
 # usage (through gpurun): tools/collect_profiles.sh <tag>
 set -u
-TAG=${1:-r02}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -28,4 +28,14 @@ python3 $ROOT/tools/pmc_summary.py $OUT/pmc > $OUT/pmc_summary.txt 2>&1
 cd $ROOT
 bash tools/measure_traffic.sh plummer4m_f32 > $OUT/traffic.log 2>&1
 cp gpurun_out/traffic_plummer4m_f32.json $OUT/traffic.json 2>/dev/null
+# One-launch kernels of the small workloads.
+cd /tmp
+for wl in 100k:plummer100k_f32:100000 1m:plummer100k_f32:1000000; do
+  tag=${wl%%:*}; rest=${wl#*:}; key=${rest%%:*}; np=${rest#*:}
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/small_$tag -- python3 $ROOT/bench.py --workload $key --nparts $np --no-cpu-baseline > $OUT/bench_small_$tag.log 2>&1
+done
+cd $ROOT
+# Kernel traces are large and not judged: keep the stats.
+find $OUT -name "*kernel_trace.csv" -delete
+find $OUT -name "*counter_collection.csv" -size +2M -delete
 find $OUT -name "*kernel_stats.csv" | head
