@@ -44,3 +44,28 @@ def test_product_never_touches_the_oracle():
     for f in ("rakau_amd.h", "rakau_amd_tree.h", os.path.join("rakau_amd", "tree.hpp"),
               os.path.join("rakau_amd", "kwargs.hpp"), os.path.join("rakau_amd", "cpu_engine.hpp")):
         assert "oracle" not in open(os.path.join(ROOT, "include", f)).read().lower()
+
+
+def test_cross_check_kernels_live_in_their_own_library():
+    """The kernels that were measured and lost (variant 1: k_dfs_wave / k_dfs_block; variant 4: k_lists / k_dense / k_combine)
+    are not in librakau_amd.so: they build into librakau_amd_xcheck.so, which exports the one entry the product binds on demand
+    (rk_xcheck.hpp). The product library stays below 16 MB (round 3: 20.7)."""
+    libdir = os.path.dirname(_capi.LIB_PATH)
+    product = open(_capi.LIB_PATH, "rb").read()
+    xpath = os.path.join(libdir, "librakau_amd_xcheck.so")
+    assert os.path.exists(xpath)
+    xcheck = open(xpath, "rb").read()
+    for kernel in (b"k_dfs_wave", b"k_dfs_block", b"k_lists", b"k_dense", b"k_combine"):
+        assert kernel not in product, kernel
+        assert kernel in xcheck, kernel
+    for kernel in (b"k_list", b"k_pc", b"k_super", b"k_census"):
+        assert kernel in product, kernel
+    assert hasattr(ctypes.CDLL(xpath), "rk_xcheck_entry")
+    if "RAKAU_AMD_LIB" not in os.environ:
+        assert len(product) < 16 * 2 ** 20, len(product)
+
+
+def test_selecting_a_cross_check_variant_without_a_state_is_an_error_not_a_crash():
+    lib = _capi.lib()
+    assert lib.rk_set_kernel_variant(None, 1) != 0
+    assert b"variant" in lib.rk_last_error()
