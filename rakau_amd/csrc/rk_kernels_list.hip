@@ -595,7 +595,7 @@ __global__ void __launch_bounds__(64 * (BIG ? LK_BIG_WPB : RK_WPB), BIG ? (sizeo
 // picks the R of its node and runs the same list_node<..., R> the class kernels run. Compiled for the registers of the
 // largest R; the launch is too small to fill the device anyway.
 template <typename F, int Q, int MAC, int ND, int RMAX = 4>
-__global__ void __launch_bounds__(64, sizeof(F) == 4 ? (RMAX >= 4 ? RK_W4 : RK_W3) : RK_W64) k_list_any(const kparams<F> P, const uint32_t *__restrict__ list, int n_list)
+__global__ void __launch_bounds__(64, sizeof(F) == 4 ? (RMAX >= 4 ? RK_WANY : RK_W3) : RK_W64) k_list_any(const kparams<F> P, const uint32_t *__restrict__ list, int n_list)
 {
     __shared__ lk_wave_lds<F> s_lds;
     const int lane = threadIdx.x;

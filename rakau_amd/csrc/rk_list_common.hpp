@@ -49,6 +49,9 @@
 #ifndef RK_W4
 #define RK_W4 5 // R = 4
 #endif
+#ifndef RK_WANY
+#define RK_WANY RK_W4 // k_list_any (one launch over all classes): the waves per SIMD of its largest R
+#endif
 #ifndef RK_W5
 #define RK_W5 4 // R = 5
 #endif
