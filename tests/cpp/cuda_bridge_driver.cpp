@@ -138,8 +138,54 @@ static int run(bool announce)
     return bad;
 }
 
-int main()
+// `cuda_bridge_driver timing <n>`: what a call through the stateless seam costs with and without the life-time hooks (one
+// device; uniform particles, theta 0.75, accelerations into pageable arrays): INTEGRATION.md section B.2.
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+static int timing(std::size_t n)
 {
+    using F = float;
+    using ref_node = rakau::tree_node_t<3, F, std::uint64_t, rakau::mac::bh>;
+    using size_type = rakau::tree_size_t<F>;
+    std::mt19937 rng(11);
+    std::uniform_real_distribution<F> u(F(-1), F(1)), um(F(0.1), F(1));
+    std::vector<F> x(n), y(n), z(n), m(n);
+    for (std::size_t i = 0; i < n; ++i) {
+        x[i] = u(rng), y[i] = u(rng), z[i] = u(rng), m[i] = um(rng);
+    }
+    namespace kw = rakau_amd::kwargs;
+    rakau_amd::tree<3, F, std::uint64_t, rakau_amd::mac::bh> t{kw::x_coords = x, kw::y_coords = y, kw::z_coords = z, kw::masses = m};
+    const auto parts = t.p_its_u();
+    const auto *nodes = reinterpret_cast<const ref_node *>(t.nodes().data());
+    const size_type n_nodes = t.nodes().size();
+    const auto *codes = reinterpret_cast<const std::uint64_t *>(t.c_it_u());
+    std::array<std::vector<F>, 3> acc;
+    for (auto &v : acc) v.assign(n, F(0));
+    const std::array<F *, 3> out{acc[0].data(), acc[1].data(), acc[2].data()};
+    const std::vector<size_type> split{0, n};
+    const F mac_value = F(1) / (F(0.75) * F(0.75));
+    auto call_ms = [&]() {
+        const auto t0 = std::chrono::steady_clock::now();
+        rakau::cuda_acc_pot_impl<0u, 3u, F, std::uint64_t, rakau::mac::bh>(out, split, nodes, n_nodes, parts, codes, n, mac_value, F(1), F(0), true);
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    };
+    std::printf("n = %zu, %zu nodes, one device\n", n, static_cast<std::size_t>(n_nodes));
+    std::printf("unannounced tree (state built from the arguments and destroyed, every call), ms:");
+    for (int i = 0; i < 5; ++i) std::printf(" %.2f", call_ms());
+    rakau::rakau_amd_tree_ready(nodes, t.ncrit());
+    std::printf("\nannounced tree (rakau_amd_tree_ready: state resident between calls), ms:");
+    for (int i = 0; i < 8; ++i) std::printf(" %.2f", call_ms());
+    rakau::rakau_amd_invalidate(nodes);
+    std::printf("\n");
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc > 2 && !std::strcmp(argv[1], "timing")) {
+        return timing(static_cast<std::size_t>(std::atoll(argv[2])));
+    }
     if (rakau::cuda_device_count() < 4u) {
         std::printf("cuda bridge: %u device(s); run with RK_ALIAS_DEVICES=4\n", rakau::cuda_device_count());
         return 2;
