@@ -1223,6 +1223,209 @@ template void build_device<double, 3>(rk_state &, const void *const[4], bool, in
 template void build_device<float, 2>(rk_state &, const void *const[4], bool, int64_t, double, uint64_t, std::string &);
 template void build_device<double, 2>(rk_state &, const void *const[4], bool, int64_t, double, uint64_t, std::string &);
 
+// ---- a tree built on the HOST, converted on the device (rk_state_create) --------------------------------------
+namespace bld
+{
+
+template <typename F>
+__global__ void k_interleave(const F *x, const F *y, const F *z, const F *m, uint32_t n, typename vt<F>::v4 *part4)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        typename vt<F>::v4 p;
+        p.x = x[i], p.y = y[i], p.z = z ? z[i] : F(0), p.w = m[i];
+        part4[i] = p;
+    }
+}
+
+// One record of rakau::tree_node_t<ND, F, uint64_t, MAC> (tree_fwd.hpp:77-116 of the reference: uint64 begin, end,
+// n_children, code, level; F props[ND + 1]; F dim2 | F dim, delta) -> the arrays the rest of the build works on. A record
+// that cannot be right (empty or out-of-range particle range, more descendants than nodes follow it) is reported through
+// ctrl->pad[0] (~index of the first one) and neutralised, so that the kernels behind this one stay inside their arrays.
+template <typename F, int ND>
+__global__ void k_from_aos(const unsigned char *aos, uint32_t stride, uint32_t n_nodes, uint32_t nparts, int mac, uint4 *topo,
+                           uint64_t *ncode, typename vt<F>::v4 *com, typename vt<F>::v2 *macp, ctrl_block *ctrl)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_nodes) {
+        return;
+    }
+    const unsigned char *rec = aos + static_cast<size_t>(k) * stride;
+    const auto *hdr = reinterpret_cast<const uint64_t *>(rec);
+    const auto *fp = reinterpret_cast<const F *>(rec + 5 * sizeof(uint64_t));
+    uint64_t begin = hdr[0], end = hdr[1], nch = hdr[2];
+    if (begin >= end || end > nparts || nch > static_cast<uint64_t>(n_nodes - 1u - k)) {
+        atomicMax(&ctrl->pad[0], ~k);
+        begin = 0, end = 1, nch = 0;
+    }
+    topo[k] = make_uint4(static_cast<uint32_t>(nch), static_cast<uint32_t>(begin), static_cast<uint32_t>(end), 0u);
+    ncode[k] = hdr[3];
+    typename vt<F>::v4 c;
+    c.x = fp[0], c.y = fp[1], c.z = ND == 3 ? fp[2] : F(0), c.w = fp[ND];
+    com[k] = c;
+    typename vt<F>::v2 mp;
+    mp.x = fp[ND + 1], mp.y = mac == RK_MAC_BH ? F(0) : fp[ND + 2];
+    macp[k] = mp;
+}
+
+// k_parents with the host builder's consistency check: the children of k must tile (k, k + n_children(k)].
+__global__ void k_parents_checked(const uint4 *topo, uint32_t n_nodes, uint32_t *parent, uint32_t *mask, ctrl_block *ctrl)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_nodes) {
+        return;
+    }
+    mask[k] = 0u;
+    if (k == 0u) {
+        mask[n_nodes] = 0u;
+    }
+    const uint32_t last = k + topo[k].x;
+    uint32_t c = k + 1u, cnt = 0u;
+    for (; c <= last; c += topo[c].x + 1u) {
+        parent[c] = k;
+        ++cnt;
+    }
+    if (c != last + 1u || cnt > (1u << 3)) {
+        atomicMax(&ctrl->pad[1], ~k);
+    }
+}
+
+// The critical nodes must tile [0, nparts) in order.
+__global__ void k_check_tiling(const uint4 *crit, uint32_t n_crit, uint32_t nparts, ctrl_block *ctrl)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_crit) {
+        return;
+    }
+    const uint32_t expect = g ? crit[g - 1u].y : 0u;
+    if (crit[g].x != expect || (g + 1u == n_crit && crit[g].y != nparts)) {
+        atomicOr(&ctrl->pad[2], 1u);
+    }
+}
+
+} // namespace bld
+
+// What rk_state_create() does with a tree built on the host: the particle arrays and the node records (the reference's own
+// AoS layout) are uploaded AS THEY ARE and everything the kernels need is derived from them on the device -- {x, y, z, m}
+// records, depth-first SoA copies, parents and child masks, critical nodes and their boxes, the sibling-ordered records, the
+// lane-mapping classes -- with the kernels the device builder uses behind its own node sums. Round 3 did all of that in
+// host loops (73-130 ms at 4M, of which the uploads of the derived arrays were a third); a reference tree that hands its
+// arrays over after every update_particles() pays this on every time step. Same buffers, same contents: states made either
+// way give the same bits (tests/test_gpu_state_create.py; RK_CREATE_ON_HOST=1 selects the host loops).
+template <typename F, int ND>
+void convert_device(rk_state &s, const void *const parts[4], int64_t nparts, const void *tree, int64_t tree_size,
+                    int64_t node_stride)
+{
+    using namespace bld;
+    using v4 = typename vt<F>::v4;
+    using v2 = typename vt<F>::v2;
+    hipStream_t st = nullptr;
+    const auto n = static_cast<uint32_t>(nparts);
+    const size_t nn = static_cast<size_t>(tree_size);
+    auto alloc_buf = [&](int which, size_t bytes) {
+        s.buf[which] = pool_alloc(std::max<size_t>(bytes, 16));
+        s.buf_bytes[which] = static_cast<int64_t>(bytes);
+        return s.buf[which];
+    };
+    auto ctrl = dalloc<ctrl_block>(1);
+    RK_HIP(hipMemsetAsync(ctrl.get(), 0, sizeof(ctrl_block), st));
+    ctrl_block hc{};
+    auto fetch_ctrl = [&] { RK_HIP(hipMemcpy(&hc, ctrl.get(), sizeof(hc), hipMemcpyDeviceToHost)); };
+
+    // ---- uploads: the caller's arrays, unconverted ----
+    auto *p4 = static_cast<v4 *>(alloc_buf(RK_BUF_PART4, static_cast<size_t>(n) * sizeof(v4)));
+    {
+        dptr<F> in[4];
+        const F *d[4] = {};
+        for (int k = 0; k < 4; ++k) {
+            const int src = k < ND ? k : (k == 3 ? ND : -1);
+            if (src < 0) {
+                continue;
+            }
+            in[k] = dalloc<F>(n);
+            RK_HIP(hipMemcpyAsync(in[k].get(), parts[src], static_cast<size_t>(n) * sizeof(F), hipMemcpyHostToDevice, st));
+            d[k] = in[k].get();
+        }
+        hipLaunchKernelGGL((k_interleave<F>), dim3(nblk(n)), dim3(256), 0, st, d[0], d[1], d[2], d[3], n, p4);
+        RK_HIP(hipStreamSynchronize(st)); // the staging arrays go back to the block cache
+    }
+    auto aos = dalloc<unsigned char>(nn * static_cast<size_t>(node_stride));
+    RK_HIP(hipMemcpyAsync(aos.get(), tree, nn * static_cast<size_t>(node_stride), hipMemcpyHostToDevice, st));
+    auto *topo = static_cast<uint4 *>(alloc_buf(RK_BUF_NODE_TOPO, nn * sizeof(uint4)));
+    auto *node_com = static_cast<v4 *>(alloc_buf(RK_BUF_NODE_COM, nn * sizeof(v4)));
+    auto *node_mac = static_cast<v2 *>(alloc_buf(RK_BUF_NODE_MAC, nn * sizeof(v2)));
+    auto *recs = static_cast<node_rec<F> *>(alloc_buf(RK_BUF_NODE_REC, nn * sizeof(node_rec<F>)));
+    auto ncode = dalloc<uint64_t>(nn);
+    auto parent = dalloc<uint32_t>(nn);
+    auto mask = dalloc<uint32_t>(nn + 1);
+    hipLaunchKernelGGL((k_from_aos<F, ND>), dim3(nblk(nn)), dim3(256), 0, st, aos.get(), static_cast<uint32_t>(node_stride),
+                       static_cast<uint32_t>(nn), n, s.mac, topo, ncode.get(), node_com, node_mac, ctrl.get());
+    hipLaunchKernelGGL(k_parents_checked, dim3(nblk(nn)), dim3(256), 0, st, topo, static_cast<uint32_t>(nn), parent.get(),
+                       mask.get(), ctrl.get());
+
+    // ---- critical nodes, child masks: one scan of three counters ----
+    const auto ncrit_c = static_cast<uint32_t>(std::min<uint64_t>(s.ncrit, 0xffffffffu));
+    auto flags = dalloc<tri>(nn + 1), offs = dalloc<tri>(nn + 1);
+    hipLaunchKernelGGL(k_flags<ND>, dim3(nblk(nn)), dim3(256), 0, st, topo, ncode.get(), parent.get(), static_cast<uint32_t>(nn),
+                       ncrit_c, flags.get(), mask.get());
+    hipLaunchKernelGGL(k_popc, dim3(nblk(nn)), dim3(256), 0, st, mask.get(), static_cast<uint32_t>(nn), flags.get());
+    exclusive_scan(flags.get(), offs.get(), nn, st);
+    hipLaunchKernelGGL(k_pack_counts, dim3(1), dim3(1), 0, st, ctrl.get(), offs.get() + nn);
+    fetch_ctrl();
+    aos.reset();
+    if (hc.pad[0]) {
+        throw error(RK_EINVAL, "inconsistent tree node at index " + std::to_string(~hc.pad[0]));
+    }
+    if (hc.pad[1]) {
+        throw error(RK_EINVAL, "inconsistent children counts below tree node " + std::to_string(~hc.pad[1]));
+    }
+    if (static_cast<size_t>(hc.n_children) + 1 != nn) {
+        // (two children of one node in the same octant, or a node no parent claims)
+        throw error(RK_EINVAL, "inconsistent tree: not every node is reachable from the root");
+    }
+    const uint32_t n_crit = hc.n_crit, n_int = hc.n_int;
+    s.n_internal = n_int;
+    auto *crit = static_cast<uint4 *>(alloc_buf(RK_BUF_CRIT, static_cast<size_t>(n_crit) * sizeof(uint4)));
+    auto *boxes = static_cast<v4 *>(alloc_buf(RK_BUF_CRIT_BOX, static_cast<size_t>(n_crit) * 2 * sizeof(v4)));
+    auto *child_tab = static_cast<uint32_t *>(alloc_buf(RK_BUF_CHILD, static_cast<size_t>(n_int) * 8 * sizeof(uint32_t)));
+    RK_HIP(hipMemsetAsync(child_tab, 0, std::max<size_t>(static_cast<size_t>(n_int) * 8 * sizeof(uint32_t), 16), st));
+    hipLaunchKernelGGL((k_crit<F>), dim3(nblk(nn)), dim3(256), 0, st, topo, flags.get(), offs.get(), static_cast<uint32_t>(nn),
+                       static_cast<const v4 *>(p4), crit, boxes);
+    hipLaunchKernelGGL(k_check_tiling, dim3(nblk(n_crit)), dim3(256), 0, st, crit, n_crit, n, ctrl.get());
+    hipLaunchKernelGGL((k_records<F, ND>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode.get(), parent.get(), mask.get(), offs.get(),
+                       static_cast<uint32_t>(nn), node_com, node_mac, recs, child_tab);
+    // ---- lane-mapping classes (second half of RK_BUF_CLASS; the first half is filled with the host mirrors on demand) ----
+    auto *lists = static_cast<uint32_t *>(alloc_buf(RK_BUF_CLASS, static_cast<size_t>(n_crit) * 2 * sizeof(uint32_t)));
+    const unsigned nb = nblk(n_crit);
+    auto hist = dalloc<uint32_t>(static_cast<size_t>(nb) * NBIN);
+    hipLaunchKernelGGL(k_bin_count, dim3(nb), dim3(256), 0, st, crit, n_crit, hist.get(), ctrl.get());
+    hipLaunchKernelGGL(k_bin_scan, dim3(NBIN), dim3(256), 0, st, hist.get(), nb, ctrl.get());
+    hipLaunchKernelGGL(k_bin_scatter, dim3(nb), dim3(256), 0, st, crit, n_crit, hist.get(), ctrl.get(), lists + n_crit);
+    fetch_ctrl();
+    RK_HIP(hipGetLastError());
+    if (hc.pad[2]) {
+        throw error(RK_EINVAL, "the critical nodes derived from the tree do not tile the particle range");
+    }
+    s.n_crit = n_crit;
+    s.max_group = hc.max_group;
+    s.mirrors_valid = false;
+    s.crit_begin.clear();
+    s.crit_end.clear();
+    s.class_off[0] = 0;
+    s.class2_off[0] = n_crit;
+    for (int c = 0; c < n_classes; ++c) {
+        s.class_list[c].clear();
+        s.class2_list[c].clear();
+        s.class_off[c + 1] = 0;
+        s.class2_count[c] = hc.class2_count[c];
+        s.class2_off[c + 1] = s.class2_off[c] + s.class2_count[c];
+    }
+}
+template void convert_device<float, 3>(rk_state &, const void *const[4], int64_t, const void *, int64_t, int64_t);
+template void convert_device<double, 3>(rk_state &, const void *const[4], int64_t, const void *, int64_t, int64_t);
+template void convert_device<float, 2>(rk_state &, const void *const[4], int64_t, const void *, int64_t, int64_t);
+template void convert_device<double, 2>(rk_state &, const void *const[4], int64_t, const void *, int64_t, int64_t);
+
 // Makes the runtime load this translation unit's code object now (rk_init) instead of at the first build.
 void touch_build()
 {

@@ -396,6 +396,10 @@ void launch_block(const rk_state &s, int q, const kparams<F> &p, const uint32_t 
 template <typename F, int ND>
 void build_device(rk_state &s, const void *const parts[4], bool parts_on_device, int64_t nparts, double box_size,
                   uint64_t max_leaf_n, std::string &bad_coord_msg);
+// rk_state_create: the device buffers of a state derived ON THE DEVICE from a host-built tree (rk_build.hip).
+template <typename F, int ND>
+void convert_device(rk_state &s, const void *const parts[4], int64_t nparts, const void *tree, int64_t tree_size,
+                    int64_t node_stride);
 // Device builder: sum node properties in the reference's serial association (rk_set_build_exact / RK_BUILD_EXACT).
 bool exact_node_sums();
 void touch_kernels();

@@ -1971,10 +1971,36 @@ int rk_state_create_nd(rk_state **out, int ndim, int fp, int mac, int device, co
         s->tree_size = tree_size;
         s->ncrit = ncrit;
         if (nparts > 0) {
-            if (fp == RK_F32) {
-                create_impl<float>(*s, parts, nparts, tree, tree_size, node_stride);
+            // The device buffers are derived from the caller's arrays on the device (rk_build.hip: convert_device; 4M fp32:
+            // an order of magnitude faster than the host loops of create_impl, which RK_CREATE_ON_HOST=1 still selects -- the
+            // two give the same buffers).
+            static const bool on_host = [] {
+                const char *e = std::getenv("RK_CREATE_ON_HOST");
+                return e && std::atoi(e) != 0;
+            }();
+            const size_t min_stride = 5 * sizeof(uint64_t)
+                                      + static_cast<size_t>(ndim + 1 + (mac == RK_MAC_BH ? 1 : 2)) * (fp == RK_F32 ? 4u : 8u);
+            if (node_stride < static_cast<int64_t>(min_stride)) {
+                throw rk::error(RK_EINVAL, "node_stride (" + std::to_string(node_stride)
+                                               + ") is smaller than the node record of the selected F/MAC ("
+                                               + std::to_string(min_stride) + ")");
+            }
+            if (on_host) {
+                if (fp == RK_F32) {
+                    create_impl<float>(*s, parts, nparts, tree, tree_size, node_stride);
+                } else {
+                    create_impl<double>(*s, parts, nparts, tree, tree_size, node_stride);
+                }
+            } else if (fp == RK_F32) {
+                if (ndim == 3) {
+                    rk::convert_device<float, 3>(*s, parts, nparts, tree, tree_size, node_stride);
+                } else {
+                    rk::convert_device<float, 2>(*s, parts, nparts, tree, tree_size, node_stride);
+                }
+            } else if (ndim == 3) {
+                rk::convert_device<double, 3>(*s, parts, nparts, tree, tree_size, node_stride);
             } else {
-                create_impl<double>(*s, parts, nparts, tree, tree_size, node_stride);
+                rk::convert_device<double, 2>(*s, parts, nparts, tree, tree_size, node_stride);
             }
             ensure_call_resources_any(*s);
         }
