@@ -49,7 +49,7 @@ def test_product_never_touches_the_oracle():
 def test_cross_check_kernels_live_in_their_own_library():
     """The kernels that were measured and lost (variant 1: k_dfs_wave / k_dfs_block; variant 4: k_lists / k_dense / k_combine)
     are not in librakau_amd.so: they build into librakau_amd_xcheck.so, which exports the one entry the product binds on demand
-    (rk_xcheck.hpp). The product library stays below 16 MB (round 3: 20.7)."""
+    (rk_xcheck.hpp). The product library stays below 8 MB (round 3: 20.7)."""
     libdir = os.path.dirname(_capi.LIB_PATH)
     product = open(_capi.LIB_PATH, "rb").read()
     xpath = os.path.join(libdir, "librakau_amd_xcheck.so")
@@ -62,7 +62,7 @@ def test_cross_check_kernels_live_in_their_own_library():
         assert kernel in product, kernel
     assert hasattr(ctypes.CDLL(xpath), "rk_xcheck_entry")
     if "RAKAU_AMD_LIB" not in os.environ:
-        assert len(product) < 16 * 2 ** 20, len(product)
+        assert len(product) < 8 * 2 ** 20, len(product)
 
 
 def test_selecting_a_cross_check_variant_without_a_state_is_an_error_not_a_crash():
