@@ -21,6 +21,9 @@
 //      exception re-thrown.
 #include <algorithm>
 #include <array>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstddef>
 #include <cstdint>
 #include <exception>
@@ -100,6 +103,14 @@ void build_first_state(resident &r, int device, const tree_node_t<NDim, F, UInt,
     rk_throw(rk_state_create_nd(&s, r.ndim, r.fp, r.mac, device, p, nullptr, static_cast<std::int64_t>(nparts), wn.data,
                                 static_cast<std::int64_t>(tree_size), wn.stride, r.ncrit));
     r.dev[static_cast<std::size_t>(device)] = s;
+}
+
+// The first particle of every critical node: needed only when there are interior cuts to snap (more than one device).
+void fetch_crit_begins(resident &r, rk_state *s)
+{
+    if (!r.crit_begin.empty()) {
+        return;
+    }
     std::int64_t info[8];
     rk_throw(rk_state_info(s, info));
     std::vector<std::int64_t> be(static_cast<std::size_t>(info[2]) * 2u);
@@ -170,6 +181,16 @@ void cuda_acc_pot_impl(const std::array<F *, tree_nvecs_res<Q, NDim>> &out,
                                     + std::to_string(cuda_device_count()) + " were detected");
     }
 
+    // RK_BRIDGE_TIMING=1: phase times of the call on stderr (diagnostic).
+    static const bool timing = std::getenv("RK_BRIDGE_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    const auto lap = [&](const char *what) {
+        if (timing) {
+            const auto t = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "RK_BRIDGE_TIMING %-28s %9.1f us\n", what, std::chrono::duration<double, std::micro>(t - t_prev).count());
+            t_prev = t;
+        }
+    };
     // 1. The tree's resident data.
     std::shared_ptr<resident> res;
     bool keep = false;
@@ -242,6 +263,10 @@ void cuda_acc_pot_impl(const std::array<F *, tree_nvecs_res<Q, NDim>> &out,
     if (src_dev < 0) {
         src_dev = first_dev;
         build_first_state<NDim, F, UInt, MAC>(*res, src_dev, tree, tree_size, parts, nparts);
+        lap("first state");
+    }
+    if (ngpus > 1u) {
+        fetch_crit_begins(*res, res->dev[static_cast<std::size_t>(src_dev)]);
     }
     const auto &cb = res->crit_begin;
     for (std::size_t i = 0; i < ngpus; ++i) {
@@ -311,6 +336,7 @@ void cuda_acc_pot_impl(const std::array<F *, tree_nvecs_res<Q, NDim>> &out,
             }
         }
     }
+    lap("device shares");
     if (ep) {
         std::rethrow_exception(ep);
     }

@@ -94,7 +94,8 @@ def lib():
     L.rk_comm_destroy.argtypes = [vp]
     L.rk_state_broadcast.argtypes = [C.POINTER(vp), ci, ci, ci, vp, vp]
     L.rk_set_kernel_variant.argtypes = [vp, ci]
-    L.rk_state_graph_stats.argtypes = [vp, C.POINTER(i64)]
+    if hasattr(L, "rk_state_graph_stats"):  # (absent from older diagnostic builds selected with RAKAU_AMD_LIB)
+        L.rk_state_graph_stats.argtypes = [vp, C.POINTER(i64)]
     L.rk_device_memcpy.argtypes = [vp, vp, i64, ci]
     L.rk_count_interactions.argtypes = [vp, i64, i64, dbl, C.POINTER(u64)]
     L.rk_state_build.argtypes = [C.POINTER(vp), ci, ci, ci, C.POINTER(vp), i64, dbl, u64, u64]

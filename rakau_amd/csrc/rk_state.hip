@@ -205,6 +205,72 @@ int user_nres(const rk_state &s, int q)
     return q == 0 ? s.ndim : (q == 1 ? 1 : s.ndim + 1);
 }
 
+// Pinned staging buffers of the host-output path outlive their state: hipHostMalloc / hipHostFree of 48 MB (4M particles) cost
+// 10-20 ms each, which a caller that rebuilds its tree -- and with it the state -- every time step would pay per step (the
+// reference re-creates its rocm_state after every update_particles()). A few buffers are parked (per physical device; at most
+// RK_STAGE_KEEP = 4, the smallest that fits is handed out); rk_pool_trim() frees them.
+std::mutex g_stage_mtx;
+struct parked_stage {
+    int dev;
+    void *p;
+    size_t bytes;
+};
+std::vector<parked_stage> g_stages;
+void *stage_take(int dev, size_t need, size_t &got)
+{
+    std::lock_guard<std::mutex> lk(g_stage_mtx);
+    size_t best = g_stages.size();
+    for (size_t i = 0; i < g_stages.size(); ++i) {
+        if (g_stages[i].dev == dev && g_stages[i].bytes >= need && g_stages[i].bytes <= 2 * need + (size_t(1) << 20)
+            && (best == g_stages.size() || g_stages[i].bytes < g_stages[best].bytes)) {
+            best = i;
+        }
+    }
+    if (best == g_stages.size()) {
+        return nullptr;
+    }
+    void *p = g_stages[best].p;
+    got = g_stages[best].bytes;
+    g_stages.erase(g_stages.begin() + static_cast<std::ptrdiff_t>(best));
+    return p;
+}
+void stage_give(int dev, void *p, size_t bytes)
+{
+    if (!p) {
+        return;
+    }
+    static const size_t keep = [] {
+        const char *e = std::getenv("RK_STAGE_KEEP");
+        return static_cast<size_t>(e ? std::max(std::atoi(e), 0) : 4);
+    }();
+    void *drop = p;
+    {
+        std::lock_guard<std::mutex> lk(g_stage_mtx);
+        if (keep) {
+            g_stages.push_back(parked_stage{dev, p, bytes});
+            drop = nullptr;
+            if (g_stages.size() > keep) {
+                drop = g_stages.front().p; // the oldest one goes
+                g_stages.erase(g_stages.begin());
+            }
+        }
+    }
+    if (drop) {
+        (void)hipHostFree(drop);
+    }
+}
+void stage_trim()
+{
+    std::vector<parked_stage> v;
+    {
+        std::lock_guard<std::mutex> lk(g_stage_mtx);
+        v.swap(g_stages);
+    }
+    for (auto &e : v) {
+        (void)hipHostFree(e.p);
+    }
+}
+
 // Give the tree-dependent device buffers back to the pool (after a device sync: traversal kernels on other
 // streams may still be reading them) and forget everything derived from them. Streams, events and the output /
 // supergroup scratch survive, so that a state can be rebuilt in place every time step.
@@ -248,9 +314,7 @@ void free_state(rk_state *s)
     if (s->sl_rep_ev) {
         (void)hipEventDestroy(s->sl_rep_ev);
     }
-    if (s->h_stage) {
-        (void)hipHostFree(s->h_stage);
-    }
+    stage_give(phys(s->device), s->h_stage, s->h_stage_bytes); // (release_tree above synchronised the device)
     if (s->ev0) {
         (void)hipEventDestroy(s->ev0);
     }
@@ -2417,12 +2481,18 @@ int rk_acc_pot(rk_state *s, int q, int64_t p_begin, int64_t p_end, void *const *
         if (s->h_stage_bytes < need) {
             if (s->h_stage) {
                 RK_HIP(hipDeviceSynchronize());
-                RK_HIP(hipHostFree(s->h_stage));
+                stage_give(phys(s->device), s->h_stage, s->h_stage_bytes);
                 s->h_stage = nullptr;
                 s->h_stage_bytes = 0;
             }
-            RK_HIP(hipHostMalloc(&s->h_stage, need, hipHostMallocDefault));
-            s->h_stage_bytes = need;
+            size_t got = 0;
+            s->h_stage = stage_take(phys(s->device), need, got);
+            if (s->h_stage) {
+                s->h_stage_bytes = got;
+            } else {
+                RK_HIP(hipHostMalloc(&s->h_stage, need, hipHostMallocDefault));
+                s->h_stage_bytes = need;
+            }
         }
         void *h_ptrs[4] = {};
         for (int k = 0; k < nres; ++k) {
@@ -2999,6 +3069,7 @@ int rk_state_rebuild_device(rk_state *s, const void *const d_parts[4], int64_t n
 void rk_pool_trim(void)
 {
     rk::pool_trim();
+    stage_trim();
 }
 
 void rk_set_build_exact(int on)
