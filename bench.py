@@ -531,7 +531,8 @@ def main():
             "frac": round(achieved_tflops / PEAK_TFLOPS[dtype], 4), "traffic": traffic,
             # `traffic` is a committed PMC figure of this very command (profiles/traffic.json, separate rocprofv3 --pmc
             # passes), not something this run measured; null when no figure for this workload has been committed.
-            "traffic_source": "profiles/traffic.json (committed rocprofv3 --pmc measurement of this command; not measured in this run)"
+            "traffic_source": "profiles/traffic.json (committed rocprofv3 --pmc measurement of this command, averaged over its launches -- "
+                              "results left in HBM and results written through PCIe alike; not measured in this run)"
                               if traffic is not None else None,
             "flop_per_interaction": flop_per_inter, "interactions_per_launch": int(inter_local),
             "kernel_ms": round(kernel_ms, 4),
