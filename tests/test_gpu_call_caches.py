@@ -127,7 +127,9 @@ def test_graph_cache_keeps_replay_for_recurring_signatures(name, extra, nsig):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, RK_BACKTRACE="1", PYTHONFAULTHANDLER="1", **extra)
+    # (the cache's own knobs are pinned: the test is about its default behaviour whatever the caller's environment says)
+    env = dict(os.environ, RK_BACKTRACE="1", PYTHONFAULTHANDLER="1", RK_GRAPH="1", RK_GRAPH_CACHE="8", RK_GRAPH_UPDATE="1")
+    env.update(extra)
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_graph_recurring.py"), "1500", str(nsig)],
                          capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert out.returncode == 0 and "graph cache stress ok" in out.stdout, name + "\n" + out.stdout[-2000:] + out.stderr[-6000:]
