@@ -563,7 +563,7 @@ __device__ __forceinline__ void list_node(const kparams<F> &P, lk_wave_lds<F> &L
 }
 
 template <typename F, int Q, int MAC, int R, int ND, bool BIG = false>
-__global__ void __launch_bounds__(64 * (BIG ? LK_BIG_WPB : RK_WPB), BIG ? (sizeof(F) == 4 ? RK_WBIG : RK_W64) : (sizeof(F) == 4 ? (R <= 2 ? RK_W12 : (R == 3 ? RK_W3 : (R == 4 ? RK_W4 : (R == 5 ? RK_W5 : RK_W6)))) : RK_W64)) k_list(const kparams<F> P, const uint32_t *__restrict__ list, int n_list, const uint32_t *__restrict__ n_list_dev = nullptr)
+__global__ void __launch_bounds__(64 * (BIG ? LK_BIG_WPB : RK_WPB), BIG ? (sizeof(F) == 4 ? RK_WBIG : RK_W64) : (sizeof(F) == 4 ? (R <= 2 ? RK_W12 : (R == 3 ? RK_W3 : (R == 4 ? RK_W4 : (R == 5 ? RK_W5 : RK_W6)))) : (R >= 4 ? RK_W64_R4 : (R == 3 ? RK_W64_R3 : RK_W64)))) k_list(const kparams<F> P, const uint32_t *__restrict__ list, int n_list, const uint32_t *__restrict__ n_list_dev = nullptr)
 {
     __shared__ lk_wave_lds<F> s_lds[BIG ? LK_BIG_WPB : RK_WPB];
 

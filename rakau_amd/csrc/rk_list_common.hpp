@@ -40,6 +40,14 @@
 #ifndef RK_W64
 #define RK_W64 4 // fp64 kernels (all R): waves per SIMD they are compiled for (3: 63.3 ms, 4: 62.8, 5: 67.3 at 16M)
 #endif
+#ifndef RK_W64_R3
+#define RK_W64_R3 RK_W64 // fp64, R = 3 class kernel
+#endif
+#ifndef RK_W64_R4
+#define RK_W64_R4 3 // fp64, R = 4 class kernel: 165 VGPRs, no scratch (at 4 waves: 128 VGPRs + 80 bytes of scratch per lane). 16M fp64
+                    // theta 0.5: 59.05 against 59.65 ms per step, same box, two rounds (tools/jobs_r04/r04_job36.sh); the R = 3
+                    // kernel at 3 waves as well: 60.0
+#endif
 #ifndef RK_W12
 #define RK_W12 7 // waves per SIMD the R <= 2 kernels are compiled for
 #endif
