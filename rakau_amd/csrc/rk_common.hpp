@@ -315,6 +315,10 @@ struct rk_state {
         bool all_padded = false; // the merged list is a light-tail arrangement (interleaved per-XCD queues with padding)
     } plan;
     std::vector<launch_plan> gcache_plan; // gcache_plan[i]: the plan gcache[i] was captured with (d_lists null: none)
+    std::vector<launch_plan> plans;       // the last few plans built (most recent last): a caller alternating among ranges --
+                                          // the two parts of a staged host-output call -- does not rebuild them
+    hipEvent_t ev_mid = nullptr;          // end of the first part of a two-part host-output call
+    bool keep_ev0 = false;                // second part of such a call: the timing start event stays where the first part put it
     std::vector<uint64_t> work_cache; // launch-plan weight of every critical node (its size; empty: not computed)
     // Scratch of the supergroup pre-pass (allocated on first use).
     void *sup_common = nullptr, *sup_resid = nullptr, *sup_cnt = nullptr;

@@ -121,6 +121,7 @@ void drop_graph_exec(rk_state &s)
     }
     s.gcache.clear();
     s.gcache_plan.clear();
+    s.plans.clear();
     s.seen_keys.clear();
 }
 
@@ -326,6 +327,9 @@ void free_state(rk_state *s)
     }
     if (s->sup_ev) {
         (void)hipEventDestroy(s->sup_ev);
+    }
+    if (s->ev_mid) {
+        (void)hipEventDestroy(s->ev_mid);
     }
     if (s->cap_stream) {
         (void)hipStreamDestroy(s->cap_stream);
@@ -1323,7 +1327,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
     ensure_call_resources<F>(s);
     // allow_graph is false on the host-output path, which waits on ev1 for completion.
     const bool need_done_event = !allow_graph;
-    if (s.timing) {
+    if (s.timing && !s.keep_ev0) {
         RK_HIP(hipEventRecord(s.ev0, stream));
     }
     bool ran_super = false;
@@ -1376,11 +1380,12 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
             if (!cached) {
                 // A plan that one of the cached graphs was captured with serves this range too (a caller alternating among a
                 // few ranges gets its plans back together with its graphs).
-                for (const auto &pl : s.gcache_plan) {
-                    if (pl.d_lists && pl.p_begin == p_begin && pl.p_end == p_end && pl.mac_value == mac_value) {
-                        s.plan = pl;
-                        cached = true;
-                        break;
+                for (const auto *v : {&s.plans, &s.gcache_plan}) {
+                    for (const auto &pl : *v) {
+                        if (!cached && pl.d_lists && pl.p_begin == p_begin && pl.p_end == p_end && pl.mac_value == mac_value) {
+                            s.plan = pl;
+                            cached = true;
+                        }
                     }
                 }
             }
@@ -1410,6 +1415,11 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                 if (!cached) {
                     build_plan<F>(s, p_begin, p_end, g_lo, g_hi, mac_value,
                                   g_hi - g_lo <= plan_max_groups ? 1 : (g_hi - g_lo <= plan_rev_max_groups ? 2 : 0));
+                    // Remember it (four plans; the oldest goes -- its buffer once nothing else holds it).
+                    if (s.plans.size() >= 4) {
+                        s.plans.erase(s.plans.begin());
+                    }
+                    s.plans.push_back(s.plan);
                 }
                 s.cur_lists = static_cast<const uint32_t *>(s.plan.d_lists);
                 std::copy(s.plan.off, s.plan.off + rk::n_classes + 1, s.cur_off);
@@ -2498,33 +2508,82 @@ int rk_acc_pot(rk_state *s, int q, int64_t p_begin, int64_t p_end, void *const *
         for (int k = 0; k < nres; ++k) {
             h_ptrs[k] = static_cast<unsigned char *>(s->h_stage) + static_cast<size_t>(k) * count * fsz;
         }
-        if (s->fp == RK_F32) {
-            run_impl<float>(*s, q, p_begin, p_end, h_ptrs, mac_value, G, eps2, 0, nullptr, false);
-        } else {
-            run_impl<double>(*s, q, p_begin, p_end, h_ptrs, mac_value, G, eps2, 0, nullptr, false);
-        }
-        RK_HIP(hipEventSynchronize(s->ev1));
         const auto *stage = static_cast<const unsigned char *>(s->h_stage);
-        const size_t piece = size_t(2) << 20;
-        const int n_items = static_cast<int>((need + piece - 1) / piece);
         static const int max_thr = [] {
             const char *e = std::getenv("RK_HOST_THREADS"); // delivery threads (default 8; memory-bound beyond that)
             const int v = e ? std::atoi(e) : 8;
             return v < 1 ? 1 : v;
         }();
-        const int n_thr = std::max(1, std::min<int>({max_thr, n_items, static_cast<int>(std::thread::hardware_concurrency())}));
         const size_t arr = count * fsz;
-        // A byte range of the staging buffer (the nres arrays back to back) -> the caller's arrays, with streaming stores
-        // (no read-for-ownership of 48 MB of destination lines that are overwritten whole).
-        delivery_pool::get().run(n_items, n_thr, [&](int item) {
-            size_t off = static_cast<size_t>(item) * piece, len = std::min(piece, need - off);
-            while (len) {
-                const size_t k = off / arr, in = off % arr, nb = std::min(len, arr - in);
-                stream_copy(dst[k] + in, stage + off, nb);
-                off += nb;
-                len -= nb;
+        // Elements [eb, ee) of every staged array -> the caller's arrays, in 2 MB pieces on the pool threads, with streaming
+        // stores (no read-for-ownership of destination lines that are overwritten whole).
+        auto deliver = [&](size_t eb, size_t ee) {
+            const size_t piece = size_t(2) << 20, span = (ee - eb) * fsz;
+            const size_t per = (span + piece - 1) / piece;
+            const int n_items = static_cast<int>(per * static_cast<size_t>(nres));
+            if (n_items <= 0) {
+                return;
             }
-        });
+            const int n_thr = std::max(1, std::min<int>({max_thr, n_items, static_cast<int>(std::thread::hardware_concurrency())}));
+            delivery_pool::get().run(n_items, n_thr, [&](int item) {
+                const size_t k = static_cast<size_t>(item) / per, off = eb * fsz + (static_cast<size_t>(item) % per) * piece;
+                const size_t nb = std::min(piece, ee * fsz - off);
+                stream_copy(dst[k] + off, stage + k * arr + off, nb);
+            });
+        };
+        auto run = [&](int64_t b, int64_t e, void *const *ptrs) {
+            if (s->fp == RK_F32) {
+                run_impl<float>(*s, q, b, e, ptrs, mac_value, G, eps2, 0, nullptr, false);
+            } else {
+                run_impl<double>(*s, q, b, e, ptrs, mac_value, G, eps2, 0, nullptr, false);
+            }
+        };
+        // Two parts (round 4): the first RK_HOST_SPLIT (0.85) of the range is traversed first and DELIVERED by the host threads
+        // while the second part is traversed; only the second part's delivery is left when the kernels end. The cut is a
+        // critical-node boundary, the two parts are ordinary sub-range calls (their union equals the one-part result bit for
+        // bit), and two launches cost about 0.1 ms more than one at 4M, where the delivery of 85 % of the results costs
+        // 0.3-0.5: 2.65 -> 2.53-2.54 ms per call (fractions 0.7 / 0.8 / 0.85 / 0.9: 2.68 / 2.56 / 2.54 / 2.53-2.80), 2M 1.59 -> 1.39,
+        // 4M accelerations + potentials 3.32 -> 2.79 (tools/jobs_r04/r04_job39.sh). RK_HOST_SPLIT=0 (or results below
+        // 16 MB): one part, delivered at the end.
+        static const double split_frac = [] {
+            const char *e = std::getenv("RK_HOST_SPLIT");
+            const double v = e ? std::atof(e) : 0.85;
+            return (v > 0.05 && v < 0.95) ? v : 0.0;
+        }();
+        int64_t cut = p_begin;
+        if (split_frac > 0.0 && need >= (size_t(16) << 20)) {
+            ensure_mirrors(*s);
+            const auto target = p_begin + static_cast<int64_t>(split_frac * static_cast<double>(count));
+            const auto it = std::lower_bound(s->crit_begin.begin(), s->crit_begin.end(), target);
+            cut = it == s->crit_begin.end() ? p_end : *it;
+        }
+        if (cut > p_begin && cut < p_end) {
+            if (!s->ev_mid) {
+                RK_HIP(hipEventCreateWithFlags(&s->ev_mid, hipEventDisableTiming));
+            }
+            run(p_begin, cut, h_ptrs);
+            RK_HIP(hipEventRecord(s->ev_mid, nullptr));
+            void *h2[4] = {};
+            for (int k = 0; k < nres; ++k) {
+                h2[k] = static_cast<unsigned char *>(h_ptrs[k]) + static_cast<size_t>(cut - p_begin) * fsz;
+            }
+            s->keep_ev0 = true;
+            try {
+                run(cut, p_end, h2);
+            } catch (...) {
+                s->keep_ev0 = false;
+                throw;
+            }
+            s->keep_ev0 = false;
+            RK_HIP(hipEventSynchronize(s->ev_mid));
+            deliver(0, static_cast<size_t>(cut - p_begin));
+            RK_HIP(hipEventSynchronize(s->ev1));
+            deliver(static_cast<size_t>(cut - p_begin), count);
+        } else {
+            run(p_begin, p_end, h_ptrs);
+            RK_HIP(hipEventSynchronize(s->ev1));
+            deliver(0, count);
+        }
     });
 }
 

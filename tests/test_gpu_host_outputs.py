@@ -25,7 +25,8 @@ def device_result(st, q, mv, n, dtype, b, e, eps2):
     return [o.cpu().numpy() for o in outs]
 
 
-@pytest.mark.parametrize("dtype,n", [(np.float32, 400000), (np.float64, 150000), (np.float32, 20000)])
+# (1.5M fp32: results of 18-24 MB, i.e. the two-part staged call whose first part is delivered while the second is traversed)
+@pytest.mark.parametrize("dtype,n", [(np.float32, 400000), (np.float64, 150000), (np.float32, 20000), (np.float32, 1500000)])
 def test_pageable_pinned_and_device_outputs_agree(dtype, n):
     import torch
     m, x, y, z = oracle.plummer(n, dtype)
