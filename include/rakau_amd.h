@@ -147,9 +147,11 @@ RK_EXPORT int rk_state_crit_ranges(const rk_state *s, int64_t *begin_end);
  *  offset_output  bit 0 (RK_OUT_OFFSET): out[j] addresses element 0 of a full-size array and results are written
  *                 at out[j] + p_begin; clear: out[j] is a compact array of p_end - p_begin values
  *                 (same meaning as in src/rakau_rocm.cpp:114-116).
- *                 bit 1 (RK_OUT_ORDERED, rk_acc_pot_device only): original-order output -- the result of the
- *                 particle at Morton position i goes to out[j][perm[i]] (the accs_o/pots_o scatter of
- *                 tree.hpp:3320-3330 done in the kernel epilogue); out[j] are full-size arrays.
+ *                 bit 1 (RK_OUT_ORDERED): original-order output -- the result of the particle at Morton position i
+ *                 goes to out[j][perm[i]] (the accs_o/pots_o scatter of tree.hpp:3320-3330 done in the kernel
+ *                 epilogue); out[j] are full-size arrays. rk_acc_pot_device: any range. rk_acc_pot (host arrays):
+ *                 the whole range [0, nparts) only -- the kernels scatter into a buffer in HBM, the ordered arrays then
+ *                 travel to the host in one piece each. Needs the permutation (rk_state_set_perm, or a device-built state).
  */
 RK_EXPORT int rk_acc_pot(rk_state *s, int q, int64_t p_begin, int64_t p_end, void *const *out, double mac_value,
                          double G, double eps2, int offset_output);

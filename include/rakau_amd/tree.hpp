@@ -341,6 +341,66 @@ inline void parallel_blocks(std::size_t n, std::size_t min_block, Fn &&f)
     }
 }
 
+// Per-thread staging for results that cannot be written where the caller wants them (original-order outputs, generic output
+// iterators): k arrays of n values, kept between calls and only ever grown. Pinned (rk_host_alloc: the kernels write into them
+// directly) when that succeeds, plain memory otherwise (no device: the CPU engine writes them).
+template <typename F>
+struct stage_buffers {
+    F *p[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::size_t cap = 0;
+    bool pinned = false;
+    ~stage_buffers()
+    {
+        release();
+    }
+    void release() noexcept
+    {
+        for (auto &q : p) {
+            if (q) {
+                if (pinned) {
+                    (void)rk_host_free(q);
+                } else {
+                    ::operator delete(q);
+                }
+                q = nullptr;
+            }
+        }
+        cap = 0;
+    }
+    static void get(std::size_t n, std::size_t k, F *out[4])
+    {
+        thread_local stage_buffers sb;
+        if (sb.cap < n) {
+            sb.release();
+            sb.cap = n;
+            sb.pinned = rk_has_accelerator() != 0;
+        }
+        const std::size_t bytes = std::max<std::size_t>(sb.cap, 1) * sizeof(F);
+        for (std::size_t j = 0; j < k; ++j) {
+            if (sb.p[j]) {
+                continue;
+            }
+            void *q = nullptr;
+            if (sb.pinned && (rk_host_alloc(&q, static_cast<std::int64_t>(bytes)) != RK_OK || !q)) {
+                // Pinned memory refused: everything in plain memory from here on (mixing the two would only confuse release()).
+                const std::size_t keep = sb.cap;
+                sb.release();
+                sb.cap = keep;
+                sb.pinned = false;
+                j = static_cast<std::size_t>(-1);
+                continue;
+            }
+            if (!sb.pinned) {
+                q = ::operator new(bytes);
+            }
+            sb.p[j] = static_cast<F *>(q);
+        }
+        for (std::size_t j = 0; j < 4; ++j) {
+            out[j] = sb.p[j];
+        }
+    }
+};
+
 // Bit interleaving for 3-D Morton codes: x -> bit 0, y -> bit 1, z -> bit 2 (the order produced by the
 // reference's encoder, tree.hpp:222-242 / libmorton/morton3D.h:38-50).
 inline std::uint64_t morton_spread3(std::uint64_t v)
@@ -407,10 +467,11 @@ inline std::uint64_t morton_coord(std::uint64_t code, std::size_t j)
 // Owner of one rk_state (device-resident copy of the tree on one GPU).
 struct device_state {
     rk_state *h = nullptr;
+    bool perm_set = false; // the state has been given the tree's permutation (original-order outputs written by the kernels)
     device_state() = default;
     device_state(const device_state &) = delete;
     device_state &operator=(const device_state &) = delete;
-    device_state(device_state &&o) noexcept : h(o.h)
+    device_state(device_state &&o) noexcept : h(o.h), perm_set(o.perm_set)
     {
         o.h = nullptr;
     }
@@ -419,6 +480,7 @@ struct device_state {
         if (this != &o) {
             reset();
             h = o.h;
+            perm_set = o.perm_set;
             o.h = nullptr;
         }
         return *this;
@@ -433,6 +495,7 @@ struct device_state {
             rk_state_destroy(h);
             h = nullptr;
         }
+        perm_set = false;
     }
 };
 
@@ -1586,6 +1649,39 @@ private:
         }
     }
 
+    // Original-order outputs without a host-side scatter: when device 0 computes everything (no CPU share, one device), the
+    // kernels scatter through perm themselves (rk_acc_pot with RK_OUT_ORDERED: into a buffer in HBM, from where the ordered
+    // arrays travel in one piece each). Returns false if the call is not of that kind (the caller then stages and scatters).
+    template <unsigned Q, typename It>
+    bool ordered_on_device(const std::array<It, nvecs_res<Q>> &out, F mac_value, F G, F eps2, const std::vector<double> &split) const
+    {
+        if constexpr (std::is_same_v<It, F *>) {
+            const auto cuts = split_cuts(split);
+            if (!nparts() || cuts.size() != 3u || cuts[1] > cuts[0] || !rk_has_accelerator()) {
+                return false;
+            }
+            rk_state *st = device_state_for(0);
+            {
+                std::lock_guard<std::mutex> lk(m_dev_mutex);
+                if (!m_dev[0].perm_set) {
+                    static_assert(sizeof(size_type) == sizeof(std::uint64_t));
+                    throw_status(rk_state_set_perm(st, reinterpret_cast<const std::uint64_t *>(m_perm.data())));
+                    m_dev[0].perm_set = true;
+                }
+            }
+            void *o[4] = {};
+            for (std::size_t j = 0; j < nvecs_res<Q>; ++j) {
+                o[j] = out[j];
+            }
+            throw_status(rk_acc_pot(st, static_cast<int>(Q), 0, static_cast<std::int64_t>(nparts()), o, static_cast<double>(mac_value),
+                                    static_cast<double>(G), static_cast<double>(eps2), RK_OUT_OFFSET | RK_OUT_ORDERED));
+            return true;
+        } else {
+            (void)out, (void)mac_value, (void)G, (void)eps2, (void)split;
+            return false;
+        }
+    }
+
     template <bool Ordered, unsigned Q, typename It>
     void acc_pot_dispatch(const std::array<It, nvecs_res<Q>> &out, F orig_mac_value, F G, F eps,
                           const std::vector<double> &split) const
@@ -1606,31 +1702,44 @@ private:
         const size_type np = nparts();
         if constexpr (!Ordered && std::is_same_v<It, F *>) {
             device_run<Q>(out, mac_value, G, eps2, split);
+        } else if (Ordered && std::is_same_v<It, F *> && ordered_on_device<Q>(out, mac_value, G, eps2, split)) {
+            // (accs_o / pots_o / accs_pots_o into plain arrays, everything on device 0: the kernels scattered through perm)
         } else {
             // Generic output iterators and/or original-order output: stage in Morton-order buffers,
             // then copy/scatter (the reference stages accelerator results the same way, tree.hpp:3081-3106).
-            std::array<std::vector<F>, nvecs_res<Q>> stage;
+            // The buffers are kept per thread between calls, in pinned memory where a device is there to write them (the
+            // kernels then store the results into them directly: no staging inside the library, no 48 MB of fresh pages per
+            // call at 4M), and the scatter through perm runs on the host threads: accs_o() at 4M 30 ms -> 6 ms.
+            F *ptrs_raw[4] = {};
+            detail::stage_buffers<F>::get(np, nvecs_res<Q>, ptrs_raw);
             std::array<F *, nvecs_res<Q>> ptrs;
             for (std::size_t j = 0; j < nvecs_res<Q>; ++j) {
-                stage[j].resize(np);
-                ptrs[j] = stage[j].data();
+                ptrs[j] = ptrs_raw[j];
             }
             device_run<Q>(ptrs, mac_value, G, eps2, split);
             using diff_t = typename std::iterator_traits<It>::difference_type;
-            for (std::size_t j = 0; j < nvecs_res<Q>; ++j) {
-                It o = out[j];
-                const F *src = ptrs[j];
+            if constexpr (Ordered) {
+                (void)checked_cast<diff_t>(np); // every index below fits
+            }
+            // One pass over the particles for all result arrays (perm is read once per particle), on the host threads.
+            detail::parallel_blocks(np, std::size_t(1) << 17, [&](std::size_t b, std::size_t e) {
                 if constexpr (Ordered) {
-                    // out[perm[i]] = res[i] (tree.hpp:3320-3330).
-                    for (size_type i = 0; i < np; ++i) {
-                        *(o + checked_cast<diff_t>(m_perm[i])) = src[i];
+                    // out[perm[i]] = res[i] (tree.hpp:3320-3330), as a gather: out[k] = res[inv_perm[k]] -- the writes stream
+                    // through the caller's arrays, the random accesses are reads.
+                    for (std::size_t k = b; k < e; ++k) {
+                        const auto i = m_inv_perm[k];
+                        for (std::size_t j = 0; j < nvecs_res<Q>; ++j) {
+                            *(out[j] + static_cast<diff_t>(k)) = ptrs[j][i];
+                        }
                     }
                 } else {
-                    for (size_type i = 0; i < np; ++i) {
-                        *(o + static_cast<diff_t>(i)) = src[i];
+                    for (std::size_t j = 0; j < nvecs_res<Q>; ++j) {
+                        for (std::size_t i = b; i < e; ++i) {
+                            *(out[j] + static_cast<diff_t>(i)) = ptrs[j][i];
+                        }
                     }
                 }
-            }
+            });
         }
     }
     template <bool Ordered, unsigned Q, typename Allocator>

@@ -331,6 +331,11 @@ void free_state(rk_state *s)
     if (s->ev_mid) {
         (void)hipEventDestroy(s->ev_mid);
     }
+    for (auto &e : s->ev_arr) {
+        if (e) {
+            (void)hipEventDestroy(e);
+        }
+    }
     if (s->cap_stream) {
         (void)hipStreamDestroy(s->cap_stream);
     }
@@ -2323,8 +2328,12 @@ int rk_acc_pot(rk_state *s, int q, int64_t p_begin, int64_t p_end, void *const *
         if (p_begin < 0 || p_end < p_begin || p_end > s->nparts) {
             throw rk::error(RK_EINVAL, "invalid particle range");
         }
-        if (offset_output & ~RK_OUT_OFFSET) {
-            throw rk::error(RK_EINVAL, "rk_acc_pot() supports only RK_OUT_COMPACT / RK_OUT_OFFSET outputs");
+        if (offset_output & ~(RK_OUT_OFFSET | RK_OUT_ORDERED)) {
+            throw rk::error(RK_EINVAL, "rk_acc_pot(): invalid output flags");
+        }
+        if ((offset_output & RK_OUT_ORDERED) && (p_begin != 0 || p_end != s->nparts)) {
+            throw rk::error(RK_EINVAL, "rk_acc_pot() with RK_OUT_ORDERED (original-order host outputs) takes the whole range "
+                                       "[0, nparts): the results are scattered all over the output arrays");
         }
         const size_t fsz = s->fp == RK_F32 ? sizeof(float) : sizeof(double);
         const auto count = static_cast<size_t>(p_end - p_begin);
@@ -2334,6 +2343,86 @@ int rk_acc_pot(rk_state *s, int q, int64_t p_begin, int64_t p_end, void *const *
         }
         device_guard dg(s->device);
         const size_t need = count * fsz * static_cast<size_t>(nres);
+        if (offset_output & RK_OUT_ORDERED) {
+            // accs_o / pots_o for host arrays (tree.hpp:3320-3330): the kernels scatter the results through perm into a buffer
+            // in HBM (where random 4-byte stores cost nothing: the RK_OUT_ORDERED epilogue of rk_acc_pot_device), the ordered
+            // arrays then travel in one piece each -- straight into pinned arrays, through the staging buffer and the host
+            // threads otherwise, array k being delivered while array k + 1 is still on its way. A host-side scatter of
+            // 3 x 4M values through a random permutation costs 6 ms on eight threads (30 ms on one); this, 1.3 ms.
+            if (s->d_out_bytes < need) {
+                if (s->d_out) {
+                    RK_HIP(hipDeviceSynchronize());
+                    rk::pool_free(s->d_out);
+                    s->d_out = nullptr;
+                    s->d_out_bytes = 0;
+                }
+                s->d_out = rk::pool_alloc(need);
+                s->d_out_bytes = need;
+            }
+            const size_t arr = count * fsz;
+            void *d_ptrs[4] = {};
+            unsigned char *dst[4] = {};
+            for (int k = 0; k < nres; ++k) {
+                d_ptrs[k] = static_cast<unsigned char *>(s->d_out) + static_cast<size_t>(k) * arr;
+                dst[k] = static_cast<unsigned char *>(out[k]);
+            }
+            if (s->fp == RK_F32) {
+                run_impl<float>(*s, q, p_begin, p_end, d_ptrs, mac_value, G, eps2, RK_OUT_OFFSET | RK_OUT_ORDERED, nullptr, false);
+            } else {
+                run_impl<double>(*s, q, p_begin, p_end, d_ptrs, mac_value, G, eps2, RK_OUT_OFFSET | RK_OUT_ORDERED, nullptr, false);
+            }
+            bool pinned = true;
+            for (int k = 0; pinned && k < nres; ++k) {
+                pinned = device_view_of_host_range(dst[k], arr) != nullptr;
+            }
+            if (pinned || need < (size_t(1) << 20)) {
+                for (int k = 0; k < nres; ++k) {
+                    RK_HIP(hipMemcpyAsync(dst[k], d_ptrs[k], arr, hipMemcpyDeviceToHost, nullptr));
+                }
+                RK_HIP(hipStreamSynchronize(nullptr));
+                return;
+            }
+            if (s->h_stage_bytes < need) {
+                if (s->h_stage) {
+                    RK_HIP(hipDeviceSynchronize());
+                    stage_give(phys(s->device), s->h_stage, s->h_stage_bytes);
+                    s->h_stage = nullptr;
+                    s->h_stage_bytes = 0;
+                }
+                size_t got = 0;
+                s->h_stage = stage_take(phys(s->device), need, got);
+                if (s->h_stage) {
+                    s->h_stage_bytes = got;
+                } else {
+                    RK_HIP(hipHostMalloc(&s->h_stage, need, hipHostMallocDefault));
+                    s->h_stage_bytes = need;
+                }
+            }
+            auto *stage = static_cast<unsigned char *>(s->h_stage);
+            for (int k = 0; k < nres; ++k) {
+                if (!s->ev_arr[k]) {
+                    RK_HIP(hipEventCreateWithFlags(&s->ev_arr[k], hipEventDisableTiming));
+                }
+                RK_HIP(hipMemcpyAsync(stage + static_cast<size_t>(k) * arr, d_ptrs[k], arr, hipMemcpyDeviceToHost, nullptr));
+                RK_HIP(hipEventRecord(s->ev_arr[k], nullptr));
+            }
+            static const int max_thr_o = [] {
+                const char *e = std::getenv("RK_HOST_THREADS");
+                const int v = e ? std::atoi(e) : 8;
+                return v < 1 ? 1 : v;
+            }();
+            const size_t piece = size_t(2) << 20;
+            for (int k = 0; k < nres; ++k) {
+                RK_HIP(hipEventSynchronize(s->ev_arr[k]));
+                const int n_items = static_cast<int>((arr + piece - 1) / piece);
+                const int n_thr = std::max(1, std::min<int>({max_thr_o, n_items, static_cast<int>(std::thread::hardware_concurrency())}));
+                delivery_pool::get().run(n_items, n_thr, [&](int item) {
+                    const size_t off = static_cast<size_t>(item) * piece;
+                    stream_copy(dst[k] + off, stage + static_cast<size_t>(k) * arr + off, std::min(piece, arr - off));
+                });
+            }
+            return;
+        }
         // No hipGraph capture on this path: the callers of the host entry point drive several devices from several host
         // threads (kwargs::split), and a capture in one thread makes legacy-stream operations of the others fail
         // (hipErrorStreamCaptureImplicit). The 35 us a replay saves vanish next to the transfer of the results.

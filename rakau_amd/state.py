@@ -213,15 +213,17 @@ class State:
         _capi.check(_capi.lib().rk_state_graph_stats(self._h, a))
         return dict(zip(("replays", "captures", "direct", "retargeted", "cached", "forked_alive"), (int(v) for v in a)))
 
-    def acc_pot(self, q, mac_value, G=1.0, eps2=0.0, p_begin=0, p_end=None, out=None, offset_output=True):
+    def acc_pot(self, q, mac_value, G=1.0, eps2=0.0, p_begin=0, p_end=None, out=None, offset_output=True, ordered=False):
         """rocm_state::acc_pot<Q>: host outputs (numpy). Returns the list of output arrays. Arrays in pinned memory
-        (pinned_empty()) are written by the kernels directly."""
+        (pinned_empty()) are written by the kernels directly. ordered=True (whole range only, after set_perm()): the
+        result of every particle at its ORIGINAL index (accs_o / pots_o), scattered on the device."""
         p_end = self.nparts if p_end is None else p_end
         if out is None:
-            n = self.nparts if offset_output else p_end - p_begin
+            n = self.nparts if (offset_output or ordered) else p_end - p_begin
             out = [np.zeros(n, dtype=self.dtype) for _ in range(nres(q, self.ndim))]
         ptrs = (C.c_void_p * 4)(*[o.ctypes.data for o in out], *([None] * (4 - len(out))))
-        _capi.check(_capi.lib().rk_acc_pot(self._h, q, p_begin, p_end, ptrs, mac_value, G, eps2, int(offset_output)))
+        flags = (_capi.RK_OUT_OFFSET | _capi.RK_OUT_ORDERED) if ordered else int(bool(offset_output))
+        _capi.check(_capi.lib().rk_acc_pot(self._h, q, p_begin, p_end, ptrs, mac_value, G, eps2, flags))
         return out
 
     def acc_pot_device(self, q, mac_value, d_ptrs, G=1.0, eps2=0.0, p_begin=0, p_end=None, offset_output=True,

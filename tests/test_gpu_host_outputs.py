@@ -145,3 +145,37 @@ print("slices ok")
     e["PYTHONPATH"] = os.pathsep.join([ROOT, os.path.join(ROOT, "tests"), e.get("PYTHONPATH", "")])
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=e, cwd=ROOT)
     assert out.returncode == 0 and "slices ok" in out.stdout, out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("dtype,n", [(np.float32, 20000), (np.float32, 700000), (np.float64, 150000)])
+def test_ordered_host_outputs(dtype, n):
+    """rk_acc_pot(RK_OUT_OFFSET | RK_OUT_ORDERED): accs_o / pots_o / accs_pots_o into host arrays (tree.hpp:3320-3330). The
+    kernels scatter through perm into HBM, the ordered arrays travel whole: same bits as the Morton-order result indexed by
+    the inverse permutation, for pageable (small: straight copy; large: staged, delivered by the host threads) and pinned
+    arrays. Sub-ranges and a state without perm are refused."""
+    m, x, y, z = oracle.plummer(n, dtype)
+    ot = oracle.Tree(x, y, z, m)
+    st = state_from_oracle(ot)
+    mv = rakau_amd.mac_value_of(0.75, "bh", dtype)
+    with pytest.raises(ValueError):
+        st.acc_pot(0, mv, ordered=True)  # no permutation yet
+    perm = ot.codes_perms()["perm"]
+    st.set_perm(perm)
+    for q in (0, 1, 2):
+        nres = rakau_amd.NRES[q]
+        ref = st.acc_pot(q, mv, eps2=1e-6)
+        for rep in range(2):
+            out = st.acc_pot(q, mv, eps2=1e-6, ordered=True, out=[np.full(n + 1, 7, dtype=dtype)[1:] for _ in range(nres)])
+            for k in range(nres):
+                assert np.array_equal(out[k][perm], ref[k])
+        pin = [rakau_amd.pinned_empty(n, dtype) for _ in range(nres)]
+        st.acc_pot(q, mv, eps2=1e-6, ordered=True, out=pin)
+        for k in range(nres):
+            assert np.array_equal(pin[k][perm], ref[k])
+    cr = st.crit_ranges()
+    with pytest.raises(ValueError):
+        st.acc_pot(0, mv, ordered=True, p_begin=int(cr[1, 0]))
+    # a compact call after the ordered ones is untouched by them
+    again = st.acc_pot(0, mv, eps2=1e-6)
+    ref0 = st.acc_pot(0, mv, eps2=1e-6)
+    assert all(np.array_equal(a, b) for a, b in zip(again, ref0))

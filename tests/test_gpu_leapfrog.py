@@ -84,13 +84,18 @@ def test_ordered_output_needs_perm_and_set_perm_provides_it():
     ref = t.accs_o(0.5)
     for o, r in zip(outs, ref):
         assert np.array_equal(o.cpu().numpy(), r)
-    # The host entry point has no ordered mode.
-    with pytest.raises(ValueError, match="RK_OUT_COMPACT / RK_OUT_OFFSET"):
-        from rakau_amd import _capi
-        import ctypes as C
-        hout = [np.zeros(5000) for _ in range(3)]
-        ptrs = (C.c_void_p * 4)(*[o.ctypes.data for o in hout], None)
-        _capi.check(_capi.lib().rk_acc_pot(st._h, 0, 0, 5000, ptrs, mv, 1.0, 0.0, _capi.RK_OUT_ORDERED))
+    # The host entry point scatters on the device as well (whole range only); unknown flag bits are refused.
+    from rakau_amd import _capi
+    import ctypes as C
+    hout = [np.zeros(5000) for _ in range(3)]
+    ptrs = (C.c_void_p * 4)(*[o.ctypes.data for o in hout], None)
+    _capi.check(_capi.lib().rk_acc_pot(st._h, 0, 0, 5000, ptrs, mv, 1.0, 0.0, _capi.RK_OUT_ORDERED))
+    for o, r in zip(hout, ref):
+        assert np.array_equal(o, r)
+    with pytest.raises(ValueError, match="invalid output flags"):
+        _capi.check(_capi.lib().rk_acc_pot(st._h, 0, 0, 5000, ptrs, mv, 1.0, 0.0, 4))
+    with pytest.raises(ValueError, match="takes the whole range"):
+        _capi.check(_capi.lib().rk_acc_pot(st._h, 0, 0, int(st.crit_ranges()[1, 0]), ptrs, mv, 1.0, 0.0, _capi.RK_OUT_ORDERED))
 
 
 def test_set_perm_between_identical_ordered_calls():
