@@ -27,10 +27,46 @@
 #define RK_PC_W64 4 // fp64
 #endif
 
+#ifndef RK_PC_NB
+#define RK_PC_NB 2 // tile buffers per workgroup: 2 = hand-off at a workgroup barrier per tile; 4 / 8 = ring with counters in LDS
+#endif
+static_assert(RK_PC_NB == 2 || RK_PC_NB == 4 || RK_PC_NB == 8);
+#ifndef RK_PC_NCONS
+// Consumer wavefronts per workgroup at most (a node of class R uses min(R, RK_PC_NCONS); with fewer consumers than target
+// slots a consumer takes two). A launch that cannot fill the device is bound by how many NODES are resident, and workgroups
+// are admitted whole: five-wave workgroups (one consumer per slot) were resident 3.1 per CU, three-wave workgroups ~6.
+// k_pc_any, kernel ms, 4 -> 3 -> 2 -> 1 consumers: 100k particles 0.137 / 0.112 / 0.107 / 0.137, 150k 0.198 / 0.157 / 0.145 /
+// 0.155, 250k 0.31 / 0.23 / 0.217 / 0.198, 350k 0.43 / 0.32 / 0.29 / 0.26 (k_list_any 0.245); fp64 100k 0.248 / - / 0.191 / 0.206
+// (profiles/r04/pc_consumers_per_workgroup.txt). Same bits whatever the value.
+#define RK_PC_NCONS 2
+#endif
+static_assert(RK_PC_NCONS >= 1 && RK_PC_NCONS <= 4);
+
 namespace rk
 {
 
 constexpr uint32_t PC_LAST = 0x80000000u;
+
+// Ring hand-off (RK_PC_NB > 2): counters in LDS, written by lane 0 of one wavefront and polled by the others. DS operations
+// of a wavefront execute in order and the LDS serves one instruction at a time, so a counter stored after a tile's stores
+// is seen after them. A wait that outlives any node by orders of magnitude (0.5 s) aborts the kernel instead of hanging.
+__device__ __forceinline__ void pc_wait_ge(const uint32_t *p, uint32_t v)
+{
+    unsigned spins = 0;
+    while (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < v) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 23)) {
+            __builtin_trap();
+        }
+    }
+}
+__device__ __forceinline__ void pc_signal(uint32_t *p, uint32_t v, int lane)
+{
+    wave_sync();
+    if (lane == 0) {
+        __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
 
 // Workgroup LDS: producer-private stack and queues, two tiles of src_cap sources, the published counts.
 // fp32: 2 + 1 + 0.5 + 4 KiB = 7.5 KiB per group.
@@ -39,8 +75,9 @@ struct pc_lds {
     uint32_t stack[LK_STACK_CAP];
     uint2 lq[LK_LQ_CAP];
     uint32_t uq[LK_UQ_CAP];
-    uint32_t tile_n[2];
-    typename vt<F>::v4 tile[2][lk_cfg<F>::src_cap];
+    uint32_t tile_n[RK_PC_NB];
+    uint32_t sync[8]; // ring: [0] tiles published, [1 + c] tiles finished by consumer c
+    typename vt<F>::v4 tile[RK_PC_NB][lk_cfg<F>::src_cap];
 };
 
 // Everything the workgroup (1 + R wavefronts; `role` 0 = producer, 1 + c = consumer c) does for critical node g. Shared by
@@ -56,7 +93,7 @@ __device__ __forceinline__ void pc_node(const kparams<F> &P, pc_lds<F> &L, const
     constexpr int TILE_CAP = SRC_CAP;
     static_assert(R >= 1 && R <= 4);
     // The consumers' split-reduction scratch (64 * NR values each) lives in the two tiles.
-    static_assert(2 * lk_cfg<F>::src_cap * 4 * sizeof(F) >= size_t(R) * 64 * 4 * sizeof(F), "reduction scratch does not fit");
+    static_assert(RK_PC_NB * lk_cfg<F>::src_cap * 4 * sizeof(F) >= size_t(R) * 64 * 4 * sizeof(F), "reduction scratch does not fit");
     const uint4 c = P.crit[g];
     const uint32_t tb = c.x, te = c.y, cnode = c.z;
     const int T = static_cast<int>(te - tb);
@@ -71,101 +108,161 @@ __device__ __forceinline__ void pc_node(const kparams<F> &P, pc_lds<F> &L, const
     const bool lane_on = sp_raw < NS;
     const int sp = lane_on ? sp_raw : 0; // idle lanes shadow split 0; their results are never stored
     const F eps2 = P.eps2;
+    constexpr int NB = RK_PC_NB;
+    if constexpr (NB > 2) {
+        if (role == 0 && lane < 8) {
+            L.sync[lane] = 0u;
+        }
+        __syncthreads();
+    }
 
+    // Consumers per workgroup: min(R, RK_PC_NCONS). With fewer consumers than target slots a consumer takes several slots
+    // (CR targets per lane, the multi-target body of the list kernel): every target still receives the sources of its split
+    // in list order, so the bits do not depend on how the slots are dealt out.
+    constexpr int NC = R < RK_PC_NCONS ? R : RK_PC_NCONS;
     if (role != 0) {
         // =====================================================================================================
-        // Consumer c: dense evaluation of the published tiles for target c * TP + ts.
+        // Consumer `cons`: dense evaluation of the published tiles for target slots r0 .. r0 + CR - 1 (targets r * TP + ts).
         // =====================================================================================================
         const int cons = role - 1;
-        v4 tp[1];
-        int tidx[1];
-        tidx[0] = ts + cons * TP;
-        {
-            const bool valid = tidx[0] < T;
-            tp[0] = P.part4[tb + (valid ? tidx[0] : 0)];
-            if (!valid) {
-                tidx[0] = -1;
-            }
-        }
-        F acc[1][NR];
+        auto consume = [&](auto CRtag, const int r0) __attribute__((always_inline)) {
+            constexpr int CR = decltype(CRtag)::value;
+            v4 tp[CR];
+            int tidx[CR];
 #pragma unroll
-        for (int k = 0; k < NR; ++k) {
-            acc[0][k] = F(0);
-        }
-        // n / NS for n <= SRC_CAP without a division per tile: exact for n * NS < 2^16.
-        const int inv_ns = (65536 + NS - 1) / NS;
-        static_assert(lk_cfg<F>::src_cap * 64 < 65536);
-        int buf = 0;
-        for (;;) {
-            __syncthreads(); // tile `buf` is published; the producer now owns the other buffer
-            const uint32_t word = L.tile_n[buf];
-            const int n = static_cast<int>(word & ~PC_LAST);
-            if (n > 0) {
-                lk_eval_tile<F, Q, 1, false, ND>(L.tile[buf], n, (n * inv_ns) >> 16, sp, NS, true, lane_on, tp, acc, eps2, tidx);
-            }
-            if (word & PC_LAST) {
-                break;
-            }
-            buf ^= 1;
-        }
-        // ---- interactions inside the group: its own particles as sources, self pair masked ----
-        // The producer has published its last tile and left: the buffer it would fill next is free. Consumer 0 loads the
-        // group's particles, every consumer evaluates them for its own targets.
-        {
-            v4 *self = L.tile[buf ^ 1];
-            for (int b0 = 0; b0 < T; b0 += SRC_CAP) {
-                const int n = (T - b0) < SRC_CAP ? (T - b0) : SRC_CAP;
-                if (cons == 0) {
-                    for (int j = lane; j < n; j += 64) {
-                        self[j] = P.part4[tb + static_cast<uint32_t>(b0 + j)];
-                    }
-                }
-                if constexpr (R > 1) {
-                    __syncthreads();
-                } else {
-                    wave_sync();
-                }
-                int tloc[1];
-                tloc[0] = tidx[0] < 0 ? -1 : tidx[0] - b0;
-                lk_eval_tile<F, Q, 1, true, ND>(self, n, (n * inv_ns) >> 16, sp, NS, true, lane_on, tp, acc, eps2, tloc);
-                if constexpr (R > 1) {
-                    __syncthreads();
-                } else {
-                    wave_sync();
+            for (int j = 0; j < CR; ++j) {
+                tidx[j] = ts + (r0 + j) * TP;
+                const bool valid = tidx[j] < T;
+                tp[j] = P.part4[tb + (valid ? tidx[j] : 0)];
+                if (!valid) {
+                    tidx[j] = -1;
                 }
             }
-        }
-        // ---- sum the source splits in a fixed order (scratch: this consumer's share of the two tiles) ----
-        if (NS > 1) {
-            F *red = reinterpret_cast<F *>(&L.tile[0][0]) + cons * 64 * NR;
-            if (lane_on) {
+            F acc[CR][NR];
+#pragma unroll
+            for (int j = 0; j < CR; ++j) {
 #pragma unroll
                 for (int k = 0; k < NR; ++k) {
-                    red[(sp_raw * TP + ts) * NR + k] = acc[0][k];
+                    acc[j][k] = F(0);
                 }
             }
-            wave_sync();
+            // n / NS for n <= SRC_CAP without a division per tile: exact for n * NS < 2^16.
+            const int inv_ns = (65536 + NS - 1) / NS;
+            static_assert(lk_cfg<F>::src_cap * 64 < 65536);
+            int buf = 0;
+            if constexpr (NB == 2) {
+                for (;;) {
+                    __syncthreads(); // tile `buf` is published; the producer now owns the other buffer
+                    const uint32_t word = L.tile_n[buf];
+                    const int n = static_cast<int>(word & ~PC_LAST);
+                    if (n > 0) {
+                        lk_eval_tile<F, Q, CR, false, ND>(L.tile[buf], n, (n * inv_ns) >> 16, sp, NS, true, lane_on, tp, acc, eps2, tidx);
+                    }
+                    if (word & PC_LAST) {
+                        break;
+                    }
+                    buf ^= 1;
+                }
+            } else {
+                // Ring: tile i sits in buffer i % NB once the producer has counted it; this consumer counts it when done.
+                for (uint32_t it = 0;;) {
+                    pc_wait_ge(&L.sync[0], it + 1u);
+                    buf = static_cast<int>(it & static_cast<uint32_t>(NB - 1));
+                    const uint32_t word = L.tile_n[buf];
+                    const int n = static_cast<int>(word & ~PC_LAST);
+                    if (n > 0) {
+                        lk_eval_tile<F, Q, CR, false, ND>(L.tile[buf], n, (n * inv_ns) >> 16, sp, NS, true, lane_on, tp, acc, eps2, tidx);
+                    }
+                    ++it;
+                    pc_signal(&L.sync[1 + cons], it, lane);
+                    if (word & PC_LAST) {
+                        break;
+                    }
+                }
+                if constexpr (NC > 1) {
+                    __syncthreads(); // every consumer has finished every tile (the producer has left or is leaving)
+                }
+            }
+            // ---- interactions inside the group: its own particles as sources, self pair masked ----
+            // The producer has published its last tile and left: the buffer it would fill next is free. Consumer 0 loads the
+            // group's particles, every consumer evaluates them for its own targets.
+            {
+                v4 *self = L.tile[NB == 2 ? (buf ^ 1) : 0];
+                for (int b0 = 0; b0 < T; b0 += SRC_CAP) {
+                    const int n = (T - b0) < SRC_CAP ? (T - b0) : SRC_CAP;
+                    if (cons == 0) {
+                        for (int j = lane; j < n; j += 64) {
+                            self[j] = P.part4[tb + static_cast<uint32_t>(b0 + j)];
+                        }
+                    }
+                    if constexpr (NC > 1) {
+                        __syncthreads();
+                    } else {
+                        wave_sync();
+                    }
+                    int tloc[CR];
+#pragma unroll
+                    for (int j = 0; j < CR; ++j) {
+                        tloc[j] = tidx[j] < 0 ? -1 : tidx[j] - b0;
+                    }
+                    lk_eval_tile<F, Q, CR, true, ND>(self, n, (n * inv_ns) >> 16, sp, NS, true, lane_on, tp, acc, eps2, tloc);
+                    if constexpr (NC > 1) {
+                        __syncthreads();
+                    } else {
+                        wave_sync();
+                    }
+                }
+            }
+            // ---- sum the source splits in a fixed order (scratch: one region of 64 * NR values per target slot) ----
+            if (NS > 1) {
+                F *red = reinterpret_cast<F *>(&L.tile[0][0]) + r0 * 64 * NR;
+                if (lane_on) {
+#pragma unroll
+                    for (int j = 0; j < CR; ++j) {
+#pragma unroll
+                        for (int k = 0; k < NR; ++k) {
+                            red[j * 64 * NR + (sp_raw * TP + ts) * NR + k] = acc[j][k];
+                        }
+                    }
+                }
+                wave_sync();
+                if (lane_on && sp_raw == 0) {
+#pragma unroll
+                    for (int j = 0; j < CR; ++j) {
+#pragma unroll
+                        for (int k = 0; k < NR; ++k) {
+                            F sum = F(0);
+                            for (int s = 0; s < NS; ++s) {
+                                sum += red[j * 64 * NR + (s * TP + ts) * NR + k];
+                            }
+                            acc[j][k] = sum;
+                        }
+                    }
+                }
+            }
+            // ---- scale by G, write out ----
             if (lane_on && sp_raw == 0) {
+                const F G = P.G;
 #pragma unroll
-                for (int k = 0; k < NR; ++k) {
-                    F sum = F(0);
-                    for (int s = 0; s < NS; ++s) {
-                        sum += red[(s * TP + ts) * NR + k];
+                for (int j = 0; j < CR; ++j) {
+                    if (tidx[j] >= 0) {
+                        const uint32_t o = out_index(P, tb + static_cast<uint32_t>(tidx[j]));
+#pragma unroll
+                        for (int k = 0; k < NR; ++k) {
+                            if (ND == 3 || Q == 1 || k != 2) { // a quadtree has no z acceleration (and no array for it)
+                                P.out[k][o] = acc[j][k] * G;
+                            }
+                        }
                     }
-                    acc[0][k] = sum;
                 }
             }
-        }
-        // ---- scale by G, write out ----
-        if (lane_on && sp_raw == 0 && tidx[0] >= 0) {
-            const F G = P.G;
-            const uint32_t o = out_index(P, tb + static_cast<uint32_t>(tidx[0]));
-#pragma unroll
-            for (int k = 0; k < NR; ++k) {
-                if (ND == 3 || Q == 1 || k != 2) { // a quadtree has no z acceleration (and no array for it)
-                    P.out[k][o] = acc[0][k] * G;
-                }
-            }
+        };
+        // Slots dealt out as evenly as possible: the first R % NC consumers take one more.
+        constexpr int CR_LO = R / NC, N_HI = R % NC;
+        if (N_HI != 0 && cons < N_HI) {
+            consume(std::integral_constant<int, CR_LO + (N_HI != 0 ? 1 : 0)>{}, cons * (CR_LO + 1));
+        } else {
+            consume(std::integral_constant<int, CR_LO>{}, N_HI * (CR_LO + 1) + (cons - N_HI) * CR_LO);
         }
 #ifdef RK_TRACE
         if (cons == 0 && lane == 0 && P.dbg) {
@@ -222,12 +319,25 @@ __device__ __forceinline__ void pc_node(const kparams<F> &P, pc_lds<F> &L, const
 
     // Hand the current tile to the consumers and take the other buffer (which they have finished with once they
     // arrive at this barrier).
+    [[maybe_unused]] uint32_t n_pub = 0;
     auto publish = [&](bool last) __attribute__((always_inline)) {
         if (lane == 0) {
             L.tile_n[cur] = static_cast<uint32_t>(n_src) | (last ? PC_LAST : 0u);
         }
-        __syncthreads();
-        cur ^= 1;
+        if constexpr (NB == 2) {
+            __syncthreads();
+            cur ^= 1;
+        } else {
+            ++n_pub;
+            pc_signal(&L.sync[0], n_pub, lane);
+            cur = (cur + 1) & (NB - 1);
+            if (!last && n_pub >= static_cast<uint32_t>(NB)) {
+                // The buffer of tile n_pub held tile n_pub - NB: every consumer must have counted it.
+                for (int c = 0; c < NC; ++c) {
+                    pc_wait_ge(&L.sync[1 + c], n_pub - static_cast<uint32_t>(NB) + 1u);
+                }
+            }
+        }
         src = L.tile[cur];
         n_src = 0;
     };
@@ -544,7 +654,7 @@ __device__ __forceinline__ void pc_node(const kparams<F> &P, pc_lds<F> &L, const
 }
 
 template <typename F, int Q, int MAC, int R, int ND>
-__global__ void __launch_bounds__(64 * (1 + R), (sizeof(F) == 4 ? RK_PC_W : RK_PC_W64))
+__global__ void __launch_bounds__(64 * (1 + (R < RK_PC_NCONS ? R : RK_PC_NCONS)), (sizeof(F) == 4 ? RK_PC_W : RK_PC_W64))
     k_pc(const kparams<F> P, const uint32_t *__restrict__ list, int n_list)
 {
     __shared__ pc_lds<F> L;
@@ -565,7 +675,7 @@ __global__ void __launch_bounds__(64 * (1 + R), (sizeof(F) == 4 ? RK_PC_W : RK_P
 // wavefronts, of which a node of class R uses 1 + R; the others return before the first barrier (a barrier waits only for
 // the wavefronts of the workgroup that are still alive).
 template <typename F, int Q, int MAC, int ND>
-__global__ void __launch_bounds__(64 * 5, (sizeof(F) == 4 ? RK_PC_W : RK_PC_W64))
+__global__ void __launch_bounds__(64 * (1 + RK_PC_NCONS), (sizeof(F) == 4 ? RK_PC_W : RK_PC_W64))
     k_pc_any(const kparams<F> P, const uint32_t *__restrict__ list, int n_list)
 {
     __shared__ pc_lds<F> L;
@@ -580,7 +690,7 @@ __global__ void __launch_bounds__(64 * 5, (sizeof(F) == 4 ? RK_PC_W : RK_PC_W64)
         return;
     }
     const int cls = class2_of_compute(static_cast<int64_t>(__builtin_amdgcn_readfirstlane(P.crit[g].w)));
-    if (cls < 0 || cls >= RK_MAX_R || role > cls + 1) {
+    if (cls < 0 || cls >= RK_MAX_R || role > (cls + 1 < RK_PC_NCONS ? cls + 1 : RK_PC_NCONS)) {
         return;
     }
     switch (cls) {
@@ -607,10 +717,10 @@ static void launch_pc_qm(const rk_state &s, const kparams<F> &p, const int64_t c
         }
         const auto grid = static_cast<unsigned>(n);
         if (s.ndim == 3 || !RK_QUAD_BODY) {
-            hipLaunchKernelGGL((k_pc<F, Q, MAC, R, 3>), dim3(grid), dim3(64 * (1 + R)), 0, streams[c], p,
+            hipLaunchKernelGGL((k_pc<F, Q, MAC, R, 3>), dim3(grid), dim3(64 * (1 + (R < RK_PC_NCONS ? R : RK_PC_NCONS))), 0, streams[c], p,
                                lists + s.cur_off[c] + cb[c], static_cast<int>(n));
         } else {
-            hipLaunchKernelGGL((k_pc<F, Q, MAC, R, 2>), dim3(grid), dim3(64 * (1 + R)), 0, streams[c], p,
+            hipLaunchKernelGGL((k_pc<F, Q, MAC, R, 2>), dim3(grid), dim3(64 * (1 + (R < RK_PC_NCONS ? R : RK_PC_NCONS))), 0, streams[c], p,
                                lists + s.cur_off[c] + cb[c], static_cast<int>(n));
         }
     };
@@ -628,7 +738,7 @@ void launch_pc_any(const rk_state &s, int q, const kparams<F> &p, const uint32_t
     if (n <= 0) {
         return;
     }
-    const dim3 grid(static_cast<unsigned>(n)), block(64 * 5);
+    const dim3 grid(static_cast<unsigned>(n)), block(64 * (1 + RK_PC_NCONS));
     const int cnt = static_cast<int>(n);
     auto go = [&](auto Qt, auto Mt) {
         constexpr int Q = decltype(Qt)::value, M = mac_targ(decltype(Mt)::value);

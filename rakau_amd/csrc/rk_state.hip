@@ -1030,6 +1030,19 @@ void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64
     s.plan.p_begin = p_begin, s.plan.p_end = p_end, s.plan.mac_value = mac_value;
 }
 
+// Calls over at most this many critical nodes take the one-launch producer / consumer kernel, larger ones k_list_any.
+// Round 4 (three-wave workgroups, rk_kernels_pc.hip RK_PC_NCONS): k_pc_any / k_list_any kernel ms at 4.2k nodes 0.145 / 0.198,
+// 5.6k 0.180 / 0.205, 6.5k 0.218 / 0.218, 8.4k 0.256 / 0.231 (round 3, five-wave workgroups: equal at 4.2k, limit 4000);
+// fp64: 2.9k 0.194 / 0.245, 4.2k 0.257 / 0.281, 5.6k 0.328 / 0.305, 6.5k 0.405 / 0.343 (tools/pc_ring_probe.py).
+int64_t pc_any_below_nodes(bool fp64)
+{
+    static const int64_t env = [] {
+        const char *e = std::getenv("RK_PC_ANY_BELOW");
+        return e ? std::atoll(e) : int64_t(-1);
+    }();
+    return env >= 0 ? env : (fp64 ? int64_t(5000) : int64_t(6000));
+}
+
 bool super_cache_enabled()
 {
     static const bool on = [] {
@@ -1512,10 +1525,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
             // 4.2k nodes: class launches on the producer / consumer kernel 0.173, k_pc_any 0.196 (its five-wave workgroups
             // are admitted four per CU), k_list_any 0.193; 5.6k nodes: k_list_any 0.205 (class launches 0.25), 6.5k: 0.215
             // (0.27); 54k nodes (2M particles): 1.19 (1.22).
-            static const int64_t pc_any_below = [] {
-                const char *e = std::getenv("RK_PC_ANY_BELOW");
-                return e ? std::atoll(e) : int64_t(4000);
-            }();
+            const int64_t pc_any_below = pc_any_below_nodes(sizeof(F) == 8);
             // (Since forked launch sequences are no longer replayed from a graph, the class launches of 3.2k-5k nodes lost
             // their place -- queued calls, ms: 3.6k nodes 0.167, k_pc_any 0.155, k_list_any 0.177; 3.9k: 0.275 / 0.178 / 0.181;
             // 4.5k: 0.202 / 0.202 / 0.186; 5.1k: 0.335 / 0.230 / 0.192 -- tools/any_probe3.py.)
@@ -1547,7 +1557,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                 && g_hi <= any_first_max && n_wave > 0 && n_wave == g_hi - (big_e - big_b)) {
                 first_list = s.cur_lists + s.class2_off[0];
                 first_n = n_wave;
-                any_mode = (any_env == 1 || any_env == 3) ? any_env : (g_hi <= 4000 ? 1 : 3);
+                any_mode = (any_env == 1 || any_env == 3) ? any_env : (g_hi <= pc_any_below_nodes(sizeof(F) == 8) ? 1 : 3);
                 p.any_rev = 1;
                 p.xcd_mode = 0; // chunks of consecutive entries dealt round-robin to the XCDs, as for a heavy-first plan
             }

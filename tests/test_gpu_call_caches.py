@@ -87,7 +87,7 @@ np.savez(sys.argv[1], **res)
 """
     files = []
     # plain: no plan (full-range calls: one launch over the reversed class lists); tail / tail_chunks: the light-tail plan; the rest: the heavy-first plan of small calls with its
-    # one-launch kernels (k_pc_any up to 4000 critical nodes, k_list_any above; forced both ways, and the mixed forms).
+    # one-launch kernels (k_pc_any up to 6000 critical nodes, k_list_any above; forced both ways, and the mixed forms).
     for name, extra in (("plain", {"RK_PLAN": "0"}), ("tail", {"RK_PLAN_MAX_GROUPS": "64"}),
                         ("tail_chunks", {"RK_PLAN_MAX_GROUPS": "64", "RK_PLAN_REGIONS": "0"}),
                         ("heavy_first_auto", {}), ("pc_any", {"RK_ANY": "1"}), ("list_any", {"RK_ANY": "3"}),
