@@ -167,6 +167,9 @@ def main():
                     help="let repeated calls on the resident tree reuse the output of the supergroup pre-pass (the "
                          "library's default, +1.5 %% at 4M); by default every timed step runs the whole traversal")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pageable-leg", action="store_true",
+                    help="skip the extra calls into pageable arrays after the timed steps (profiling runs: their sub-range "
+                         "launches would mix into the per-kernel averages of the timed steps)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all host cores)")
     args = ap.parse_args()
 
@@ -553,7 +556,7 @@ def main():
     # The same call into plain pageable arrays (what a tree.hpp user with std::vector<F> outputs pays per accs_u() on a
     # resident tree: the results go through the library's pinned staging buffer and are delivered by host threads).
     try:
-        if world == 1:
+        if world == 1 and not args.no_pageable_leg:
             host_out = [np.zeros(n, dtype=dtype) for _ in range(nres)]
             def settle_and_time(arrays):
                 ts, busy = [], 0.0

@@ -12,6 +12,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
+if [ "${2:-}" != "prof-only" ]; then
 ( time timeout 1500 python3 -m pytest tests -m gpu -q --durations=12 ) > $OUT/pytest_gpu.log 2>&1; tail -4 $OUT/pytest_gpu.log
 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; cut -c1-300 $OUT/bench_default.json
 for wl in plummer4m_f32_accpot plummer16m_f64 plummer64m_f32 plummer100k_f32; do
@@ -20,9 +21,12 @@ done
 timeout 600 python3 bench.py --builder device > $OUT/bench_device_builder.json 2> $OUT/bench_device_builder.err
 RK_BENCH_SINGLE_DEVICE=1 RK_BENCH_BACKEND=gloo timeout 600 python3 bench.py --gpus 2 > $OUT/bench_selflaunch_2ranks_1gpu.json 2> $OUT/bench_selflaunch.err
 timeout 900 python3 tools/shard_sim.py 4000000 > $OUT/shard_sim.txt 2>&1
+fi
+# Profiling runs: bench.py --no-pageable-leg, i.e. the timed steps only (the extra calls into pageable arrays run in two
+# sub-range parts, whose launches would mix into the per-kernel averages).
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/overlapped -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/bench_overlapped.log 2>&1
-RK_SERIAL_CLASSES=1 RK_GRAPH=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/serial -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/bench_serial.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/overlapped -- python3 $ROOT/bench.py --no-cpu-baseline --no-pageable-leg > $OUT/bench_overlapped.log 2>&1
+RK_SERIAL_CLASSES=1 RK_GRAPH=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/serial -- python3 $ROOT/bench.py --no-cpu-baseline --no-pageable-leg > $OUT/bench_serial.log 2>&1
 BENCH_ARGS="" bash $ROOT/tools/prof_pmc.sh gpurun_out/$TAG/pmc > /dev/null 2>&1
 python3 $ROOT/tools/pmc_summary.py $OUT/pmc > $OUT/pmc_summary.txt 2>&1
 cd $ROOT
@@ -32,7 +36,7 @@ cp gpurun_out/traffic_plummer4m_f32.json $OUT/traffic.json 2>/dev/null
 cd /tmp
 for wl in 100k:plummer100k_f32:100000 1m:plummer100k_f32:1000000; do
   tag=${wl%%:*}; rest=${wl#*:}; key=${rest%%:*}; np=${rest#*:}
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/small_$tag -- python3 $ROOT/bench.py --workload $key --nparts $np --no-cpu-baseline > $OUT/bench_small_$tag.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/small_$tag -- python3 $ROOT/bench.py --workload $key --nparts $np --no-cpu-baseline --no-pageable-leg > $OUT/bench_small_$tag.log 2>&1
 done
 cd $ROOT
 # Kernel traces are large and not judged: keep the stats.

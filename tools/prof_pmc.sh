@@ -9,7 +9,7 @@ mkdir -p $ROOT/$OUT
 cd /tmp && export TMPDIR=/tmp
 run() {
   name=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d $ROOT/$OUT/$name -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline $BENCH_ARGS > $ROOT/$OUT/$name.log 2>&1
+  rocprofv3 --pmc "$@" --output-format csv -d $ROOT/$OUT/$name -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pageable-leg $BENCH_ARGS > $ROOT/$OUT/$name.log 2>&1
 }
 BENCH_ARGS="${BENCH_ARGS:-}"
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM
