@@ -1673,10 +1673,18 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                 }
             }
         };
-        if (use_graph && allow_graph) {
+        // The one-launch sequences (pre-pass + k_pc_any / k_list_any on one stream) are launched directly: replayed from a graph
+        // they are 3-8 us slower per call (device-resident ms per step, graph / direct: 100k 0.1141-0.1153 / 0.1109-0.1115, 350k
+        // 0.2598-0.2608 / 0.2522-0.2532, 1M 0.668 / 0.653-0.664; tools/jobs_r04/r04_job57.sh) -- round 2 measured the opposite for
+        // the four forked class kernels these sizes ran then. RK_GRAPH_LINEAR=1 captures them too.
+        static const bool graph_linear = [] {
+            const char *e = std::getenv("RK_GRAPH_LINEAR");
+            return e && std::atoi(e) != 0;
+        }();
+        const bool one_launch_seq = (any_mode == 1 || any_mode == 3) && !split;
+        if (use_graph && allow_graph && (!one_launch_seq || graph_linear)) {
             // A call that repeats the previous one (same range, outputs, parameters) replays a captured graph:
-            // one hipGraphLaunch instead of a handful of runtime calls (the one-launch kernels of small calls, where the
-            // launch overhead is a tenth of the call).
+            // one hipGraphLaunch instead of a handful of runtime calls and stream hand-overs (the forked class kernels).
             rk_state::graph_key key{};
             key.q = q, key.p_begin = p_begin, key.p_end = p_end, key.mac_value = mac_value, key.G = G, key.eps2 = eps2;
             key.offset_output = offset_output, key.super_k = s.super_k, key.variant = s.variant;

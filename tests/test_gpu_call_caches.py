@@ -99,7 +99,7 @@ np.savez(sys.argv[1], **res)
                         # graphs of forked sequences: parked, only the first two captured, never captured
                         ("forked_graphs_cap2", {"RK_PLAN": "0", "RK_ANY_FIRST": "0", "RK_GRAPH_FORKED_MAX": "2"}),
                         ("forked_graphs_off", {"RK_PLAN_MAX_GROUPS": "64", "RK_PLAN_REV_MAX_GROUPS": "0", "RK_GRAPH_FORKED": "0"}),
-                        ("no_graphs", {"RK_GRAPH": "0"})):
+                        ("no_graphs", {"RK_GRAPH": "0"}), ("linear_graphs", {"RK_GRAPH_LINEAR": "1"})):
         env = dict(os.environ, RK_BACKTRACE="1", PYTHONFAULTHANDLER="1", **extra)
         env["PYTHONPATH"] = os.pathsep.join([root, os.path.join(root, "tests"), env.get("PYTHONPATH", "")])
         f = str(tmp_path / (name + ".npz"))
@@ -115,12 +115,13 @@ np.savez(sys.argv[1], **res)
             assert np.array_equal(files[0][k], other[k]), k
 
 
-@pytest.mark.parametrize("name,extra,nsig", [("one_launch_8", {}, 8), ("forked_8", {"RK_PLAN": "0", "RK_ANY_FIRST": "0"}, 8),
+@pytest.mark.parametrize("name,extra,nsig", [("one_launch_8", {"RK_GRAPH_LINEAR": "1"}, 8), ("forked_8", {"RK_PLAN": "0", "RK_ANY_FIRST": "0"}, 8),
                                              ("forked_20_cap4", {"RK_PLAN": "0", "RK_ANY_FIRST": "0", "RK_GRAPH_FORKED_MAX": "4"}, 20)])
 def test_graph_cache_keeps_replay_for_recurring_signatures(name, extra, nsig):
     """tools/stress_graph_recurring.py: a caller alternating among `nsig` recurring signatures. Up to 8 (RK_GRAPH_CACHE) every
     signature is captured once and replayed ever after -- linear graphs (one-launch kernels) and forked ones (class kernels on
-    side streams) alike; beyond, least-recently-used executables are evicted, the forked ones parked and re-targeted
+    side streams) alike (the linear ones only under RK_GRAPH_LINEAR=1: by default one-launch sequences are launched directly,
+    which is faster); beyond, least-recently-used executables are evicted, the forked ones parked and re-targeted
     (hipGraphExecUpdate) instead of destroyed, and no more than RK_GRAPH_FORKED_MAX of them ever exist. Results bit-identical
     to the first result of every signature throughout."""
     import os
