@@ -844,6 +844,89 @@ __global__ void k_records(uint4 *topo, const uint64_t *ncode, const uint32_t *pa
 constexpr unsigned NBIN = 8;
 static_assert(NBIN >= static_cast<unsigned>(n_classes));
 
+// Launch order of the FIRST call on a small tree (at most FIRST_ORDER_MAX critical nodes): the critical nodes of the wave
+// kernels' classes sorted by decreasing size, ties in Morton order -- the order of the heavy-first launch plan that repeated
+// calls get from the host (rk_state.hip build_plan), made here so that a time-stepping loop, whose every traversal is a first
+// call, has it too (100k particles, one-launch producer / consumer kernel: 0.144 ms over the class lists read backwards, 0.101
+// over the sorted list). One workgroup of 16 wavefronts: each counts a contiguous share of the nodes per size, the counts are
+// scanned over (size, wavefront), each wavefront then places its share in order (ranks among equal sizes by ballot): stable,
+// no atomics on the placement, the same list every time. Oversized nodes (their own kernel) are left out.
+constexpr unsigned FIRST_ORDER_WAVES = 16, FIRST_ORDER_KEYS = 64 * RK_MAX_R + 1;
+__global__ void __launch_bounds__(64 * FIRST_ORDER_WAVES) k_first_order(const uint4 *crit, uint32_t n_crit, uint32_t *out)
+{
+    __shared__ uint32_t cnt[FIRST_ORDER_WAVES][FIRST_ORDER_KEYS];
+    const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    for (unsigned i = threadIdx.x; i < FIRST_ORDER_WAVES * FIRST_ORDER_KEYS; i += blockDim.x) {
+        (&cnt[0][0])[i] = 0u;
+    }
+    __syncthreads();
+    const uint32_t per = (n_crit + FIRST_ORDER_WAVES - 1u) / FIRST_ORDER_WAVES;
+    const uint32_t b = w * per < n_crit ? w * per : n_crit, e = b + per < n_crit ? b + per : n_crit;
+    // key 0 = the largest size; FIRST_ORDER_KEYS = not on the list
+    auto key_of = [&](uint32_t g) -> unsigned {
+        const uint32_t size = crit[g].w;
+        return (size == 0u || size > 64u * RK_MAX_R) ? FIRST_ORDER_KEYS : 64u * RK_MAX_R - size;
+    };
+    for (uint32_t g = b + lane; g < e; g += 64u) {
+        const unsigned k = key_of(g);
+        if (k < FIRST_ORDER_KEYS) {
+            atomicAdd(&cnt[w][k], 1u);
+        }
+    }
+    __syncthreads();
+    // Exclusive scan over (key, wavefront) in that order: wavefront 0 walks it (4 K additions: a few microseconds).
+    if (w == 0u) {
+        uint32_t carry = 0u;
+        for (unsigned k0 = 0; k0 < FIRST_ORDER_KEYS; k0 += 64u) {
+            const unsigned k = k0 + lane;
+            uint32_t tot = 0u;
+            if (k < FIRST_ORDER_KEYS) {
+                for (unsigned v = 0; v < FIRST_ORDER_WAVES; ++v) {
+                    const uint32_t c = cnt[v][k];
+                    cnt[v][k] = tot; // offset of wavefront v inside key k, for now
+                    tot += c;
+                }
+            }
+            // exclusive prefix of tot over the 64 keys of this round
+            uint32_t incl = tot;
+            for (unsigned d = 1; d < 64u; d <<= 1) {
+                const uint32_t up = __shfl_up(incl, d, 64);
+                if (lane >= d) {
+                    incl += up;
+                }
+            }
+            const uint32_t base = carry + incl - tot;
+            if (k < FIRST_ORDER_KEYS) {
+                for (unsigned v = 0; v < FIRST_ORDER_WAVES; ++v) {
+                    cnt[v][k] += base;
+                }
+            }
+            carry += __shfl(incl, 63, 64);
+        }
+    }
+    __syncthreads();
+    // Placement: the wavefront's share in chunks of 64 consecutive nodes; inside a chunk, equal keys rank by lane.
+    for (uint32_t g0 = b; g0 < e; g0 += 64u) {
+        const uint32_t g = g0 + lane;
+        const unsigned k = g < e ? key_of(g) : FIRST_ORDER_KEYS;
+        unsigned long long todo = __ballot(k < FIRST_ORDER_KEYS);
+        while (todo != 0ull) {
+            const int leader = __ffsll(static_cast<long long>(todo)) - 1;
+            const unsigned kk = static_cast<unsigned>(__shfl(static_cast<int>(k), leader, 64));
+            const unsigned long long same = __ballot(k == kk);
+            if (k == kk) {
+                out[cnt[w][kk] + static_cast<uint32_t>(__popcll(same & ((1ull << lane) - 1ull)))] = g;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0u) {
+                cnt[w][kk] += static_cast<uint32_t>(__popcll(same));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            todo &= ~same;
+        }
+    }
+}
+
 __global__ void k_bin_count(const uint4 *crit, uint32_t n_crit, uint32_t *block_hist, ctrl_block *ctrl)
 {
     __shared__ uint32_t h[NBIN];
@@ -976,6 +1059,15 @@ void exclusive_scan(const tri *in, tri *out, size_t n, hipStream_t st)
 }
 
 } // namespace bld
+
+static bool first_order_enabled()
+{
+    static const bool on = [] {
+        const char *e = std::getenv("RK_FIRST_ORDER"); // 0: first calls on small trees read the class lists backwards instead
+        return !(e && std::atoi(e) == 0);
+    }();
+    return on;
+}
 
 // Builds the tree and fills `s` (buffers, sizes). Host inputs in the caller's original order.
 template <typename F, int ND>
@@ -1198,6 +1290,14 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     hipLaunchKernelGGL(k_bin_count, dim3(nb), dim3(256), 0, st, crit, n_crit, hist.get(), ctrl.get());
     hipLaunchKernelGGL(k_bin_scan, dim3(NBIN), dim3(256), 0, st, hist.get(), nb, ctrl.get());
     hipLaunchKernelGGL(k_bin_scatter, dim3(nb), dim3(256), 0, st, crit, n_crit, hist.get(), ctrl.get(), lists + n_crit);
+    s.first_order_valid = false;
+    if (first_order_enabled() && n_crit <= FIRST_ORDER_MAX) {
+        if (!s.first_order) {
+            s.first_order = pool_alloc(FIRST_ORDER_MAX * sizeof(uint32_t));
+        }
+        hipLaunchKernelGGL(k_first_order, dim3(1), dim3(64 * FIRST_ORDER_WAVES), 0, st, crit, n_crit, static_cast<uint32_t *>(s.first_order));
+        s.first_order_valid = true;
+    }
 
     // ---- third round trip: class sizes (also the final synchronisation) ----
     fetch_ctrl();
@@ -1401,6 +1501,14 @@ void convert_device(rk_state &s, const void *const parts[4], int64_t nparts, con
     hipLaunchKernelGGL(k_bin_count, dim3(nb), dim3(256), 0, st, crit, n_crit, hist.get(), ctrl.get());
     hipLaunchKernelGGL(k_bin_scan, dim3(NBIN), dim3(256), 0, st, hist.get(), nb, ctrl.get());
     hipLaunchKernelGGL(k_bin_scatter, dim3(nb), dim3(256), 0, st, crit, n_crit, hist.get(), ctrl.get(), lists + n_crit);
+    s.first_order_valid = false;
+    if (first_order_enabled() && n_crit <= FIRST_ORDER_MAX) {
+        if (!s.first_order) {
+            s.first_order = pool_alloc(FIRST_ORDER_MAX * sizeof(uint32_t));
+        }
+        hipLaunchKernelGGL(k_first_order, dim3(1), dim3(64 * FIRST_ORDER_WAVES), 0, st, crit, n_crit, static_cast<uint32_t *>(s.first_order));
+        s.first_order_valid = true;
+    }
     fetch_ctrl();
     RK_HIP(hipGetLastError());
     if (hc.pad[2]) {

@@ -40,6 +40,7 @@ __host__ __device__ constexpr int nres_of(int q)
 constexpr uint32_t RK_PLAN_PAD_VALUE = 0xffffffffu; // launch-plan list entry without a critical node (skipped)
 constexpr int n_classes = 7;  // classes 0..5 are served by wave kernels, the last one by the block-per-group kernel
 constexpr int big_class = n_classes - 1;
+constexpr unsigned FIRST_ORDER_MAX = 8192; // critical nodes up to which a tree gets its first-call launch order on the device
 constexpr int n_list_R = 6;   // variant 2: class c keeps R = c + 1 targets per lane
 __host__ __device__ constexpr int class_R(int c)
 {
@@ -333,6 +334,10 @@ struct rk_state {
     int super_k = -1;      // -1 = not initialised (read RK_SUPER_K, default 8)
     // Split traversal (variant 4): list pool and control words, sized per call (grown, never shrunk, until the state goes).
     void *sl_idx = nullptr, *sl_next = nullptr, *sl_cnt = nullptr, *sl_ctl = nullptr, *sl_fb = nullptr;
+    // Launch order of the first call on a small tree (rk_build.hip k_first_order): the nodes of the wave kernels' classes by
+    // decreasing size, made on the device with the tree. Valid for the tree it was made with only.
+    void *first_order = nullptr;
+    bool first_order_valid = false;
     int64_t sl_nseg = 0, sl_ncnt = 0;   // segments / per-node counters allocated
     void *sl_pbase = nullptr, *sl_part = nullptr;
     int64_t sl_npart = 0, sl_part_hint = 0; // partial-sum slots allocated / asked for by the last reports

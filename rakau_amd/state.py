@@ -142,10 +142,11 @@ class State:
         _capi.check(_capi.lib().rk_state_set_perm(self._h, perm.ctypes.data))
 
     def device_ptr(self, what):
-        """(address, bytes) of a resident array: 'parts' ({x,y,z,m} AoS, Morton order), 'perm' (uint32), 'codes'."""
+        """(address, bytes) of a resident array: 'parts' ({x,y,z,m} AoS, Morton order), 'perm' (uint32), 'codes',
+        'first_order' (launch order of the first call on a small tree: critical-node indices, uint32)."""
         ptr = C.c_void_p()
         nbytes = C.c_int64()
-        sel = {"parts": 0, "perm": 1, "codes": 2}[what]
+        sel = {"parts": 0, "perm": 1, "codes": 2, "first_order": 3}[what]
         _capi.check(_capi.lib().rk_state_device_ptr(self._h, sel, C.byref(ptr), C.byref(nbytes)))
         return ptr.value or 0, nbytes.value
 

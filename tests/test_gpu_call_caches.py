@@ -96,6 +96,8 @@ np.savez(sys.argv[1], **res)
                         # calls without a plan: one launch over the class lists read backwards (full range), forced both ways, off
                         ("first_pc_any", {"RK_PLAN": "0", "RK_ANY": "1"}), ("first_list_any", {"RK_PLAN": "0", "RK_ANY": "3"}),
                         ("first_class_launches", {"RK_PLAN": "0", "RK_ANY_FIRST": "0"}),
+                        # first calls over the class lists read backwards instead of the order made on the device with the tree
+                        ("first_pc_any_class_order", {"RK_PLAN": "0", "RK_ANY": "1", "RK_FIRST_ORDER": "0"}),
                         # graphs of forked sequences: parked, only the first two captured, never captured
                         ("forked_graphs_cap2", {"RK_PLAN": "0", "RK_ANY_FIRST": "0", "RK_GRAPH_FORKED_MAX": "2"}),
                         ("forked_graphs_off", {"RK_PLAN_MAX_GROUPS": "64", "RK_PLAN_REV_MAX_GROUPS": "0", "RK_GRAPH_FORKED": "0"}),

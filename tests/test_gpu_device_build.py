@@ -282,3 +282,36 @@ def test_exact_build_4m_census_and_time():
         assert np.array_equal(a, b)
     assert dt_exact < 0.08  # 24-27 ms measured (round 2: 60 ms): the root's chain of N dependent multiply-adds + 64 MB of H2D
     sf.close()
+
+
+@pytest.mark.parametrize("n,ncrit", [(3000, 128), (60000, 128), (150000, 256), (150000, 1300)])
+def test_first_call_launch_order_made_on_the_device(n, ncrit):
+    """Small trees (at most 8192 critical nodes) come with the launch order of their first call, made on the device with the
+    tree (rk_build.hip k_first_order): the critical nodes the wave kernels serve by decreasing size, ties in Morton order --
+    the heavy-first order repeated calls get from the host -- for trees built on the device and for host trees converted
+    there; every such node exactly once, oversized nodes (ncrit = 1300) left to their own kernel. The first call over that
+    list gives the bits of the first call over the class lists (RK_FIRST_ORDER=0 is one of the environments of
+    tests/test_gpu_call_caches.py)."""
+    import torch
+    m, x, y, z = oracle.plummer(n, np.float32)
+    ot = oracle.Tree(x, y, z, m, ncrit=ncrit, max_leaf_n=16 if ncrit < 1000 else 300)
+    for st in (rakau_amd.State.build(x, y, z, m, ncrit=ncrit, max_leaf_n=ot.max_leaf_n), state_from_oracle(ot)):
+        cr = st.crit_ranges()
+        size = (cr[:, 1] - cr[:, 0]).astype(np.int64)
+        ptr, nbytes = st.device_ptr("first_order")
+        if len(cr) > 8192:
+            assert nbytes == 0
+            continue
+        wave = np.flatnonzero(size <= 256)
+        assert nbytes == 4 * len(wave) and ptr != 0
+        d_got = torch.zeros(len(wave), dtype=torch.int32, device="cuda")
+        rakau_amd._capi.check(rakau_amd._capi.lib().rk_device_memcpy(d_got.data_ptr(), ptr, nbytes, 0))
+        torch.cuda.synchronize()
+        expect = wave[np.lexsort((wave, -size[wave]))]
+        assert np.array_equal(d_got.cpu().numpy().astype(np.int64), expect)
+        # and the first call, which runs over it, agrees with a repeated call (host plan) bit for bit
+        mv = rakau_amd.mac_value_of(0.75, "bh", np.float32)
+        a = st.acc_pot(0, mv)
+        b = st.acc_pot(0, mv)
+        c = st.acc_pot(0, mv)
+        assert all(np.array_equal(u, v) and np.array_equal(u, w) for u, v, w in zip(a, b, c))
