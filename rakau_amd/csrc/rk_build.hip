@@ -848,82 +848,17 @@ static_assert(NBIN >= static_cast<unsigned>(n_classes));
 // kernels' classes sorted by decreasing size, ties in Morton order -- the order of the heavy-first launch plan that repeated
 // calls get from the host (rk_state.hip build_plan), made here so that a time-stepping loop, whose every traversal is a first
 // call, has it too (100k particles, one-launch producer / consumer kernel: 0.144 ms over the class lists read backwards, 0.101
-// over the sorted list). One workgroup of 16 wavefronts: each counts a contiguous share of the nodes per size, the counts are
-// scanned over (size, wavefront), each wavefront then places its share in order (ranks among equal sizes by ballot): stable,
-// no atomics on the placement, the same list every time. Oversized nodes (their own kernel) are left out.
-constexpr unsigned FIRST_ORDER_WAVES = 16, FIRST_ORDER_KEYS = 64 * RK_MAX_R + 1;
-__global__ void __launch_bounds__(64 * FIRST_ORDER_WAVES) k_first_order(const uint4 *crit, uint32_t n_crit, uint32_t *out)
+// over the sorted list). Keys for a stable radix sort over eight bits (one pass): sizes in steps of two, 0 = the largest a
+// wavefront serves; oversized nodes (their own kernel) get the last key and fall off the end of the list.
+constexpr unsigned FIRST_ORDER_KEY_BITS = 8;
+static_assert(((64 * RK_MAX_R) >> 1) < (1 << FIRST_ORDER_KEY_BITS) - 1);
+__global__ void k_first_keys(const uint4 *crit, uint32_t n_crit, uint32_t *keys, uint32_t *vals)
 {
-    __shared__ uint32_t cnt[FIRST_ORDER_WAVES][FIRST_ORDER_KEYS];
-    const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    for (unsigned i = threadIdx.x; i < FIRST_ORDER_WAVES * FIRST_ORDER_KEYS; i += blockDim.x) {
-        (&cnt[0][0])[i] = 0u;
-    }
-    __syncthreads();
-    const uint32_t per = (n_crit + FIRST_ORDER_WAVES - 1u) / FIRST_ORDER_WAVES;
-    const uint32_t b = w * per < n_crit ? w * per : n_crit, e = b + per < n_crit ? b + per : n_crit;
-    // key 0 = the largest size; FIRST_ORDER_KEYS = not on the list
-    auto key_of = [&](uint32_t g) -> unsigned {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n_crit) {
         const uint32_t size = crit[g].w;
-        return (size == 0u || size > 64u * RK_MAX_R) ? FIRST_ORDER_KEYS : 64u * RK_MAX_R - size;
-    };
-    for (uint32_t g = b + lane; g < e; g += 64u) {
-        const unsigned k = key_of(g);
-        if (k < FIRST_ORDER_KEYS) {
-            atomicAdd(&cnt[w][k], 1u);
-        }
-    }
-    __syncthreads();
-    // Exclusive scan over (key, wavefront) in that order: wavefront 0 walks it (4 K additions: a few microseconds).
-    if (w == 0u) {
-        uint32_t carry = 0u;
-        for (unsigned k0 = 0; k0 < FIRST_ORDER_KEYS; k0 += 64u) {
-            const unsigned k = k0 + lane;
-            uint32_t tot = 0u;
-            if (k < FIRST_ORDER_KEYS) {
-                for (unsigned v = 0; v < FIRST_ORDER_WAVES; ++v) {
-                    const uint32_t c = cnt[v][k];
-                    cnt[v][k] = tot; // offset of wavefront v inside key k, for now
-                    tot += c;
-                }
-            }
-            // exclusive prefix of tot over the 64 keys of this round
-            uint32_t incl = tot;
-            for (unsigned d = 1; d < 64u; d <<= 1) {
-                const uint32_t up = __shfl_up(incl, d, 64);
-                if (lane >= d) {
-                    incl += up;
-                }
-            }
-            const uint32_t base = carry + incl - tot;
-            if (k < FIRST_ORDER_KEYS) {
-                for (unsigned v = 0; v < FIRST_ORDER_WAVES; ++v) {
-                    cnt[v][k] += base;
-                }
-            }
-            carry += __shfl(incl, 63, 64);
-        }
-    }
-    __syncthreads();
-    // Placement: the wavefront's share in chunks of 64 consecutive nodes; inside a chunk, equal keys rank by lane.
-    for (uint32_t g0 = b; g0 < e; g0 += 64u) {
-        const uint32_t g = g0 + lane;
-        const unsigned k = g < e ? key_of(g) : FIRST_ORDER_KEYS;
-        unsigned long long todo = __ballot(k < FIRST_ORDER_KEYS);
-        while (todo != 0ull) {
-            const int leader = __ffsll(static_cast<long long>(todo)) - 1;
-            const unsigned kk = static_cast<unsigned>(__shfl(static_cast<int>(k), leader, 64));
-            const unsigned long long same = __ballot(k == kk);
-            if (k == kk) {
-                out[cnt[w][kk] + static_cast<uint32_t>(__popcll(same & ((1ull << lane) - 1ull)))] = g;
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0u) {
-                cnt[w][kk] += static_cast<uint32_t>(__popcll(same));
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            todo &= ~same;
-        }
+        keys[g] = (size == 0u || size > 64u * RK_MAX_R) ? (1u << FIRST_ORDER_KEY_BITS) - 1u : (64u * RK_MAX_R - size) >> 1;
+        vals[g] = g;
     }
 }
 
@@ -1059,6 +994,26 @@ void exclusive_scan(const tri *in, tri *out, size_t n, hipStream_t st)
 }
 
 } // namespace bld
+
+// (see k_first_keys)
+static void make_first_order(rk_state &s, const uint4 *crit, uint32_t n_crit, hipStream_t st)
+{
+    using namespace bld;
+    if (!s.first_order) {
+        s.first_order = pool_alloc(FIRST_ORDER_MAX * sizeof(uint32_t));
+    }
+    auto keys_in = dalloc<uint32_t>(n_crit), keys_out = dalloc<uint32_t>(n_crit), vals_in = dalloc<uint32_t>(n_crit);
+    hipLaunchKernelGGL(k_first_keys, dim3((n_crit + 255u) / 256u), dim3(256), 0, st, crit, n_crit, keys_in.get(), vals_in.get());
+    size_t tb = 0;
+    RK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys_in.get(), keys_out.get(), vals_in.get(),
+                                              static_cast<uint32_t *>(s.first_order), static_cast<int>(n_crit), 0,
+                                              static_cast<int>(FIRST_ORDER_KEY_BITS), st));
+    auto tmp = dalloc<unsigned char>(tb);
+    RK_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.get(), tb, keys_in.get(), keys_out.get(), vals_in.get(),
+                                              static_cast<uint32_t *>(s.first_order), static_cast<int>(n_crit), 0,
+                                              static_cast<int>(FIRST_ORDER_KEY_BITS), st));
+    s.first_order_valid = true;
+}
 
 static bool first_order_enabled()
 {
@@ -1292,11 +1247,7 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     hipLaunchKernelGGL(k_bin_scatter, dim3(nb), dim3(256), 0, st, crit, n_crit, hist.get(), ctrl.get(), lists + n_crit);
     s.first_order_valid = false;
     if (first_order_enabled() && n_crit <= FIRST_ORDER_MAX) {
-        if (!s.first_order) {
-            s.first_order = pool_alloc(FIRST_ORDER_MAX * sizeof(uint32_t));
-        }
-        hipLaunchKernelGGL(k_first_order, dim3(1), dim3(64 * FIRST_ORDER_WAVES), 0, st, crit, n_crit, static_cast<uint32_t *>(s.first_order));
-        s.first_order_valid = true;
+        make_first_order(s, crit, n_crit, st);
     }
 
     // ---- third round trip: class sizes (also the final synchronisation) ----
@@ -1503,11 +1454,7 @@ void convert_device(rk_state &s, const void *const parts[4], int64_t nparts, con
     hipLaunchKernelGGL(k_bin_scatter, dim3(nb), dim3(256), 0, st, crit, n_crit, hist.get(), ctrl.get(), lists + n_crit);
     s.first_order_valid = false;
     if (first_order_enabled() && n_crit <= FIRST_ORDER_MAX) {
-        if (!s.first_order) {
-            s.first_order = pool_alloc(FIRST_ORDER_MAX * sizeof(uint32_t));
-        }
-        hipLaunchKernelGGL(k_first_order, dim3(1), dim3(64 * FIRST_ORDER_WAVES), 0, st, crit, n_crit, static_cast<uint32_t *>(s.first_order));
-        s.first_order_valid = true;
+        make_first_order(s, crit, n_crit, st);
     }
     fetch_ctrl();
     RK_HIP(hipGetLastError());

@@ -284,10 +284,10 @@ def test_exact_build_4m_census_and_time():
     sf.close()
 
 
-@pytest.mark.parametrize("n,ncrit", [(3000, 128), (60000, 128), (150000, 256), (150000, 1300)])
+@pytest.mark.parametrize("n,ncrit", [(3000, 128), (60000, 128), (150000, 256), (150000, 1300), (1500000, 128)])
 def test_first_call_launch_order_made_on_the_device(n, ncrit):
-    """Small trees (at most 8192 critical nodes) come with the launch order of their first call, made on the device with the
-    tree (rk_build.hip k_first_order): the critical nodes the wave kernels serve by decreasing size, ties in Morton order --
+    """Small trees (at most 32768 critical nodes) come with the launch order of their first call, made on the device with the
+    tree (rk_build.hip make_first_order): the critical nodes the wave kernels serve by decreasing size (in steps of two), ties in Morton order --
     the heavy-first order repeated calls get from the host -- for trees built on the device and for host trees converted
     there; every such node exactly once, oversized nodes (ncrit = 1300) left to their own kernel. The first call over that
     list gives the bits of the first call over the class lists (RK_FIRST_ORDER=0 is one of the environments of
@@ -299,7 +299,7 @@ def test_first_call_launch_order_made_on_the_device(n, ncrit):
         cr = st.crit_ranges()
         size = (cr[:, 1] - cr[:, 0]).astype(np.int64)
         ptr, nbytes = st.device_ptr("first_order")
-        if len(cr) > 8192:
+        if len(cr) > 32768:
             assert nbytes == 0
             continue
         wave = np.flatnonzero(size <= 256)
@@ -307,7 +307,7 @@ def test_first_call_launch_order_made_on_the_device(n, ncrit):
         d_got = torch.zeros(len(wave), dtype=torch.int32, device="cuda")
         rakau_amd._capi.check(rakau_amd._capi.lib().rk_device_memcpy(d_got.data_ptr(), ptr, nbytes, 0))
         torch.cuda.synchronize()
-        expect = wave[np.lexsort((wave, -size[wave]))]
+        expect = wave[np.lexsort((wave, (256 - size[wave]) >> 1))]  # sizes in steps of two, ties in Morton order
         assert np.array_equal(d_got.cpu().numpy().astype(np.int64), expect)
         # and the first call, which runs over it, agrees with a repeated call (host plan) bit for bit
         mv = rakau_amd.mac_value_of(0.75, "bh", np.float32)
