@@ -3,19 +3,20 @@
 // The list kernel (rk_kernels_list.hip) alternates list building and dense evaluation inside ONE wavefront per critical
 // node. That is the best use of the wave slots when the device is full; a launch with few critical nodes, however, ends
 // with the longest serial chains -- the dense phase of the largest groups, R targets per lane times all their sources --
-// running alone on their SIMDs. Here a workgroup of 1 + R wavefronts serves one critical node of lane-mapping class R:
+// running alone on their SIMDs. Here a workgroup of 1 + min(R, 2) wavefronts serves one critical node of lane-mapping class R
+// (rounds 2-3: 1 + R; see RK_PC_NCONS below for why smaller workgroups are faster):
 //
 //   * the PRODUCER wave builds the interaction list exactly as the list kernel does (same stack of sibling runs, same
 //     box / probe / exact MAC tests, same leaf gathering, same supergroup pre-pass inputs) into a double-buffered LDS tile;
-//   * CONSUMER wave c (c < R) evaluates every published tile for the c-th target of each lane of the list kernel's
-//     mapping (targets c * TP .. c * TP + TP - 1), i.e. with ONE target per lane, while the producer fills the other
-//     buffer. One workgroup barrier per tile: the producer arrives when tile k is complete, the consumers when they have
-//     finished tile k - 1.
+//   * the CONSUMER waves evaluate every published tile, each for one or two of the R target slots of every lane of the list
+//     kernel's mapping (slot r = targets r * TP .. r * TP + TP - 1; two slots: the two-target body), while the producer fills
+//     the other buffer. One workgroup barrier per tile: the producer arrives when tile k is complete, the consumers when
+//     they have finished tile k - 1.
 //
 // The sequence of tiles, their contents, the number of source splits NS and the order in which every target receives its
 // contributions are those of the list kernel, so the results are BIT-IDENTICAL to it (tests assert this) -- which kernel
 // serves a call is therefore a pure scheduling decision (rk_state.hip picks this one for calls over few critical nodes).
-// What it buys there: the critical path of a group is max(list building, dense / R) instead of list building + dense.
+// What it buys there: the critical path of a group is max(list building, dense / consumers) instead of list building + dense.
 //
 // The MAC decisions are those of the reference's CPU engine (include/rakau/tree.hpp:2662-2672 of the reference).
 #include "rk_list_common.hpp"
