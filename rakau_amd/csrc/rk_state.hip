@@ -1389,10 +1389,14 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                 // tree 1.34-1.37 instead of 1.25-1.28: the heavy-first order gives up the L2 locality of neighbouring nodes.)
                 return e ? std::atoll(e) : int64_t(30000);
             }();
-            // Between RK_PLAN_MAX_GROUPS and this many nodes: the class-reversed plan for k_list_any (0 = never).
+            // Between RK_PLAN_MAX_GROUPS and this many nodes: the class-reversed plan for k_list_any (0 = never). Round 3 used it
+            // up to 60 000 nodes (equal to the light-tail plan within 2 % then, and free of the outliers forked launches showed
+            // when they were not replayed from graphs); with the graph cache of round 4 the light-tail plan on the class kernels
+            // is ahead there -- ms per call, reversed / light-tail: 34k nodes 0.833 / 0.809, 38k 0.936 / 0.905, 47k 1.142 / 1.058,
+            // 54k 1.218 / 1.147, 58k 1.406 / 1.327 (tools/size_scan.py, tools/jobs_r04/r04_job64.sh) -- so nothing takes it by default.
             static const int64_t plan_rev_max_groups = [] {
                 const char *e = std::getenv("RK_PLAN_REV_MAX_GROUPS");
-                return e ? std::atoll(e) : int64_t(60000);
+                return e ? std::atoll(e) : int64_t(30000);
             }();
             bool cached = s.plan.d_lists && s.plan.p_begin == p_begin && s.plan.p_end == p_end
                           && s.plan.mac_value == mac_value;
