@@ -1469,7 +1469,10 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
             // The cached pre-pass output was written (or is being read) on another stream: wait for it here, and never
             // extend it from two streams (an extending pre-pass may rewrite supergroups the other stream's kernels are still
             // reading). sup_stream is only ever COMPARED -- the caller may have destroyed that stream since --: the wait is
-            // for the whole device.
+            // for the whole device. (An event of the state's own recorded after every call, waited on asynchronously when the
+            // stream changes, would not block the host here; it would cost EVERY call of a one-stream caller a barrier packet
+            // -- ~10 us on the GPU, 10 % of a 100k-particle call -- to spare callers that alternate streams a wait they need
+            // only when they do.)
             RK_HIP(hipDeviceSynchronize());
         }
         // Variant 4 (and the automatic variant unless RK_SPLIT=0): list building and dense evaluation as two kernels.
