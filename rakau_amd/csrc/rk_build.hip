@@ -996,6 +996,7 @@ void exclusive_scan(const tri *in, tri *out, size_t n, hipStream_t st)
 } // namespace bld
 
 // (see k_first_keys)
+static bool first_order_enabled();
 static void make_first_order(rk_state &s, const uint4 *crit, uint32_t n_crit, hipStream_t st)
 {
     using namespace bld;
@@ -1022,6 +1023,16 @@ static bool first_order_enabled()
         return !(e && std::atoi(e) == 0);
     }();
     return on;
+}
+
+// The same for a replica (rk_state_clone / import / broadcast: the critical nodes are on its device already).
+void replica_first_order(rk_state &s)
+{
+    s.first_order_valid = false;
+    if (first_order_enabled() && s.n_crit > 0 && s.n_crit <= static_cast<int64_t>(FIRST_ORDER_MAX) && s.buf[RK_BUF_CRIT]) {
+        make_first_order(s, static_cast<const uint4 *>(s.buf[RK_BUF_CRIT]), static_cast<uint32_t>(s.n_crit), nullptr);
+        RK_HIP(hipStreamSynchronize(nullptr)); // (the temporaries of the sort go back to the pool)
+    }
 }
 
 // Builds the tree and fills `s` (buffers, sizes). Host inputs in the caller's original order.

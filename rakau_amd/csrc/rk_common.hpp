@@ -410,6 +410,8 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
 template <typename F, int ND>
 void convert_device(rk_state &s, const void *const parts[4], int64_t nparts, const void *tree, int64_t tree_size,
                     int64_t node_stride);
+// Launch order of the first call for a replica whose critical nodes are on its device already (rk_build.hip).
+void replica_first_order(rk_state &s);
 // Device builder: sum node properties in the reference's serial association (rk_set_build_exact / RK_BUILD_EXACT).
 bool exact_node_sums();
 void touch_kernels();

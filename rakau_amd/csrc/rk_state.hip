@@ -2851,6 +2851,7 @@ static void replica_finish(rk_state &s)
     }
     build_host_mirrors(s, crit);
     ensure_call_resources_any(s);
+    rk::replica_first_order(s); // (small trees: the first call of a replica runs in heavy-first order like its source's)
 }
 
 // rk_state_import (buffers already on `device`: src_device < 0) and rk_state_clone (buffers on src_device).

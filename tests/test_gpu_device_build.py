@@ -288,14 +288,16 @@ def test_exact_build_4m_census_and_time():
 def test_first_call_launch_order_made_on_the_device(n, ncrit):
     """Small trees (at most 32768 critical nodes) come with the launch order of their first call, made on the device with the
     tree (rk_build.hip make_first_order): the critical nodes the wave kernels serve by decreasing size (in steps of two), ties in Morton order --
-    the heavy-first order repeated calls get from the host -- for trees built on the device and for host trees converted
-    there; every such node exactly once, oversized nodes (ncrit = 1300) left to their own kernel. The first call over that
+    the heavy-first order repeated calls get from the host -- for trees built on the device, for host trees converted
+    there and for replicas; every such node exactly once, oversized nodes (ncrit = 1300) left to their own kernel. The first call over that
     list gives the bits of the first call over the class lists (RK_FIRST_ORDER=0 is one of the environments of
     tests/test_gpu_call_caches.py)."""
     import torch
     m, x, y, z = oracle.plummer(n, np.float32)
     ot = oracle.Tree(x, y, z, m, ncrit=ncrit, max_leaf_n=16 if ncrit < 1000 else 300)
-    for st in (rakau_amd.State.build(x, y, z, m, ncrit=ncrit, max_leaf_n=ot.max_leaf_n), state_from_oracle(ot)):
+    built = rakau_amd.State.build(x, y, z, m, ncrit=ncrit, max_leaf_n=ot.max_leaf_n)
+    # (a replica sorts its own copy of the critical nodes: rk_state_clone / import / broadcast)
+    for st in (built, state_from_oracle(ot), built.clone(0)):
         cr = st.crit_ranges()
         size = (cr[:, 1] - cr[:, 0]).astype(np.int64)
         ptr, nbytes = st.device_ptr("first_order")
