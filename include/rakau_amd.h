@@ -102,6 +102,11 @@ RK_EXPORT int rk_init(int device);
  *  tree        host array of tree_size records laid out as rakau::tree_node_t<3, F, uint64_t, MAC>
  *              (include/rakau/detail/tree_fwd.hpp:77-116): uint64 begin, end, n_children, code, level;
  *              F props[4] (COM x,y,z, mass); then F dim2 (bh) or F dim, delta (bh_geom).
+ *              Every field the reference fills must be valid, `code` included: the low NDim bits of a node's code (its
+ *              octant inside the parent, tree.hpp:1046-1060) give the sibling order of the engine's node records and
+ *              two children of one node must differ in them. Records with codes left at 0 are refused with
+ *              "inconsistent tree: not every node is reachable from the root" (RK_CREATE_ON_HOST=1, the host-side
+ *              conversion kept as a cross-check, derives the order from the array positions and ignores the codes).
  *  node_stride sizeof of one record in bytes (64/80 for bh fp32/fp64, 64/88 for bh_geom).
  *  ncrit       tree::m_ncrit. Critical nodes (the target groups, tree.hpp:794-807) are re-derived
  *              from the node array: first node on each root->leaf path with

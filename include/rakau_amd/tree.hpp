@@ -9,10 +9,13 @@
 //     sort -> task-parallel depth-first node construction), producing the reference's data contract
 //     (tree_node_t / tree_cnode_t, include/rakau/detail/tree_fwd.hpp:77-125);
 //   * every acc/pot call is served by hand-written HIP kernels through the C ABI of
-//     include/rakau_amd.h -- there is no CPU traversal path in the product;
-//   * `split` keeps the reference's spelling {host, dev0, dev1, ...} (tree.hpp:3150-3187) but the
-//     host share is executed by device 0: results do not depend on the split because every device
-//     evaluates the same per-critical-node interaction lists.
+//     include/rakau_amd.h; a call without a gfx950 device throws, it never falls back to the CPU;
+//   * `split` keeps the reference's spelling and meaning {host, dev0, dev1, ...} (tree.hpp:3047-3240):
+//     the critical nodes below the first cut are computed by this header's own CPU engine
+//     (cpu_engine.hpp) on the calling thread WHILE one host thread per device runs the device
+//     shares. Deliberate differences: an empty split (the default) means "everything on device 0"
+//     (the reference: CPU; -DRAKAU_AMD_EMPTY_SPLIT_IS_CPU restores that), and every cut is snapped to
+//     a critical-node boundary (the reference snaps the first one).
 //
 // Define RAKAU_AMD_DROP_IN before including to get `namespace rakau = rakau_amd;`.
 #ifndef RAKAU_AMD_TREE_HPP

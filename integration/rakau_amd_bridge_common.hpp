@@ -55,8 +55,9 @@ inline void rk_throw(int rc)
 }
 
 // The C ABI takes the node records with 64-bit code / level fields (tree_node_t<NDim, F, std::uint64_t, MAC>); trees with
-// 32-bit codes hand over a widened copy. The engine never looks at the codes: it uses the topology and the node
-// properties only, and sorted codes are not needed with critical-node grouping.
+// 32-bit codes hand over a widened copy (values unchanged). Of the NODE codes the engine reads the low NDim bits -- the
+// octant inside the parent, which orders the sibling records (include/rakau_amd.h, rk_state_create) -- and nothing else;
+// the sorted PARTICLE codes (m_codes) are not needed with critical-node grouping.
 template <std::size_t NDim, typename F, typename UInt, rakau::mac MAC>
 struct wide_nodes {
     using wide_node = rakau::tree_node_t<NDim, F, std::uint64_t, MAC>;

@@ -756,12 +756,17 @@ __global__ void k_flags(const uint4 *topo, const uint64_t *ncode, const uint32_t
     }
     auto cand = [&](uint32_t j) { return (topo[j].z - topo[j].y) <= ncrit_clamped || topo[j].x == 0u; };
     const bool c = cand(k);
-    flags[k].a = (c && (k == 0u || !cand(parent[k]))) ? 1u : 0u;
+    // A parent lies before its children in depth-first order. An index that does not (the sentinel convert_device() leaves in
+    // nodes that no parent's walk reached -- a malformed host tree) is never dereferenced: such a node counts as a child of
+    // nobody, the child count then misses it and the conversion is refused ("not every node is reachable from the root").
+    const uint32_t par = k != 0u ? parent[k] : 0u;
+    const bool orphan = k != 0u && par >= k;
+    flags[k].a = (c && (k == 0u || orphan || !cand(par))) ? 1u : 0u;
     flags[k].b = topo[k].x != 0u ? 1u : 0u;
-    if (k != 0u) {
-        atomicOr(&mask[parent[k]], 1u << (static_cast<unsigned>(ncode[k]) & geo<ND>::DMASK));
-    } else {
+    if (k == 0u) {
         flags[n_nodes] = tri{0u, 0u, 0u};
+    } else if (!orphan) {
+        atomicOr(&mask[par], 1u << (static_cast<unsigned>(ncode[k]) & geo<ND>::DMASK));
     }
 }
 
@@ -1306,12 +1311,15 @@ __global__ void k_interleave(const F *x, const F *y, const F *z, const F *m, uin
 // ctrl->pad[0] (~index of the first one) and neutralised, so that the kernels behind this one stay inside their arrays.
 template <typename F, int ND>
 __global__ void k_from_aos(const unsigned char *aos, uint32_t stride, uint32_t n_nodes, uint32_t nparts, int mac, uint4 *topo,
-                           uint64_t *ncode, typename vt<F>::v4 *com, typename vt<F>::v2 *macp, ctrl_block *ctrl)
+                           uint64_t *ncode, typename vt<F>::v4 *com, typename vt<F>::v2 *macp, uint32_t *parent, ctrl_block *ctrl)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_nodes) {
         return;
     }
+    // k_parents_checked writes parent[c] only for the nodes some parent's walk reaches; the array comes from the block cache
+    // uninitialised. Every node starts as "claimed by nobody" (k_flags treats any index >= k as that).
+    parent[k] = 0xffffffffu;
     const unsigned char *rec = aos + static_cast<size_t>(k) * stride;
     const auto *hdr = reinterpret_cast<const uint64_t *>(rec);
     const auto *fp = reinterpret_cast<const F *>(rec + 5 * sizeof(uint64_t));
@@ -1421,7 +1429,7 @@ void convert_device(rk_state &s, const void *const parts[4], int64_t nparts, con
     auto parent = dalloc<uint32_t>(nn);
     auto mask = dalloc<uint32_t>(nn + 1);
     hipLaunchKernelGGL((k_from_aos<F, ND>), dim3(nblk(nn)), dim3(256), 0, st, aos.get(), static_cast<uint32_t>(node_stride),
-                       static_cast<uint32_t>(nn), n, s.mac, topo, ncode.get(), node_com, node_mac, ctrl.get());
+                       static_cast<uint32_t>(nn), n, s.mac, topo, ncode.get(), node_com, node_mac, parent.get(), ctrl.get());
     hipLaunchKernelGGL(k_parents_checked, dim3(nblk(nn)), dim3(256), 0, st, topo, static_cast<uint32_t>(nn), parent.get(),
                        mask.get(), ctrl.get());
 

@@ -49,20 +49,15 @@ __device__ __forceinline__ void list_node(const kparams<F> &P, lk_wave_lds<F> &L
         const bool lane_on = sp_raw < NS;
         const int sp = lane_on ? sp_raw : 0; // idle lanes shadow split 0; their results are never stored
 
-        v4 tp[R];
+        lk_regs<F, Q, R> tg; // the lane's R targets and their sums (register pairs in the packed fp32 flavour)
         int tidx[R];
-        F acc[R][NR];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             tidx[r] = ts + r * TP;
             const bool valid = tidx[r] < T;
-            tp[r] = P.part4[tb + (valid ? tidx[r] : 0)];
+            tg.set_target(r, P.part4[tb + (valid ? tidx[r] : 0)]);
             if (!valid) {
                 tidx[r] = -1;
-            }
-#pragma unroll
-            for (int k = 0; k < NR; ++k) {
-                acc[r][k] = F(0);
             }
         }
 
@@ -76,6 +71,8 @@ __device__ __forceinline__ void list_node(const kparams<F> &P, lk_wave_lds<F> &L
         const unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime(), tr_c0 = __builtin_amdgcn_s_memtime();
 #endif
         int size = 0, n_src = 0, n_lq = 0, n_uq = 0;
+        RK_COUNT_DECL
+        RK_COUNT(0, 1) RK_COUNT(20, NS) RK_COUNT(21, TP * NS) RK_COUNT(22, T * NS) RK_COUNT(26, T)
         // Supergroup pre-pass results for this group's supergroup (if enabled and not overflowed).
         uint32_t sup_S = 0, sup_ncommon = 0, sup_nresid = 0, sup_rpos = 0;
         bool from_root = true;
@@ -110,8 +107,8 @@ __device__ __forceinline__ void list_node(const kparams<F> &P, lk_wave_lds<F> &L
             if (n_src > 0) {
                 RK_STAMP(7)
                 const int full = (n_src * inv_ns) >> 16;
-                lk_eval_tile<F, Q, R, false, ND>(L.src, n_src, full, sp, NS, final || !RK_CARRY_REMAINDER, lane_on, tp, acc, eps2,
-                                             tidx);
+                RK_COUNT(12, 1) RK_COUNT(13, full) RK_COUNT(14, (final || !RK_CARRY_REMAINDER) && n_src - full * NS > 0 ? 1 : 0) RK_COUNT(15, n_src)
+                lk_eval_tile<F, Q, R, false, ND>(L.src, n_src, full, sp, NS, final || !RK_CARRY_REMAINDER, lane_on, tg, eps2, tidx);
 #if RK_CARRY_REMAINDER
                 const int left = final ? 0 : n_src - full * NS;
                 v4 keep;
@@ -139,6 +136,7 @@ __device__ __forceinline__ void list_node(const kparams<F> &P, lk_wave_lds<F> &L
             while (n_lq > 0) {
                 RK_STAMP(7)
                 const int free_slots = SRC_CAP - n_src;
+                RK_COUNT(8, 1)
                 uint2 lf = make_uint2(0u, 0u);
                 if (lane < n_lq) {
                     lf = L.lq[lane];
@@ -166,10 +164,38 @@ __device__ __forceinline__ void list_node(const kparams<F> &P, lk_wave_lds<F> &L
                     flush(true);
                     continue;
                 }
-                // Lane l copies the particles of leaf l, eight loads in flight at a time.
                 const unsigned mycnt = fits ? cnt : 0u;
                 const int dst = n_src + static_cast<int>(incl - cnt);
+                const int total = __builtin_amdgcn_readlane(static_cast<int>(incl), m - 1);
+                RK_COUNT(10, m)
+#if RK_LEAF_LANE_PARTICLE
+                // Lane = particle. First every fitting leaf writes the Morton indices of its particles into the first word of
+                // the tile slots they will occupy (lane = leaf, one 4-byte LDS store per particle), then lane i fetches the
+                // record slot i names and stores it over the index: one record in flight per lane and 64 per wavefront, whatever
+                // the sizes of the leaves -- four registers where eight records per LEAF used to be held (32: the register
+                // peak of list building). Same records in the same slots as before.
+                {
+                    constexpr int W = static_cast<int>(sizeof(v4) / sizeof(uint32_t));
+                    uint32_t *slot_word = reinterpret_cast<uint32_t *>(&L.src[0]);
+                    for (unsigned k = 0; __builtin_amdgcn_ballot_w64(k < mycnt) != 0ull; ++k) {
+                        if (k < mycnt) {
+                            slot_word[(dst + static_cast<int>(k)) * W] = lf.x + k;
+                        }
+                    }
+                    wave_sync();
+                    RK_COUNT(9, (total + 63) / 64)
+                    for (int i0 = 0; i0 < total; i0 += 64) {
+                        const int i = i0 + lane;
+                        if (i < total) {
+                            const uint32_t pi = slot_word[(n_src + i) * W];
+                            L.src[n_src + i] = P.part4[pi];
+                        }
+                    }
+                }
+#else
+                // Lane l copies the particles of leaf l, eight loads in flight at a time.
                 for (unsigned j0 = 0; __builtin_amdgcn_ballot_w64(j0 < mycnt) != 0ull; j0 += 8u) {
+                    RK_COUNT(9, 1)
                     v4 tmp[8];
                     // Unconditional loads (index clamped into the leaf; particle 0 for idle lanes).
                     const uint32_t lbase = mycnt ? lf.x : 0u, llast = mycnt ? mycnt - 1u : 0u;
@@ -185,7 +211,9 @@ __device__ __forceinline__ void list_node(const kparams<F> &P, lk_wave_lds<F> &L
                         }
                     }
                 }
-                n_src += __builtin_amdgcn_readlane(static_cast<int>(incl), m - 1);
+#endif
+                n_src += total;
+                RK_COUNT(11, total)
                 // Drop the consumed leaves from the queue (move the rest down, 64 entries at a time).
                 const int tail = n_lq - m;
                 wave_sync();
@@ -265,6 +293,7 @@ __device__ __forceinline__ void list_node(const kparams<F> &P, lk_wave_lds<F> &L
                 L.src[n_src + static_cast<int>(wave_prefix_count(m_acc))] = bt.com;
             }
             n_src += __builtin_popcountll(m_acc);
+            RK_COUNT(23, __builtin_popcountll(m_acc))
             const unsigned long long m_leaf = __builtin_amdgcn_ballot_w64(leaf);
             if (leaf) {
                 L.lq[n_lq + static_cast<int>(wave_prefix_count(m_leaf))] = make_uint2(bt.ra, bt.rb);
@@ -275,11 +304,13 @@ __device__ __forceinline__ void list_node(const kparams<F> &P, lk_wave_lds<F> &L
                 L.stack[size + static_cast<int>(wave_prefix_count(m_exp))] = (bt.ra << 3) | (bt.rb - 1u);
             }
             size += __builtin_popcountll(m_exp);
+            RK_COUNT(24, __builtin_popcountll(m_exp))
             const unsigned long long m_und = __builtin_amdgcn_ballot_w64(undecided);
             if (undecided) {
                 L.uq[n_uq + static_cast<int>(wave_prefix_count(m_und))] = bt.rec;
             }
             n_uq += __builtin_popcountll(m_und);
+            RK_COUNT(7, __builtin_popcountll(m_und))
             wave_sync();
         };
 
@@ -297,6 +328,7 @@ __device__ __forceinline__ void list_node(const kparams<F> &P, lk_wave_lds<F> &L
             const bool anc = bt.active && bt.node <= cnode && cnode <= bt.node + bt.nch;
             const bool self = anc && bt.node == cnode;
             const bool test = bt.active && !anc;
+            RK_COUNT(1, 1) RK_COUNT(2, __builtin_popcountll(__builtin_amdgcn_ballot_w64(bt.active)))
             const F mac_lh = mac_lhs<F>(MAC == RK_MAC_RT ? P.mac : MAC, bt.mp, mac_value);
 #ifdef RK_STAMPS
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -344,6 +376,7 @@ __device__ __forceinline__ void list_node(const kparams<F> &P, lk_wave_lds<F> &L
             bool fail;
 #if RK_EXACT_TRANSPOSED
             if (!BIG && k * (7 * R + 3) < T * 7) {
+                RK_COUNT(5, 1) RK_COUNT(6, k)
                 // Few candidates: lane = target. Every lane already keeps R targets of the group in registers (unused
                 // slots repeat target 0), so a candidate costs one broadcast LDS read and 7 R + 3 instructions instead of
                 // a share of the 7 T of the loop below. Same formula, same operands: same decision.
@@ -360,7 +393,7 @@ __device__ __forceinline__ void list_node(const kparams<F> &P, lk_wave_lds<F> &L
                     bool f = false;
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
-                        const F dx = cand.x - tp[r].x, dy = cand.y - tp[r].y, dz = cand.z - tp[r].z;
+                        const F dx = cand.x - tg.tx(r), dy = cand.y - tg.ty(r), dz = cand.z - tg.tz(r);
                         const F d2 = rk_fma(dz, dz, rk_fma(dy, dy, dx * dx));
                         f |= cand.w >= d2;
                     }
@@ -376,6 +409,7 @@ __device__ __forceinline__ void list_node(const kparams<F> &P, lk_wave_lds<F> &L
                 // min over the targets of the unsoftened squared distance to the node's centre of mass. The target
                 // coordinates are wave-uniform: they arrive through scalar loads as SGPR operands.
                 F mind2 = std::numeric_limits<F>::infinity();
+                RK_COUNT(3, 1) RK_COUNT(4, TG) RK_COUNT(25, k)
                 for (int t = 0; t < TG; t += 4) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -402,6 +436,7 @@ __device__ __forceinline__ void list_node(const kparams<F> &P, lk_wave_lds<F> &L
             for (uint32_t base = 0; base < sup_ncommon;) {
                 const uint32_t room = static_cast<uint32_t>(SRC_CAP - n_src), left = sup_ncommon - base;
                 const uint32_t take = left < room ? left : room;
+                RK_COUNT(16, (take + 63u) / 64u) RK_COUNT(17, take)
                 for (uint32_t j = lane; j < take; j += 64u) {
                     L.src[n_src + static_cast<int>(j)] = common[base + j];
                 }
@@ -439,6 +474,9 @@ __device__ __forceinline__ void list_node(const kparams<F> &P, lk_wave_lds<F> &L
         // Queues are settled BEFORE the next batch of records is fetched, so that no candidate registers are live
         // across the dense phase (register pressure decides the occupancy of this kernel).
         bool done = false;
+#ifdef RK_ABLATE_LIST
+        size = 0, sup_nresid = 0; // diagnostic build: no list building at all (prologue, own particles, reduction, epilogue remain)
+#endif
         for (;;) {
             // Room for the worst-case output of one pass (64 sources, 64 leaves); everything is settled at the end.
             if (n_lq + 64 > LK_LQ_CAP || done) {
@@ -488,7 +526,8 @@ __device__ __forceinline__ void list_node(const kparams<F> &P, lk_wave_lds<F> &L
             for (int r = 0; r < R; ++r) {
                 tloc[r] = tidx[r] < 0 ? -1 : static_cast<int>(tb - gb) + tidx[r] - b0;
             }
-            lk_eval_tile<F, Q, R, true, ND>(L.src, n, (n * inv_ns) >> 16, sp, NS, true, lane_on, tp, acc, eps2, tloc);
+            RK_COUNT(18, 1) RK_COUNT(19, (n * inv_ns) >> 16) RK_COUNT(27, n - ((n * inv_ns) >> 16) * NS > 0 ? 1 : 0)
+            lk_eval_tile<F, Q, R, true, ND>(L.src, n, (n * inv_ns) >> 16, sp, NS, true, lane_on, tg, eps2, tloc);
             wave_sync();
         }
 
@@ -504,7 +543,7 @@ __device__ __forceinline__ void list_node(const kparams<F> &P, lk_wave_lds<F> &L
                 if (lane_on) {
 #pragma unroll
                     for (int k = 0; k < NR; ++k) {
-                        red[(sp_raw * TP + ts) * NR + k] = acc[r][k];
+                        red[(sp_raw * TP + ts) * NR + k] = tg.get(r, k);
                     }
                 }
                 wave_sync();
@@ -515,7 +554,7 @@ __device__ __forceinline__ void list_node(const kparams<F> &P, lk_wave_lds<F> &L
                         for (int s = 0; s < NS; ++s) {
                             sum += red[(s * TP + ts) * NR + k];
                         }
-                        acc[r][k] = sum;
+                        tg.set(r, k, sum);
                     }
                 }
                 wave_sync();
@@ -529,7 +568,7 @@ __device__ __forceinline__ void list_node(const kparams<F> &P, lk_wave_lds<F> &L
 #pragma unroll
                     for (int k = 0; k < NR; ++k) {
                         if (ND == 3 || Q == 1 || k != 2) { // a quadtree has no z acceleration (and no array for it)
-                            P.out[k][o] = acc[r][k] * G;
+                            P.out[k][o] = tg.get(r, k) * G;
                         }
                     }
                 }
@@ -537,6 +576,7 @@ __device__ __forceinline__ void list_node(const kparams<F> &P, lk_wave_lds<F> &L
         }
         RK_STAMP(7)
         RK_STAMP_FLUSH
+        RK_COUNT_FLUSH
 #ifdef RK_TRACE
         if (!BIG && lane == 0 && P.dbg) {
             const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
@@ -760,7 +800,9 @@ void launch_super(const rk_state &s, const kparams<F> &p, int64_t s_begin, int64
     RK_HIP(hipGetLastError());
 }
 template void launch_super<float>(const rk_state &, const kparams<float> &, int64_t, int64_t, hipStream_t);
+#ifndef RK_SLIM
 template void launch_super<double>(const rk_state &, const kparams<double> &, int64_t, int64_t, hipStream_t);
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Launch.
@@ -811,11 +853,13 @@ void launch_list(const rk_state &s, int q, const kparams<F> &p, const int64_t cb
 {
     switch (q * 2 + s.mac) {
         case 0: launch_list_qm<F, 0, mac_targ(0)>(s, p, cb, ce, streams, class_mask); break;
+#ifndef RK_SLIM // (RK_SLIM: device-code inspection builds with one instantiation per kernel; never linked)
         case 1: launch_list_qm<F, 0, mac_targ(1)>(s, p, cb, ce, streams, class_mask); break;
         case 2: launch_list_qm<F, 1, mac_targ(0)>(s, p, cb, ce, streams, class_mask); break;
         case 3: launch_list_qm<F, 1, mac_targ(1)>(s, p, cb, ce, streams, class_mask); break;
         case 4: launch_list_qm<F, 2, mac_targ(0)>(s, p, cb, ce, streams, class_mask); break;
         case 5: launch_list_qm<F, 2, mac_targ(1)>(s, p, cb, ce, streams, class_mask); break;
+#endif
         default: throw error(RK_EINVAL, "invalid q / mac combination");
     }
     RK_HIP(hipGetLastError());
@@ -857,17 +901,21 @@ void launch_list_any(const rk_state &s, int q, const kparams<F> &p, const uint32
     using i2 = std::integral_constant<int, 2>;
     switch (q * 2 + s.mac) {
         case 0: go(i0{}, i0{}); break;
+#ifndef RK_SLIM
         case 1: go(i0{}, i1{}); break;
         case 2: go(i1{}, i0{}); break;
         case 3: go(i1{}, i1{}); break;
         case 4: go(i2{}, i0{}); break;
         case 5: go(i2{}, i1{}); break;
+#endif
         default: throw error(RK_EINVAL, "invalid q / mac combination");
     }
     RK_HIP(hipGetLastError());
 }
 template void launch_list_any<float>(const rk_state &, int, const kparams<float> &, const uint32_t *, int64_t, hipStream_t, int);
+#ifndef RK_SLIM
 template void launch_list_any<double>(const rk_state &, int, const kparams<double> &, const uint32_t *, int64_t, hipStream_t, int);
+#endif
 
 // Critical nodes of more than 64 * RK_MAX_R particles: k_list<..., BIG> (one workgroup per node).
 template <typename F>
@@ -892,24 +940,30 @@ void launch_list_big(const rk_state &s, int q, const kparams<F> &p, const uint32
     using i2 = std::integral_constant<int, 2>;
     switch (q * 2 + s.mac) {
         case 0: go(i0{}, i0{}); break;
+#ifndef RK_SLIM
         case 1: go(i0{}, i1{}); break;
         case 2: go(i1{}, i0{}); break;
         case 3: go(i1{}, i1{}); break;
         case 4: go(i2{}, i0{}); break;
         case 5: go(i2{}, i1{}); break;
+#endif
         default: throw error(RK_EINVAL, "invalid q / mac combination");
     }
     RK_HIP(hipGetLastError());
 }
 template void launch_list_big<float>(const rk_state &, int, const kparams<float> &, const uint32_t *, int64_t, hipStream_t,
                                      const uint32_t *);
+#ifndef RK_SLIM
 template void launch_list_big<double>(const rk_state &, int, const kparams<double> &, const uint32_t *, int64_t, hipStream_t,
                                       const uint32_t *);
+#endif
 
 template void launch_list<float>(const rk_state &, int, const kparams<float> &, const int64_t[n_classes],
                                  const int64_t[n_classes], hipStream_t const[n_list_R], unsigned);
+#ifndef RK_SLIM
 template void launch_list<double>(const rk_state &, int, const kparams<double> &, const int64_t[n_classes],
                                   const int64_t[n_classes], hipStream_t const[n_list_R], unsigned);
+#endif
 
 // Makes the runtime load this translation unit's code object now (rk_init) instead of at the first launch.
 void touch_list()

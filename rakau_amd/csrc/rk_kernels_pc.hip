@@ -128,23 +128,15 @@ __device__ __forceinline__ void pc_node(const kparams<F> &P, pc_lds<F> &L, const
         const int cons = role - 1;
         auto consume = [&](auto CRtag, const int r0) __attribute__((always_inline)) {
             constexpr int CR = decltype(CRtag)::value;
-            v4 tp[CR];
+            lk_regs<F, Q, CR> tg; // this consumer's targets and their sums (register pairs in the packed fp32 flavour)
             int tidx[CR];
 #pragma unroll
             for (int j = 0; j < CR; ++j) {
                 tidx[j] = ts + (r0 + j) * TP;
                 const bool valid = tidx[j] < T;
-                tp[j] = P.part4[tb + (valid ? tidx[j] : 0)];
+                tg.set_target(j, P.part4[tb + (valid ? tidx[j] : 0)]);
                 if (!valid) {
                     tidx[j] = -1;
-                }
-            }
-            F acc[CR][NR];
-#pragma unroll
-            for (int j = 0; j < CR; ++j) {
-#pragma unroll
-                for (int k = 0; k < NR; ++k) {
-                    acc[j][k] = F(0);
                 }
             }
             // n / NS for n <= SRC_CAP without a division per tile: exact for n * NS < 2^16.
@@ -157,7 +149,7 @@ __device__ __forceinline__ void pc_node(const kparams<F> &P, pc_lds<F> &L, const
                     const uint32_t word = L.tile_n[buf];
                     const int n = static_cast<int>(word & ~PC_LAST);
                     if (n > 0) {
-                        lk_eval_tile<F, Q, CR, false, ND>(L.tile[buf], n, (n * inv_ns) >> 16, sp, NS, true, lane_on, tp, acc, eps2, tidx);
+                        lk_eval_tile<F, Q, CR, false, ND>(L.tile[buf], n, (n * inv_ns) >> 16, sp, NS, true, lane_on, tg, eps2, tidx);
                     }
                     if (word & PC_LAST) {
                         break;
@@ -172,7 +164,7 @@ __device__ __forceinline__ void pc_node(const kparams<F> &P, pc_lds<F> &L, const
                     const uint32_t word = L.tile_n[buf];
                     const int n = static_cast<int>(word & ~PC_LAST);
                     if (n > 0) {
-                        lk_eval_tile<F, Q, CR, false, ND>(L.tile[buf], n, (n * inv_ns) >> 16, sp, NS, true, lane_on, tp, acc, eps2, tidx);
+                        lk_eval_tile<F, Q, CR, false, ND>(L.tile[buf], n, (n * inv_ns) >> 16, sp, NS, true, lane_on, tg, eps2, tidx);
                     }
                     ++it;
                     pc_signal(&L.sync[1 + cons], it, lane);
@@ -206,7 +198,7 @@ __device__ __forceinline__ void pc_node(const kparams<F> &P, pc_lds<F> &L, const
                     for (int j = 0; j < CR; ++j) {
                         tloc[j] = tidx[j] < 0 ? -1 : tidx[j] - b0;
                     }
-                    lk_eval_tile<F, Q, CR, true, ND>(self, n, (n * inv_ns) >> 16, sp, NS, true, lane_on, tp, acc, eps2, tloc);
+                    lk_eval_tile<F, Q, CR, true, ND>(self, n, (n * inv_ns) >> 16, sp, NS, true, lane_on, tg, eps2, tloc);
                     if constexpr (NC > 1) {
                         __syncthreads();
                     } else {
@@ -222,7 +214,7 @@ __device__ __forceinline__ void pc_node(const kparams<F> &P, pc_lds<F> &L, const
                     for (int j = 0; j < CR; ++j) {
 #pragma unroll
                         for (int k = 0; k < NR; ++k) {
-                            red[j * 64 * NR + (sp_raw * TP + ts) * NR + k] = acc[j][k];
+                            red[j * 64 * NR + (sp_raw * TP + ts) * NR + k] = tg.get(j, k);
                         }
                     }
                 }
@@ -236,7 +228,7 @@ __device__ __forceinline__ void pc_node(const kparams<F> &P, pc_lds<F> &L, const
                             for (int s = 0; s < NS; ++s) {
                                 sum += red[j * 64 * NR + (s * TP + ts) * NR + k];
                             }
-                            acc[j][k] = sum;
+                            tg.set(j, k, sum);
                         }
                     }
                 }
@@ -251,7 +243,7 @@ __device__ __forceinline__ void pc_node(const kparams<F> &P, pc_lds<F> &L, const
 #pragma unroll
                         for (int k = 0; k < NR; ++k) {
                             if (ND == 3 || Q == 1 || k != 2) { // a quadtree has no z acceleration (and no array for it)
-                                P.out[k][o] = acc[j][k] * G;
+                                P.out[k][o] = tg.get(j, k) * G;
                             }
                         }
                     }

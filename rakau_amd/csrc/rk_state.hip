@@ -1315,6 +1315,28 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
         p.dbg = d_dbg;
     }
 #endif
+#ifdef RK_COUNTS
+    {
+        // Diagnostic build: event counts of the PREVIOUS call (rk_list_common.hpp, RK_COUNT), 32 per lane-mapping class.
+        static unsigned long long *d_cnt = nullptr;
+        if (!d_cnt) {
+            RK_HIP(hipMalloc(&d_cnt, 128 * sizeof(unsigned long long)));
+            RK_HIP(hipMemset(d_cnt, 0, 128 * sizeof(unsigned long long)));
+        }
+        unsigned long long h[128];
+        RK_HIP(hipDeviceSynchronize());
+        RK_HIP(hipMemcpy(h, d_cnt, sizeof(h), hipMemcpyDeviceToHost));
+        for (int r = 0; r < 4; ++r) {
+            fprintf(stderr, "RK_COUNTS prev R=%d:", r + 1);
+            for (int i = 0; i < 32; ++i) {
+                fprintf(stderr, " %llu", h[r * 32 + i]);
+            }
+            fprintf(stderr, "\n");
+        }
+        RK_HIP(hipMemset(d_cnt, 0, sizeof(h)));
+        p.dbg = d_cnt;
+    }
+#endif
 #ifdef RK_TRACE
     {
         // Diagnostic build: per-wave {start, end, placement, size} records of the PREVIOUS call go to $RK_TRACE_FILE.

@@ -92,6 +92,53 @@ def test_malformed_node_arrays_are_refused():
     assert st.n_crit == ot.n_crit
 
 
+ORPHAN_CODE = """
+import sys, numpy as np, oracle, rakau_amd
+from helpers import oracle_nodes_aos
+m, x, y, z = oracle.plummer(5000, np.float32)
+ot = oracle.Tree(x, y, z, m)
+p = ot.parts_u()
+good = oracle_nodes_aos(ot)
+n = len(good)
+# an internal node in the middle of the array whose children are internal too
+mid = [k for k in range(n // 3, n) if good["n_children"][k] > 20][0]
+first_child_span = int(good["n_children"][mid + 1]) + 1
+def edits():
+    yield "root without children", lambda a: a["n_children"].__setitem__(0, 0)
+    yield "root count truncated to its first child", lambda a: a["n_children"].__setitem__(0, int(a["n_children"][1]) + 1)
+    yield "inner node keeps its first child only", lambda a: a["n_children"].__setitem__(mid, first_child_span)
+    yield "inner node becomes a leaf", lambda a: a["n_children"].__setitem__(mid, 0)
+for rep in range(3):   # warm and cold block cache alike
+    for name, edit in edits():
+        a = good.copy()
+        edit(a)
+        try:
+            rakau_amd.State(p[0], p[1], p[2], p[3], a, ncrit=ot.ncrit)
+        except ValueError as e:
+            assert "inconsistent" in str(e), (name, str(e))
+        else:
+            raise SystemExit("accepted: " + name)
+    st = rakau_amd.State(p[0], p[1], p[2], p[3], good, ncrit=ot.ncrit)
+    assert st.n_crit == ot.n_crit
+    st.close()
+print("ORPHANS_REFUSED")
+"""
+
+
+@pytest.mark.parametrize("where", ["device", "host"])
+def test_nodes_no_parent_claims_are_refused_under_a_poisoned_pool(where):
+    """node arrays in which some node is claimed by no parent (a root with n_children = 0 or truncated, an inner
+    node whose count covers only part of its subtree). The device conversion keeps parent[] in a block from the recycling
+    pool; with RK_POOL_POISON=255 every block is handed out filled with 0xff, so a read of a parent index nobody wrote is
+    an out-of-range index, deterministically. Both conversions must refuse such trees with the reference-style error."""
+    env = dict(os.environ, RK_POOL_POISON="255", RK_BACKTRACE="1")
+    if where == "host":
+        env["RK_CREATE_ON_HOST"] = "1"
+    env["PYTHONPATH"] = os.pathsep.join([ROOT, os.path.join(ROOT, "tests"), env.get("PYTHONPATH", "")])
+    out = subprocess.run([sys.executable, "-c", ORPHAN_CODE], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0 and "ORPHANS_REFUSED" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
 def test_state_create_time_4m():
     """Not a parity test: prints what rk_state_create() costs at 4M either way (run with -s)."""
     code = """

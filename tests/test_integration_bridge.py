@@ -6,32 +6,27 @@ this repository or travels to the GPU box). The GPU test runs the driver built h
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REF_INC = "/root/reference/include"
-BUILD = os.path.join(ROOT, "tests", "build")
-LIB = os.path.join(BUILD, "librakau_rocm_bridge.so")
-DRIVER = os.path.join(BUILD, "bridge_driver")
-CUDA_LIB = os.path.join(BUILD, "librakau_cuda_bridge.so")
-CUDA_DRIVER = os.path.join(BUILD, "cuda_bridge_driver")
-RK_LIBDIR = os.path.join(ROOT, "rakau_amd", "lib")
+sys.path.insert(0, os.path.join(ROOT, "integration"))
+import build_bridges as bb  # noqa: E402  (the recipe, shared with __graft_entry__.build())
+
+REF_INC, LIB, DRIVER, CUDA_LIB, CUDA_DRIVER = bb.REF_INC, bb.LIB, bb.DRIVER, bb.CUDA_LIB, bb.CUDA_DRIVER
+build = bb.build
 
 
-def build():
-    os.makedirs(BUILD, exist_ok=True)
-    common = ["g++", "-std=c++17", "-O2", "-fPIC", "-Wall", "-Wextra", "-Wno-comment", "-I" + REF_INC, "-I" + os.path.join(ROOT, "include")]
-    subprocess.check_call(common + ["-shared", os.path.join(ROOT, "integration", "rakau_amd_bridge.cpp"), "-L" + RK_LIBDIR,
-                                    "-lrakau_amd", "-Wl,-rpath," + RK_LIBDIR, "-o", LIB])
-    subprocess.check_call(common + ["-pthread", os.path.join(ROOT, "tests", "cpp", "bridge_driver.cpp"), "-L" + BUILD, "-lrakau_rocm_bridge",
-                                    "-L" + RK_LIBDIR, "-lrakau_amd", "-Wl,-rpath," + BUILD, "-Wl,-rpath," + RK_LIBDIR, "-o", DRIVER])
-    # The CUDA seam (include/rakau/detail/cuda_fwd.hpp:23-30): the reference's multi-GPU entry.
-    subprocess.check_call(common + ["-shared", "-pthread", os.path.join(ROOT, "integration", "rakau_amd_cuda_bridge.cpp"), "-L" + RK_LIBDIR,
-                                    "-lrakau_amd", "-Wl,-rpath," + RK_LIBDIR, "-o", CUDA_LIB])
-    subprocess.check_call(common + ["-pthread", os.path.join(ROOT, "tests", "cpp", "cuda_bridge_driver.cpp"), "-L" + BUILD,
-                                    "-lrakau_cuda_bridge", "-L" + RK_LIBDIR, "-lrakau_amd", "-Wl,-rpath," + BUILD, "-Wl,-rpath," + RK_LIBDIR,
-                                    "-o", CUDA_DRIVER])
+def driver_or_fail(path):
+    """The GPU box has no checkout of the reference: the drivers travel prebuilt (tests/build/, made by
+    __graft_entry__.build() where the reference's headers are). A missing driver there is a FAILURE, not a skip: these two
+    tests are the only ones that call the engine through the reference-side bindings."""
+    if bb.have_reference():
+        bb.build(force=False)
+    assert os.path.exists(path), ("%s was not built: run __graft_entry__.build() (or python integration/build_bridges.py) on a "
+                                  "machine with the reference's headers at %s before shipping the tree to the GPU box" % (path, REF_INC))
+    return path
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_INC), reason="no checkout of the reference: the bridge cannot be compiled")
@@ -52,11 +47,7 @@ def test_bridge_compiles_against_the_reference_headers():
 
 @pytest.mark.gpu
 def test_bridge_driver_on_gpu():
-    if not os.path.exists(DRIVER):
-        if not os.path.isdir(REF_INC):
-            pytest.skip("bridge driver not built (no checkout of the reference where this tree was built)")
-        build()
-    out = subprocess.run([DRIVER], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([driver_or_fail(DRIVER)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "bridge checks: 0 failure(s)" in out.stdout, out.stdout + out.stderr
 
 
@@ -87,10 +78,6 @@ def test_cuda_bridge_driver_on_gpu():
     """cuda_acc_pot_impl over four logical devices (RK_ALIAS_DEVICES=4 on the 1-GPU box): every device share bit-identical
     to the one-device call, compact and offset outputs, announced (resident replicas, invalidated by a mass update) and
     unannounced (state per call) trees, 32-bit codes, the reference's error for too many accelerators."""
-    if not os.path.exists(CUDA_DRIVER):
-        if not os.path.isdir(REF_INC):
-            pytest.skip("cuda bridge driver not built (no checkout of the reference where this tree was built)")
-        build()
     env = dict(os.environ, RK_ALIAS_DEVICES="4")
-    out = subprocess.run([CUDA_DRIVER], capture_output=True, text=True, timeout=600, env=env)
+    out = subprocess.run([driver_or_fail(CUDA_DRIVER)], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and "cuda bridge checks: 0 failure(s)" in out.stdout, out.stdout + out.stderr
