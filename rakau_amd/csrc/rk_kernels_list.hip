@@ -49,7 +49,7 @@ __device__ __forceinline__ void list_node(const kparams<F> &P, lk_wave_lds<F> &L
         const bool lane_on = sp_raw < NS;
         const int sp = lane_on ? sp_raw : 0; // idle lanes shadow split 0; their results are never stored
 
-        lk_regs<F, Q, R> tg; // the lane's R targets and their sums (register pairs in the packed fp32 flavour)
+        lk_regs<F, Q, R> tg; // the lane's R targets and their sums
         int tidx[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {

@@ -128,7 +128,7 @@ __device__ __forceinline__ void pc_node(const kparams<F> &P, pc_lds<F> &L, const
         const int cons = role - 1;
         auto consume = [&](auto CRtag, const int r0) __attribute__((always_inline)) {
             constexpr int CR = decltype(CRtag)::value;
-            lk_regs<F, Q, CR> tg; // this consumer's targets and their sums (register pairs in the packed fp32 flavour)
+            lk_regs<F, Q, CR> tg; // this consumer's targets and their sums
             int tidx[CR];
 #pragma unroll
             for (int j = 0; j < CR; ++j) {
