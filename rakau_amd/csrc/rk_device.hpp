@@ -2,6 +2,8 @@
 #ifndef RK_DEVICE_HPP
 #define RK_DEVICE_HPP
 
+#include <type_traits>
+
 #include "rk_common.hpp"
 
 namespace rk
@@ -139,17 +141,24 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-// Inclusive prefix sum over the 64 lanes.
+// Inclusive prefix sum over the 64 lanes (all of them active). Data-parallel-primitive form: a Hillis-Steele scan inside every
+// row of 16 lanes (row_shr 1, 2, 4, 8; lanes without a source add 0), then the row totals are passed on (row_bcast:15 into
+// rows 1 and 3, row_bcast:31 into rows 2 and 3): six v_add_u32 with DPP operands. Rounds 1-4 used six dependent __shfl_up,
+// i.e. six ds_bpermute_b32 round trips through the LDS crossbar per scan (~400 cycles in the leaf-gathering path of every
+// list-building wave) that also kept six address registers and six lane masks alive for the whole kernel.
 __device__ __forceinline__ unsigned wave_incl_scan(unsigned v)
 {
-    const int lane = static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned o = static_cast<unsigned>(__shfl_up(static_cast<int>(v), d, 64));
-        if (lane >= d) {
-            v += o;
-        }
-    }
+    const auto step = [](unsigned x, auto ctrl, auto rows) __attribute__((always_inline)) {
+        return static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), decltype(ctrl)::value, decltype(rows)::value,
+                                                                 0xf, false));
+    };
+    using std::integral_constant;
+    v += step(v, integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{}); // row_shr:1
+    v += step(v, integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{}); // row_shr:2
+    v += step(v, integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{}); // row_shr:4
+    v += step(v, integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{}); // row_shr:8
+    v += step(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{}); // row_bcast:15 -> rows 1, 3
+    v += step(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{}); // row_bcast:31 -> rows 2, 3
     return v;
 }
 

@@ -58,7 +58,9 @@
                     // kernel at 3 waves as well: 60.0
 #endif
 #ifndef RK_W12
-#define RK_W12 7 // waves per SIMD the R <= 2 kernels are compiled for
+#define RK_W12 8 // waves per SIMD the R <= 2 kernels are compiled for. Round 5: 8 (64 VGPRs, 12 / 44 bytes of scratch, 5 KiB of LDS per
+                 // wave) once the DPP prefix sum had freed six address registers and six lane masks: 4M 2.215 -> 2.195 ms, the
+                 // seam's call 1717-1728 -> 1759-1767 Mparticles/s (tools/jobs_r05/r05_job11.sh); rounds 1-4: 7 (8 spilled 50-60 B)
 #endif
 #ifndef RK_W3
 #define RK_W3 6 // R = 3
@@ -137,10 +139,17 @@ constexpr int mac_targ(int mac)
 
 // Stack of pending sibling runs; an entry = (first child record << 3) | (number of children - 1) names up to
 // 8 candidate nodes. Popping k entries can push at most 8k (every candidate opened).
-constexpr int LK_STACK_CAP = 512;
+#ifndef RK_STACK_CAP
+#define RK_STACK_CAP 384 // (rounds 1-4: 512. 384 entries + tile + queues = 5 KiB per wave = 32 single-wave workgroups per CU; the 237
+                         // entries above the depth-first reserve still take 8 runs per batch in every tree measured: same bits)
+#endif
+constexpr int LK_STACK_CAP = RK_STACK_CAP;
 // Worst-case growth of the stack while descending depth-first from one entry: 7 pending entries per level.
 constexpr int LK_DFS_RESERVE = 7 * 21;
-constexpr int LK_LQ_CAP = 128;
+#ifndef RK_LQ_CAP
+#define RK_LQ_CAP 128
+#endif
+constexpr int LK_LQ_CAP = RK_LQ_CAP;
 // Queue of candidates left undecided by the bounding-box / probe tests.
 constexpr int LK_UQ_CAP = 128;
 // Critical nodes too large for one wavefront (k_list<..., BIG>): wavefronts per workgroup, targets per chunk.
@@ -159,7 +168,7 @@ struct lk_cfg {
     static constexpr int src_cap = 128; // sources per tile (2 KiB fp32, 4 KiB fp64)
 };
 
-// Per-wave LDS: 2 + 2 + 1 + 0.5 KiB = 5.5 KiB (fp32; 7.5 KiB fp64): 28 single-wave blocks per CU = 7 waves per SIMD.
+// Per-wave LDS: 1.5 + 2 + 1 + 0.5 KiB = 5 KiB (fp32; 7 KiB fp64): 32 single-wave blocks per CU = 8 waves per SIMD.
 template <typename F>
 struct lk_wave_lds {
     uint32_t stack[LK_STACK_CAP];
