@@ -20,6 +20,7 @@
 // particle order like the reference). The reference sums every node's particles serially; its own SIMD flavour
 // (tree.hpp:1134-1161) already associates differently, so centres of mass agree to rounding, not bit for bit.
 #include "rk_common.hpp"
+#include "rk_device.hpp"
 
 #include <hipcub/hipcub.hpp>
 
@@ -165,10 +166,17 @@ __global__ void k_maxabs(const F *x, const F *y, const F *z, uint32_t n, ctrl_bl
     }
 }
 
-// Domain size: given, or 2 * max|coord| + 5% (tree.hpp:1306-1312 of the reference). One thread.
-template <typename F>
-__global__ void k_box(ctrl_block *ctrl, F box_in)
+// ---- discretise + encode ----------------------------------------------------------------------------------
+template <typename F, int ND>
+__global__ void k_encode(const F *x, const F *y, const F *z, uint32_t n, ctrl_block *ctrl, F box_in, uint64_t *codes,
+                         uint32_t *idx)
 {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    // Domain size: given, or 2 * max|coord| + 5% (tree.hpp:1306-1312 of the reference) -- every thread derives it from the
+    // reduction's result (three operations), thread 0 records it for the host: no one-thread kernel in between.
     F box = box_in;
     if (box_in == F(0)) {
         F mx;
@@ -177,26 +185,16 @@ __global__ void k_box(ctrl_block *ctrl, F box_in)
         } else {
             mx = __longlong_as_double(static_cast<long long>(ctrl->maxbits));
         }
-        F b = mx * F(2);
-        b = d_fma(b, F(1) / F(20), b);
-        if (!isfinite(b)) {
+        const F b = mx * F(2);
+        box = d_fma(b, F(1) / F(20), b);
+    }
+    if (i == 0u) {
+        if (!isfinite(box)) {
             atomicOr(&ctrl->err, static_cast<unsigned>(ERR_BOX));
         }
-        box = b;
+        ctrl->box = static_cast<double>(box);
     }
-    ctrl->box = static_cast<double>(box);
-}
-
-// ---- discretise + encode ----------------------------------------------------------------------------------
-template <typename F, int ND>
-__global__ void k_encode(const F *x, const F *y, const F *z, uint32_t n, ctrl_block *ctrl, uint64_t *codes,
-                         uint32_t *idx)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) {
-        return;
-    }
-    const F inv_box = F(1) / static_cast<F>(ctrl->box);
+    const F inv_box = F(1) / box;
     constexpr F factor = F(1u << geo<ND>::CB);
     uint64_t d[3] = {};
     const F v[3] = {x[i], y[i], ND == 3 ? z[i] : F(0)};
@@ -329,19 +327,27 @@ __global__ void k_node_counts(const uint64_t *codes, uint32_t n, const uint8_t *
     }
     __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned lvl = 0u;
     if (i < n) {
         // Identical codes never start a node.
         const unsigned dv = i > 0 ? common_levels<ND>(codes[i - 1], codes[i]) + 1u : 1u;
-        const unsigned lvl = leaf[i];
+        lvl = leaf[i];
         ldiv[i] = static_cast<uint8_t>(dv);
         cnt[i] = dv <= lvl ? lvl - dv + 1u : 0u;
         if (i == 0u) {
             cnt[n] = 0u; // the scan runs over n + 1 values so that off[n] is the total
         }
-        atomicMax(&s_max, lvl);
+    }
+    // Deepest level of the block: levels are below 32, so the wavefront's maximum is the highest bit of the OR of (1 << level)
+    // over its lanes (a DPP reduction), one LDS atomic per wavefront instead of one per thread.
+    const unsigned any = wave_reduce_or(1u << (lvl & 31u));
+    if ((threadIdx.x & 63u) == 0u) {
+        atomicMax(&s_max, 31u - static_cast<unsigned>(__clz(static_cast<int>(any))));
     }
     __syncthreads();
-    if (threadIdx.x == 0u) {
+    // (Same-address atomics serialise at ~10 ns each: with one per block this line alone was 150 us of a 4M-particle rebuild. The
+    // value only grows, so a block that sees its own maximum already recorded has nothing to add.)
+    if (threadIdx.x == 0u && s_max > __hip_atomic_load(&ctrl->max_level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
         atomicMax(&ctrl->max_level, s_max);
     }
 }
@@ -377,7 +383,10 @@ __global__ void k_emit_nodes(const uint64_t *codes, uint32_t n, const uint8_t *l
     for (unsigned lvl = lf; lvl >= dv; --lvl) {
         const unsigned shift = geo<ND>::DB * (geo<ND>::CB - lvl);
         const uint64_t p = ci >> shift;
-        // Smallest j >= hi with j == n or a different level-lvl prefix.
+        // Smallest j >= hi with j == n or a different level-lvl prefix. The chain of dependent probes sets this kernel's time
+        // (the first particle of a large cell walks up a dozen levels, each probe a memory round trip), so both phases are
+        // 8-ary: the gallop grows its stride by 8, the search issues seven independent probes per step -- a third of the
+        // dependent steps of the binary forms for 2.3 x the loads.
         uint32_t a = hi, b, step = 1u;
         for (;;) {
             b = a + (step - 1u);
@@ -389,15 +398,44 @@ __global__ void k_emit_nodes(const uint64_t *codes, uint32_t n, const uint8_t *l
                 break;
             }
             a = b + 1u;
-            step <<= 1;
+            step = step > (1u << 28) ? step : step << 3;
         }
-        while (a < b) {
-            const uint32_t mid = a + (b - a) / 2u;
-            if ((codes[mid] >> shift) == p) {
-                a = mid + 1u;
-            } else {
-                b = mid;
+        // Invariant: every j < a has the prefix, b has not (or b == n).
+        while (b - a >= 8u) {
+            const uint32_t w = (b - a) >> 3;
+            uint64_t c[7];
+#pragma unroll
+            for (uint32_t k = 0; k < 7u; ++k) {
+                c[k] = codes[a + w * (k + 1u)];
             }
+            uint32_t na = a, nb = b;
+            bool found = false;
+#pragma unroll
+            for (uint32_t k = 0; k < 7u; ++k) {
+                const bool same = (c[k] >> shift) == p;
+                if (!found) {
+                    if (same) {
+                        na = a + w * (k + 1u) + 1u;
+                    } else {
+                        nb = a + w * (k + 1u);
+                        found = true;
+                    }
+                }
+            }
+            a = na, b = nb;
+        }
+        {
+            // At most seven candidates left: probe them all, the prefix holds for a leading run of them.
+            uint32_t run = 0;
+            bool open = true;
+#pragma unroll
+            for (uint32_t k = 0; k < 7u; ++k) {
+                const uint32_t j = a + k;
+                const bool same = j < b && (codes[j < n ? j : n - 1u] >> shift) == p;
+                open = open && same;
+                run += open ? 1u : 0u;
+            }
+            a += run;
         }
         hi = a;
         const uint32_t dfs = base_dfs + (lvl - dv);
@@ -786,8 +824,7 @@ __global__ void k_pack_counts(ctrl_block *ctrl, const tri *total)
 }
 
 template <typename F>
-__global__ void k_crit(const uint4 *topo, const tri *flags, const tri *offs, uint32_t n_nodes,
-                       const typename vt<F>::v4 *part4, uint4 *crit, typename vt<F>::v4 *boxes)
+__global__ void k_crit(const uint4 *topo, const tri *flags, const tri *offs, uint32_t n_nodes, uint4 *crit)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_nodes || !flags[k].a) {
@@ -795,15 +832,36 @@ __global__ void k_crit(const uint4 *topo, const tri *flags, const tri *offs, uin
     }
     const uint32_t g = offs[k].a, b = topo[k].y, e = topo[k].z;
     crit[g] = make_uint4(b, e, k, e - b);
-    typename vt<F>::v4 lo = part4[b], hi = lo;
-    for (uint32_t i = b + 1u; i < e; ++i) {
+}
+
+// Tight bounding box of every critical node's particles: one wavefront per node (lanes stride over its particles, minima and
+// maxima folded across the lanes; both are exact, so the boxes are those of a serial loop). Rounds 2-4 had one THREAD walk the up
+// to ncrit particles of its node inside k_crit: 75 us at 4M particles against 8.
+template <typename F>
+__global__ void __launch_bounds__(256) k_crit_boxes(const uint4 *crit, uint32_t n_crit, const typename vt<F>::v4 *part4,
+                                                    typename vt<F>::v4 *boxes)
+{
+    const uint32_t g = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (g >= n_crit) {
+        return;
+    }
+    const uint32_t lane = threadIdx.x & 63u, b = crit[g].x, e = crit[g].y;
+    typename vt<F>::v4 lo = part4[b], hi = lo; // (every lane starts from the first particle: idle lanes are neutral)
+    for (uint32_t i = b + lane; i < e; i += 64u) {
         const typename vt<F>::v4 p = part4[i];
         lo.x = fmin(lo.x, p.x), lo.y = fmin(lo.y, p.y), lo.z = fmin(lo.z, p.z);
         hi.x = fmax(hi.x, p.x), hi.y = fmax(hi.y, p.y), hi.z = fmax(hi.z, p.z);
     }
-    lo.w = hi.w = F(0);
-    boxes[2u * g] = lo;
-    boxes[2u * g + 1u] = hi;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        lo.x = fmin(lo.x, __shfl_xor(lo.x, d, 64)), lo.y = fmin(lo.y, __shfl_xor(lo.y, d, 64)), lo.z = fmin(lo.z, __shfl_xor(lo.z, d, 64));
+        hi.x = fmax(hi.x, __shfl_xor(hi.x, d, 64)), hi.y = fmax(hi.y, __shfl_xor(hi.y, d, 64)), hi.z = fmax(hi.z, __shfl_xor(hi.z, d, 64));
+    }
+    if (lane == 0u) {
+        lo.w = hi.w = F(0);
+        boxes[2u * g] = lo;
+        boxes[2u * g + 1u] = hi;
+    }
 }
 
 template <typename F, int ND>
@@ -1090,11 +1148,10 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
         hipLaunchKernelGGL((k_maxabs<F>), dim3(std::min(nblk(n), 1024u)), dim3(256), 0, st, dx.get(), dy.get(), dz.get(), n,
                            ctrl.get());
     }
-    hipLaunchKernelGGL((k_box<F>), dim3(1), dim3(1), 0, st, ctrl.get(), static_cast<F>(box_size_in));
     auto keys_in = dalloc<uint64_t>(n), keys_out = dalloc<uint64_t>(n);
     auto vals_in = dalloc<uint32_t>(n), vals_out = dalloc<uint32_t>(n);
     hipLaunchKernelGGL((k_encode<F, ND>), dim3(nblk(n)), dim3(256), 0, st, dx.get(), dy.get(), dz.get(), n, ctrl.get(),
-                       keys_in.get(), vals_in.get());
+                       static_cast<F>(box_size_in), keys_in.get(), vals_in.get());
     {
         size_t tb = 0;
         RK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys_in.get(), keys_out.get(), vals_in.get(),
@@ -1248,8 +1305,8 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     auto *boxes = static_cast<v4 *>(alloc_buf(RK_BUF_CRIT_BOX, static_cast<size_t>(n_crit) * 2 * sizeof(v4)));
     auto *child_tab = static_cast<uint32_t *>(alloc_buf(RK_BUF_CHILD, static_cast<size_t>(n_int) * 8 * sizeof(uint32_t)));
     RK_HIP(hipMemsetAsync(child_tab, 0, std::max<size_t>(static_cast<size_t>(n_int) * 8 * sizeof(uint32_t), 16), st));
-    hipLaunchKernelGGL((k_crit<F>), dim3(nblk(nn)), dim3(256), 0, st, topo, flags.get(), offs.get(),
-                       static_cast<uint32_t>(nn), static_cast<const v4 *>(p4), crit, boxes);
+    hipLaunchKernelGGL((k_crit<F>), dim3(nblk(nn)), dim3(256), 0, st, topo, flags.get(), offs.get(), static_cast<uint32_t>(nn), crit);
+    hipLaunchKernelGGL((k_crit_boxes<F>), dim3((n_crit + 3u) / 4u), dim3(256), 0, st, crit, n_crit, static_cast<const v4 *>(p4), boxes);
     hipLaunchKernelGGL((k_records<F, ND>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, parent.get(), mask.get(), offs.get(),
                        static_cast<uint32_t>(nn), node_com, node_mac, recs, child_tab);
 
@@ -1459,8 +1516,8 @@ void convert_device(rk_state &s, const void *const parts[4], int64_t nparts, con
     auto *boxes = static_cast<v4 *>(alloc_buf(RK_BUF_CRIT_BOX, static_cast<size_t>(n_crit) * 2 * sizeof(v4)));
     auto *child_tab = static_cast<uint32_t *>(alloc_buf(RK_BUF_CHILD, static_cast<size_t>(n_int) * 8 * sizeof(uint32_t)));
     RK_HIP(hipMemsetAsync(child_tab, 0, std::max<size_t>(static_cast<size_t>(n_int) * 8 * sizeof(uint32_t), 16), st));
-    hipLaunchKernelGGL((k_crit<F>), dim3(nblk(nn)), dim3(256), 0, st, topo, flags.get(), offs.get(), static_cast<uint32_t>(nn),
-                       static_cast<const v4 *>(p4), crit, boxes);
+    hipLaunchKernelGGL((k_crit<F>), dim3(nblk(nn)), dim3(256), 0, st, topo, flags.get(), offs.get(), static_cast<uint32_t>(nn), crit);
+    hipLaunchKernelGGL((k_crit_boxes<F>), dim3((n_crit + 3u) / 4u), dim3(256), 0, st, crit, n_crit, static_cast<const v4 *>(p4), boxes);
     hipLaunchKernelGGL(k_check_tiling, dim3(nblk(n_crit)), dim3(256), 0, st, crit, n_crit, n, ctrl.get());
     hipLaunchKernelGGL((k_records<F, ND>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode.get(), parent.get(), mask.get(), offs.get(),
                        static_cast<uint32_t>(nn), node_com, node_mac, recs, child_tab);
@@ -1504,7 +1561,7 @@ template void convert_device<double, 2>(rk_state &, const void *const[4], int64_
 void touch_build()
 {
     hipFuncAttributes attr{};
-    RK_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&bld::k_box<float>)));
+    RK_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&bld::k_pack_nodes)));
 }
 
 } // namespace rk

@@ -162,6 +162,23 @@ __device__ __forceinline__ unsigned wave_incl_scan(unsigned v)
     return v;
 }
 
+// OR of a value over the 64 lanes (all of them active), returned to every lane: the DPP network of wave_incl_scan().
+__device__ __forceinline__ unsigned wave_reduce_or(unsigned v)
+{
+    const auto step = [](unsigned x, auto ctrl, auto rows) __attribute__((always_inline)) {
+        return static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), decltype(ctrl)::value, decltype(rows)::value,
+                                                                 0xf, false));
+    };
+    using std::integral_constant;
+    v |= step(v, integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{});
+    v |= step(v, integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{});
+    v |= step(v, integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{});
+    v |= step(v, integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{});
+    v |= step(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});
+    v |= step(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});
+    return static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
+}
+
 } // namespace rk
 
 #endif

@@ -115,7 +115,8 @@ for rep in range(3):   # warm and cold block cache alike
         try:
             rakau_amd.State(p[0], p[1], p[2], p[3], a, ncrit=ot.ncrit)
         except ValueError as e:
-            assert "inconsistent" in str(e), (name, str(e))
+            # (the two conversions word some of these differently: "inconsistent ..." / "tree node N has more than 8 children")
+            assert "inconsistent" in str(e) or "children" in str(e), (name, str(e))
         else:
             raise SystemExit("accepted: " + name)
     st = rakau_amd.State(p[0], p[1], p[2], p[3], good, ncrit=ot.ncrit)
