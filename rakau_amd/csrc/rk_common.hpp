@@ -330,7 +330,14 @@ struct rk_state {
     double sup_mac = 0.;
     int64_t sup_b = 0, sup_e = 0; // supergroups [sup_b, sup_e) are valid for sup_mac (empty: nothing cached)
     hipEvent_t sup_ev = nullptr;  // recorded after the last k_super
-    hipStream_t sup_stream = nullptr; // stream of the call that wrote / last used the cached lists
+    // Calls on different streams. The state's scratch (pre-pass lists, launch plans, the cross-check variant's list pool) belongs to
+    // one call at a time; calls on ONE stream are ordered by the stream. A call that arrives on another stream than the previous one
+    // waits -- on the device, hipStreamWaitEvent -- for the event the previous call recorded behind its last launch: ev1 while the
+    // timing events are on (the default), ev_done once the state has seen a stream change with them off. last_stream is only ever
+    // COMPARED (the caller may have destroyed that stream since); last_done names the event that covers the previous call, or null.
+    hipStream_t last_stream = nullptr;
+    bool has_last_stream = false, multi_stream = false;
+    hipEvent_t ev_done = nullptr, last_done = nullptr;
     int super_k = -1;      // -1 = not initialised (read RK_SUPER_K, default 8)
     // Split traversal (variant 4): list pool and control words, sized per call (grown, never shrunk, until the state goes).
     void *sl_idx = nullptr, *sl_next = nullptr, *sl_cnt = nullptr, *sl_ctl = nullptr, *sl_fb = nullptr;
@@ -344,7 +351,6 @@ struct rk_state {
     int64_t sl_extra_hint = 0;          // pool segments (beyond the fixed first ones) the last reports ask for
     uint32_t *sl_host = nullptr;        // pinned mirror of sl_ctl, filled by the report copy of a call
     hipEvent_t sl_rep_ev = nullptr;     // recorded behind that copy
-    hipStream_t sl_stream = nullptr;    // stream of the last split call (a call on another stream waits for it)
     bool sl_used = false;
     struct sl_key {                     // (range, MAC value) of a call
         int64_t p_begin = -1, p_end = -1;

@@ -275,9 +275,11 @@ void stage_trim()
 // Give the tree-dependent device buffers back to the pool (after a device sync: traversal kernels on other
 // streams may still be reading them) and forget everything derived from them. Streams, events and the output /
 // supergroup scratch survive, so that a state can be rebuilt in place every time step.
+void free_retired_plan_buffers_device_idle(); // (launch-plan buffers parked until the device is idle: see build_plan())
 void release_tree(rk_state *s)
 {
     (void)hipDeviceSynchronize();
+    free_retired_plan_buffers_device_idle();
     for (int i = 0; i < RK_NBUF; ++i) {
         rk::pool_free(s->buf[i]);
         s->buf[i] = nullptr;
@@ -854,6 +856,58 @@ bool plan_regions_enabled()
     return on;
 }
 
+// Launch-plan list buffers that nothing refers to any more. A launch still in flight (on a stream this library knows nothing about
+// by then) may be reading one, so they are not handed back to the block cache at once -- rounds 2-4 drained the whole device for
+// every one of them -- but parked here until the device is known to be idle anyway (release_tree(): a rebuild, a destroyed state)
+// or 64 of them (a few hundred KB) have piled up, which costs one drain for all.
+std::mutex g_retired_mtx;
+std::vector<std::pair<int, void *>> g_retired_plan_buffers; // (physical device, buffer)
+// The CURRENT device has just been synchronised: its retired buffers go back to the block cache.
+void free_retired_plan_buffers_device_idle()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        return;
+    }
+    std::vector<void *> mine;
+    {
+        std::lock_guard<std::mutex> lk(g_retired_mtx);
+        auto keep = g_retired_plan_buffers.begin();
+        for (auto &e : g_retired_plan_buffers) {
+            if (e.first == dev) {
+                mine.push_back(e.second);
+            } else {
+                *keep++ = e;
+            }
+        }
+        g_retired_plan_buffers.erase(keep, g_retired_plan_buffers.end());
+    }
+    for (void *b : mine) {
+        rk::pool_free(b);
+    }
+}
+void retire_plan_buffer(int dev, void *b) noexcept
+{
+    size_t n = 0;
+    try {
+        std::lock_guard<std::mutex> lk(g_retired_mtx);
+        g_retired_plan_buffers.emplace_back(dev, b);
+        for (const auto &e : g_retired_plan_buffers) {
+            n += e.first == dev ? 1u : 0u;
+        }
+    } catch (...) {
+        n = 64; // (out of memory for the list itself: the buffer is in it or not; drain either way, then free it)
+    }
+    if (n >= 64) {
+        int prev = 0;
+        (void)hipGetDevice(&prev);
+        (void)hipSetDevice(dev);
+        (void)hipDeviceSynchronize();
+        free_retired_plan_buffers_device_idle();
+        (void)hipSetDevice(prev);
+    }
+}
+
 template <typename F>
 void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64_t g_hi, double mac_value, int mode)
 {
@@ -1012,18 +1066,16 @@ void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64
             (pass == 0 ? s.plan.n_all : (pass == 1 ? s.plan.n_oth : s.plan.n_123)) = static_cast<int64_t>(lists.size()) - first;
         }
     }
-    // The list buffer: a fresh one whenever the current one is too small or is shared with a cached graph (whose kernels
-    // read it on every replay: it is never rewritten); otherwise the current one, once nothing in flight reads it.
-    if (!s.plan.hold || s.plan.hold.use_count() > 1 || s.plan.alloc < static_cast<int64_t>(lists.size())) {
+    // The list buffer: always a fresh one (the block cache makes that cheap), so that nothing in flight -- an earlier call on any
+    // stream, a cached graph captured on the previous plan -- can be reading what the blocking copy below writes, and no wait is
+    // needed here. The buffer it replaces is retired, not freed: see retire_plan_buffer().
+    {
         void *buf = rk::pool_alloc(std::max<size_t>(lists.size(), 1) * sizeof(uint32_t));
-        s.plan.hold = std::shared_ptr<void>(buf, [](void *b) {
-            (void)hipDeviceSynchronize(); // a launch still in flight may be reading it
-            rk::pool_free(b);
-        });
+        int dev = 0;
+        RK_HIP(hipGetDevice(&dev));
+        s.plan.hold = std::shared_ptr<void>(buf, [dev](void *b) { retire_plan_buffer(dev, b); });
         s.plan.d_lists = buf;
         s.plan.alloc = static_cast<int64_t>(lists.size());
-    } else {
-        RK_HIP(hipDeviceSynchronize()); // a previous call may still be reading the old plan
     }
     if (!lists.empty()) {
         RK_HIP(hipMemcpy(s.plan.d_lists, lists.data(), lists.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -1089,11 +1141,7 @@ bool prepare_split(rk_state &s, rk::kparams<F> &p, int64_t p_begin, int64_t p_en
         RK_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.sl_host), 8 * sizeof(uint32_t), hipHostMallocDefault));
         std::fill(s.sl_host, s.sl_host + 8, 0u);
     }
-    // A call on another stream must not overwrite lists an earlier call may still be reading.
-    if (s.sl_used && s.sl_stream != stream) {
-        RK_HIP(hipDeviceSynchronize()); // (sl_stream is only compared: the caller may have destroyed that stream)
-    }
-    s.sl_stream = stream;
+    // (A call on another stream than the previous one has already been ordered behind it: order_after_previous_call().)
     s.sl_used = true;
     if (s.sl_rep_pending && hipEventQuery(s.sl_rep_ev) == hipSuccess) {
         s.sl_rep_pending = false;
@@ -1240,7 +1288,25 @@ void ensure_call_resources(rk_state &s)
     }
     if (!s.sup_ev) {
         RK_HIP(hipEventCreateWithFlags(&s.sup_ev, hipEventDisableTiming));
+        RK_HIP(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
     }
+}
+
+// A call on another stream than the state's previous one: everything that call enqueued must be finished before this one touches
+// the state's scratch. Waits on the device for the event recorded behind the previous call (rk_common.hpp, last_done); only a
+// state whose previous call recorded none -- timing events off and no stream change seen before -- drains the device, once.
+void order_after_previous_call(rk_state &s, hipStream_t stream)
+{
+    if (s.has_last_stream && s.last_stream != stream) {
+        if (s.last_done) {
+            RK_HIP(hipStreamWaitEvent(stream, s.last_done, 0));
+        } else {
+            RK_HIP(hipDeviceSynchronize());
+        }
+        s.multi_stream = true;
+    }
+    s.last_stream = stream;
+    s.has_last_stream = true;
 }
 
 void ensure_call_resources_any(rk_state &s)
@@ -1366,6 +1432,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
     }
 #endif
     ensure_call_resources<F>(s);
+    order_after_previous_call(s, stream);
     // allow_graph is false on the host-output path, which waits on ev1 for completion.
     const bool need_done_event = !allow_graph;
     if (s.timing && !s.keep_ev0) {
@@ -1487,23 +1554,12 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
         const int64_t sb = (p.super_k && g_hi > g_lo) ? g_lo / s.super_k : 0,
                       se = (p.super_k && g_hi > g_lo) ? (g_hi - 1) / s.super_k + 1 : 0;
         const bool sup_cache = super_cache_enabled();
-        if (s.sup_e > s.sup_b && s.sup_stream != stream) {
-            // The cached pre-pass output was written (or is being read) on another stream: wait for it here, and never
-            // extend it from two streams (an extending pre-pass may rewrite supergroups the other stream's kernels are still
-            // reading). sup_stream is only ever COMPARED -- the caller may have destroyed that stream since --: the wait is
-            // for the whole device. (An event of the state's own recorded after every call, waited on asynchronously when the
-            // stream changes, would not block the host here; it would cost EVERY call of a one-stream caller a barrier packet
-            // -- ~10 us on the GPU, 10 % of a 100k-particle call -- to spare callers that alternate streams a wait they need
-            // only when they do.)
-            RK_HIP(hipDeviceSynchronize());
-        }
+        // (The cached pre-pass output may have been written, or be in use, on another stream: order_after_previous_call() has
+        // put this call behind the previous one in that case, so it may reuse or extend the lists.)
         // Variant 4 (and the automatic variant unless RK_SPLIT=0): list building and dense evaluation as two kernels.
         const bool split = g_hi > g_lo && (s.variant == 4 || (s.variant == 0 && split_default()));
         const bool need_super = se > sb && !(sup_cache && s.sup_mac == mac_value && s.sup_b <= sb && se <= s.sup_e);
         ran_super = need_super;
-        if (se > sb) {
-            s.sup_stream = stream;
-        }
         bool split_fb = false;
         if (split) {
             split_fb = prepare_split<F>(s, p, p_begin, p_end, g_lo, g_hi, mac_value, stream);
@@ -1883,6 +1939,12 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
     // timing events only if wanted (rk_state_set_timing), the completion event only where something waits on it.
     if (s.timing || need_done_event) {
         RK_HIP(hipEventRecord(s.ev1, stream));
+        s.last_done = s.ev1;
+    } else if (s.multi_stream) {
+        RK_HIP(hipEventRecord(s.ev_done, stream)); // (3 us per call, only for callers that do change streams)
+        s.last_done = s.ev_done;
+    } else {
+        s.last_done = nullptr;
     }
     s.timed = s.timing;
 }

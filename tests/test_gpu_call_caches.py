@@ -136,3 +136,48 @@ def test_graph_cache_keeps_replay_for_recurring_signatures(name, extra, nsig):
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_graph_recurring.py"), "1500", str(nsig)],
                          capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert out.returncode == 0 and "graph cache stress ok" in out.stdout, name + "\n" + out.stdout[-2000:] + out.stderr[-6000:]
+
+
+@pytest.mark.parametrize("timing", [True, False])
+def test_alternating_streams_wait_for_each_other_not_for_the_device(timing):
+    """VERDICT r04 item 5. One state, 100 calls alternating between two streams, while a THIRD stream is busy with a kernel that
+    runs for about a second. Rounds 2-4 drained the whole device (hipDeviceSynchronize) at every stream change, i.e. every call
+    waited for that kernel; now a call on another stream waits, on the device, for the event behind the state's previous call
+    only. Checked: the 100 calls finish long before the busy stream does, and every result equals the one-stream result bit for
+    bit (the calls share the state's pre-pass lists and launch plan: an ordering bug shows up as different bits). With the
+    timing events off the state has no event behind its first call, so its FIRST stream change drains the device once -- the
+    busy kernel is therefore started after that change in that case."""
+    import time
+    import torch
+    m, x, y, z = oracle.plummer(60000, np.float32)
+    st = rakau_amd.Octree(x, y, z, m).state()
+    mv = rakau_amd.mac_value_of(0.75, "bh", np.float32)
+    n = st.nparts
+    ref = [torch.zeros(n, dtype=torch.float32, device="cuda") for _ in range(3)]
+    st.acc_pot_device(0, mv, [o.data_ptr() for o in ref])
+    torch.cuda.synchronize()
+    st.set_timing(timing)
+    s = [torch.cuda.Stream(), torch.cuda.Stream()]
+    busy = torch.cuda.Stream()
+    outs = [[torch.zeros(n, dtype=torch.float32, device="cuda") for _ in range(3)] for _ in range(2)]
+    # two calls first: every stream has been seen, the plan of this signature exists
+    for k in range(2):
+        st.acc_pot_device(0, mv, [o.data_ptr() for o in outs[k]], stream=s[k].cuda_stream)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(busy):
+        t_busy0 = time.perf_counter()
+        torch.cuda._sleep(int(2.0e9))  # ~1 s of spinning at ~2 GHz
+    t0 = time.perf_counter()
+    for it in range(100):
+        k = it & 1
+        st.acc_pot_device(0, mv, [o.data_ptr() for o in outs[k]], stream=s[k].cuda_stream)
+    s[0].synchronize()
+    s[1].synchronize()
+    t_calls = time.perf_counter() - t0
+    still_busy = not busy.query()
+    busy.synchronize()
+    t_busy = time.perf_counter() - t_busy0
+    assert still_busy and t_calls < 0.5 * t_busy, (t_calls, t_busy, still_busy)
+    for k in range(2):
+        for a, b in zip(outs[k], ref):
+            assert torch.equal(a, b)

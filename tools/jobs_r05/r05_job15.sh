@@ -4,9 +4,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $ROOT
 O=$ROOT/gpurun_out/r05_job15
 mkdir -p $O
-timeout 300 python3 -m pytest tests/test_gpu_state_create.py -x -q -k "no_parent" 2>&1 | tail -30 | tee $O/pytest.txt
 cd /tmp && export TMPDIR=/tmp
-for n in 4000000; do
+for n in 100000 4000000; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$n -o p -- $ROOT/examples/leapfrog --nparts $n --steps 40 --warmup 5 > $O/prof_$n.log 2>&1
   f=$(find $O/prof_$n -name "*kernel_stats.csv" | head -1)
   echo "== $n"; python3 - "$f" <<'PY' | tee $O/kernels_$n.txt
