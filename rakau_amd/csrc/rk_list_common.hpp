@@ -12,7 +12,7 @@
 #define RK_UNR1 4 // sources in flight per lane in the dense loop, R = 1
 #endif
 #ifndef RK_UNR2
-#define RK_UNR2 2 // R = 2
+#define RK_UNR2 1 // R = 2 (round 5, at 8 waves per SIMD: 1M 0.593 -> 0.584 ms, 4M -0.2 %; rounds 1-4: 2)
 #endif
 #ifndef RK_UNR3
 #define RK_UNR3 1 // R = 3
@@ -66,10 +66,12 @@
 #define RK_W3 6 // R = 3
 #endif
 #ifndef RK_W4
-#define RK_W4 5 // R = 4
+#define RK_W4 6 // R = 4 (round 5: 80 VGPRs, 36 bytes of scratch: 4M 2.189 -> 2.156 ms over four alternating rounds,
+                // tools/jobs_r05/r05_job19.sh; rounds 1-4: 5)
 #endif
 #ifndef RK_WANY
-#define RK_WANY RK_W4 // k_list_any (one launch over all classes): the waves per SIMD of its largest R
+#define RK_WANY 5 // k_list_any (one launch over all classes), compiled for the registers of its largest R at 5 waves per SIMD (6: 1M
+                  // 0.596 -> 0.576 ms but 350k 0.224 -> 0.236, shards of the 4M tree equal: tools/jobs_r05/r05_job12.sh, _job18)
 #endif
 #ifndef RK_W5
 #define RK_W5 4 // R = 5
