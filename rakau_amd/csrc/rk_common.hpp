@@ -313,7 +313,6 @@ struct rk_state {
         // Heavy-first plans also carry merged lists for the one-launch kernels (k_pc_any / k_list_any): the wave-kernel
         // classes together, and without the R = 2 class (which then keeps its own producer / consumer launch).
         int64_t off_all = 0, n_all = 0, off_oth = 0, n_oth = 0, off_123 = 0, n_123 = 0;
-        bool all_padded = false; // the merged list is a light-tail arrangement (interleaved per-XCD queues with padding)
     } plan;
     std::vector<launch_plan> gcache_plan; // gcache_plan[i]: the plan gcache[i] was captured with (d_lists null: none)
     std::vector<launch_plan> plans;       // the last few plans built (most recent last): a caller alternating among ranges --

@@ -191,20 +191,12 @@ __device__ __forceinline__ unsigned xcd_chunked_block(unsigned b, unsigned nb)
 // mode 0: XCD x walks chunks x, x + 8, x + 16, ... of XCD_CHUNK consecutive blocks (L2 locality inside a
 // chunk, work spread evenly over the XCDs whatever the spatial variation of the group costs);
 // mode 1: one contiguous slice per XCD; mode 2: identity (hardware round-robin: block i on XCD i % 8; the light-tail launch
-// plan of rk_state.hip lays its list out for this);
-// modes 3, 4: mode 1 with the slice walked from both ends alternately (3) or backwards (4) -- experiments on where
-// the expensive groups of a centrally condensed system end up in the dispatch order.
+// plan of rk_state.hip lays its list out for this).
 constexpr unsigned XCD_CHUNK = 16;
 __device__ __forceinline__ unsigned xcd_map_block(unsigned b, unsigned nb, int mode)
 {
     if (mode == 2) {
         return b;
-    }
-    if (mode == 3 || mode == 4) {
-        const unsigned q = nb >> 3, r = nb & 7u, xcd = b & 7u, pos = b >> 3;
-        const unsigned len = xcd < r ? q + 1u : q, base = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
-        const unsigned p = mode == 4 ? len - 1u - pos : ((pos & 1u) ? len - 1u - (pos >> 1) : (pos >> 1));
-        return base + p;
     }
     if (mode == 1) {
         return xcd_chunked_block(b, nb);

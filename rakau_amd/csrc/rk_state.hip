@@ -932,11 +932,7 @@ void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64
     auto arrange_light_tail = [&](const std::ptrdiff_t first) {
 
             // Morton order, the lightest quarter of the nodes moved to the end (in Morton order among themselves).
-            static const double tail_frac = [] {
-                const char *e = std::getenv("RK_PLAN_TAIL"); // fraction of the nodes dispatched last (0 = none)
-                const double v = e ? std::atof(e) : 0.25;
-                return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
-            }();
+            constexpr double tail_frac = 0.25; // (2, 4 or 8 work quantiles instead: no better, tools/archive_r02/r02_job45.sh)
             std::vector<uint64_t> w;
             w.reserve(lists.size() - static_cast<size_t>(first));
             for (auto it = lists.begin() + first; it != lists.end(); ++it) {
@@ -1012,7 +1008,6 @@ void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64
     }
     s.plan.off[rk::n_classes] = static_cast<int64_t>(lists.size());
     s.plan.off_all = s.plan.n_all = s.plan.off_oth = s.plan.n_oth = s.plan.off_123 = s.plan.n_123 = 0;
-    s.plan.all_padded = !lpt && !rev;
     if (rev) {
         const auto first = static_cast<std::ptrdiff_t>(lists.size());
         for (int c = RK_MAX_R - 1; c >= 0; --c) {
@@ -1021,31 +1016,6 @@ void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64
         }
         s.plan.off_all = first;
         s.plan.n_all = static_cast<int64_t>(lists.size()) - first;
-    }
-    if (!lpt && !rev) {
-        // One list of all wave-kernel classes in the light-tail arrangement (experiment: RK_ANY_TAIL=1 runs k_list_any on it.
-        // Measured: 4M 2.288 instead of 2.238 ms, 2M equal -- on a full device the occupancy the single kernel gives up
-        // (5 waves per SIMD for every class) costs more than the staggered starts of four class kernels; off by default).
-        static const bool any_tail = [] {
-            const char *e = std::getenv("RK_ANY_TAIL");
-            return e && std::atoi(e) != 0;
-        }();
-        if (any_tail) {
-            std::vector<uint32_t> merged;
-            for (int c = 0; c < RK_MAX_R; ++c) {
-                const auto &l = s.class2_list[c];
-                merged.insert(merged.end(), std::lower_bound(l.begin(), l.end(), static_cast<uint32_t>(g_lo)),
-                              std::lower_bound(l.begin(), l.end(), static_cast<uint32_t>(g_hi)));
-            }
-            std::sort(merged.begin(), merged.end());
-            const auto first = static_cast<std::ptrdiff_t>(lists.size());
-            lists.insert(lists.end(), merged.begin(), merged.end());
-            if (merged.size() > 1u) {
-                arrange_light_tail(first);
-            }
-            s.plan.off_all = first;
-            s.plan.n_all = static_cast<int64_t>(lists.size()) - first;
-        }
     }
     if (lpt) {
         // Merged heavy-first lists over the wave-kernel classes (stable: equal weights keep class, then Morton order): all
@@ -1360,11 +1330,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
     }
     p.dbg = nullptr;
     {
-        static const int xcd_mode = [] {
-            const char *e = std::getenv("RK_XCD_MODE"); // experiment knob; default 1 (contiguous slice per XCD)
-            return e ? std::atoi(e) : 1;
-        }();
-        p.xcd_mode = xcd_mode;
+        p.xcd_mode = 1; // a contiguous slice of the list per XCD (launch plans choose their own mapping below)
         p.any_rev = 0;
     }
 #ifdef RK_STAMPS
@@ -1570,32 +1536,14 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
         // consumer kernel (1 + R waves per node): all of them below 5 000 critical nodes, the class with the longest
         // chains (R = 2: 64 < T <= 128 targets on one wave) below 20 000. Both kernels give the same bits, so this is
         // a pure scheduling decision (measured: tools/archive_r02/r02_job11.sh, r02_job12.sh).
-        static const int64_t pc_all_below = [] {
-            const char *e = std::getenv("RK_PC_ALL_BELOW");
-            return e ? std::atoll(e) : int64_t(5000);
-        }();
-        static const int64_t pc_r2_below = [] {
-            const char *e = std::getenv("RK_PC_R2_BELOW");
-            return e ? std::atoll(e) : int64_t(20000);
-        }();
-        static const int pc_mask_env = [] {
-            const char *e = std::getenv("RK_PC_MASK"); // experiment knob: bit c = class R = c + 1 on the P/C kernel
-            return e ? std::atoi(e) : -1;
-        }();
+        constexpr int64_t pc_all_below = 5000, pc_r2_below = 20000;
         unsigned pc_mask = 0u;
         if (s.variant == 3) {
-            pc_mask = pc_mask_env >= 0 ? static_cast<unsigned>(pc_mask_env) & 0xfu : 0xfu;
+            pc_mask = 0xfu;
         } else if (s.variant == 0) {
             const int64_t ng = g_hi - g_lo;
             pc_mask = ng <= pc_all_below ? 0xfu : (ng <= pc_r2_below ? 0x2u : 0u);
         }
-        // Order in which the class kernels are handed to the GPU. The dispatcher serves the queues roughly in launch
-        // order until the device is full, so the classes launched last start late, and their longest nodes end the
-        // call: RK_CLASS_ORDER (e.g. "4312": R = 4 first) overrides the default.
-        static const std::string class_order = [] {
-            const char *e = std::getenv("RK_CLASS_ORDER");
-            return std::string(e ? e : "");
-        }();
         // 0: per-class launches; 1: k_pc_any; 2: k_pc for R = 2 + k_list_any for the rest; 3: k_list_any (heavy-first plans
         // only, i.e. repeated calls over at most RK_PLAN_MAX_GROUPS critical nodes; RK_ANY=0 keeps the class launches).
         static const int any_env = [] {
@@ -1604,7 +1552,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
         }();
         int any_mode = 0;
         if (!split && s.variant == 0 && any_env != 0 && s.cur_lists == static_cast<const uint32_t *>(s.plan.d_lists)
-            && s.plan.n_all > 0 && (s.plan.all_padded || s.plan.n_all == g_hi - g_lo - (big_e - big_b))) {
+            && s.plan.n_all > 0 && s.plan.n_all == g_hi - g_lo - (big_e - big_b)) {
             // Measured (tools/any_probe.py, profiles/r03/one_launch_kernels.txt): k_pc_any at 2.9k nodes 0.134 ms (class
             // launches 0.140, k_list_any 0.173); k_list_any at 9.4k nodes 0.23 (0.29-0.30; with R = 2 on k_pc 0.27), on the
             // 13.4k-node shards of the 4M tree 0.373-0.379 (0.406-0.412; 0.40), at 26k nodes 0.62 (0.66).
@@ -1616,9 +1564,6 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
             // their place -- queued calls, ms: 3.6k nodes 0.167, k_pc_any 0.155, k_list_any 0.177; 3.9k: 0.275 / 0.178 / 0.181;
             // 4.5k: 0.202 / 0.202 / 0.186; 5.1k: 0.335 / 0.230 / 0.192 -- tools/any_probe3.py.)
             any_mode = any_env > 0 ? any_env : (g_hi - g_lo <= pc_any_below ? 1 : 3);
-            if (s.plan.all_padded) {
-                any_mode = 3; // the merged light-tail list (RK_ANY_TAIL=1)
-            }
         }
         // A small call WITHOUT a plan (the first call on a tree: every step of a time-stepping loop) that covers all critical
         // nodes: one launch too, over the state's own class lists read backwards -- R = 4 first, the lightest class last, which
@@ -1634,8 +1579,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                 // First calls, ms (tools/first_call_probe.py, Plummer; class launches -> this): 100k 0.191 -> 0.178, 350k
                 // 0.488 -> 0.360, 1M 0.83 -> 0.76, 1.8M (47.6k nodes) 1.51 -> 1.25; leapfrog harness 100k 0.187 -> 0.166,
                 // 2M (~50k nodes) 1.082 -> 1.069; beyond, the class kernels with a Morton slice per XCD win: 4M 1.97 vs 2.05.
-                const char *e = std::getenv("RK_ANY_FIRST_MAX");
-                return e ? std::atoll(e) : int64_t(60000);
+                return int64_t(60000);
             }();
             const int64_t n_wave = s.class2_off[RK_MAX_R] - s.class2_off[0];
             if (any_first && any_mode == 0 && !split && s.variant == 0 && any_env != 0
@@ -1706,24 +1650,6 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                 } else {
                     rk::launch_list_any<F>(s, q, p, pl + s.plan.off_all, s.plan.n_all, streams[0]);
                 }
-            } else if (!class_order.empty()) {
-                unsigned done_mask = 0u;
-                for (const char ch : class_order) {
-                    const int c = ch - '1';
-                    if (c < 0 || c >= RK_MAX_R || ((done_mask >> c) & 1u)) {
-                        continue;
-                    }
-                    done_mask |= 1u << c;
-                    if ((pc_mask >> c) & 1u) {
-                        rk::launch_pc<F>(s, q, p, cb, ce, streams, 1u << c);
-                    } else {
-                        rk::launch_list<F>(s, q, p, cb, ce, streams, 1u << c);
-                    }
-                }
-                if (pc_mask & ~done_mask) {
-                    rk::launch_pc<F>(s, q, p, cb, ce, streams, pc_mask & ~done_mask);
-                }
-                rk::launch_list<F>(s, q, p, cb, ce, streams, ~pc_mask & ~done_mask);
             } else {
                 if (pc_mask) {
                     rk::launch_pc<F>(s, q, p, cb, ce, streams, pc_mask);

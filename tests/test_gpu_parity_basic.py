@@ -15,7 +15,9 @@ pytestmark = pytest.mark.gpu
 # fp64 <= 2e-11 (test/ordering_acc.cpp:94); identical lists deliver far better, so a tighter regression
 # bound is asserted (~1e-7 median, < 1e-5 max in fp32).
 TIGHT = {np.float32: 2e-5, np.float64: 1e-12}
-VARIANTS = [1, 2, 3, 4]
+# 0 = the automatic variant (what every caller gets: list kernel / producer-consumer kernel / one-launch forms chosen per call),
+# 1 = scalar walk (cross-check library), 2 = list kernel, 3 = producer / consumer kernel, 4 = split traversal (cross-check library).
+VARIANTS = [0, 1, 2, 3, 4]
 
 
 def check(got, ref, q, dtype, tol=None, ndim=3):
