@@ -561,17 +561,34 @@ __device__ __forceinline__ void list_node(const kparams<F> &P, lk_wave_lds<F> &L
             }
         }
         if (lane_on && sp_raw == 0) {
+            // Nothing but stores once the output positions are known. (With the look-up of the ordered form inside the loop,
+            // rounds 1-4, every target's stores waited -- s_waitcnt vmcnt(0) -- for the stores of the target before: a round trip
+            // to the caller's HOST array per target when the results cross PCIe, 0.1 ms of the 4M seam call.)
+            auto store_all = [&](auto pos) __attribute__((always_inline)) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                if (tidx[r] >= 0) {
-                    const uint32_t o = out_index(P, tb + static_cast<uint32_t>(tidx[r]));
+                for (int r = 0; r < R; ++r) {
+                    if (tidx[r] >= 0) {
+                        const uint32_t o = pos(r);
 #pragma unroll
-                    for (int k = 0; k < NR; ++k) {
-                        if (ND == 3 || Q == 1 || k != 2) { // a quadtree has no z acceleration (and no array for it)
-                            P.out[k][o] = tg.get(r, k) * G;
+                        for (int k = 0; k < NR; ++k) {
+                            if (ND == 3 || Q == 1 || k != 2) { // a quadtree has no z acceleration (and no array for it)
+                                P.out[k][o] = tg.get(r, k) * G;
+                            }
                         }
                     }
                 }
+            };
+            if (P.perm) {
+                // Original-order output: all look-ups through the permutation first, one wait, then the stores.
+                uint32_t o[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    o[r] = P.perm[tb + static_cast<uint32_t>(tidx[r] >= 0 ? tidx[r] : 0)];
+                }
+                __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+                store_all([&](int r) { return o[r]; });
+            } else {
+                store_all([&](int r) { return tb + static_cast<uint32_t>(tidx[r]) - P.out_sub; });
             }
         }
         RK_STAMP(7)

@@ -236,17 +236,31 @@ __device__ __forceinline__ void pc_node(const kparams<F> &P, pc_lds<F> &L, const
             // ---- scale by G, write out ----
             if (lane_on && sp_raw == 0) {
                 const F G = P.G;
+                // (nothing but stores once the positions are known: see the list kernel's epilogue)
+                auto store_all = [&](auto pos) __attribute__((always_inline)) {
 #pragma unroll
-                for (int j = 0; j < CR; ++j) {
-                    if (tidx[j] >= 0) {
-                        const uint32_t o = out_index(P, tb + static_cast<uint32_t>(tidx[j]));
+                    for (int j = 0; j < CR; ++j) {
+                        if (tidx[j] >= 0) {
+                            const uint32_t o = pos(j);
 #pragma unroll
-                        for (int k = 0; k < NR; ++k) {
-                            if (ND == 3 || Q == 1 || k != 2) { // a quadtree has no z acceleration (and no array for it)
-                                P.out[k][o] = tg.get(j, k) * G;
+                            for (int k = 0; k < NR; ++k) {
+                                if (ND == 3 || Q == 1 || k != 2) { // a quadtree has no z acceleration (and no array for it)
+                                    P.out[k][o] = tg.get(j, k) * G;
+                                }
                             }
                         }
                     }
+                };
+                if (P.perm) {
+                    uint32_t o[CR];
+#pragma unroll
+                    for (int j = 0; j < CR; ++j) {
+                        o[j] = P.perm[tb + static_cast<uint32_t>(tidx[j] >= 0 ? tidx[j] : 0)];
+                    }
+                    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+                    store_all([&](int j) { return o[j]; });
+                } else {
+                    store_all([&](int j) { return tb + static_cast<uint32_t>(tidx[j]) - P.out_sub; });
                 }
             }
         };
