@@ -319,6 +319,7 @@ struct rk_state {
                                           // the two parts of a staged host-output call -- does not rebuild them
     hipEvent_t ev_mid = nullptr;          // end of the first part of a two-part host-output call
     hipEvent_t ev_arr[4] = {};            // ordered host outputs: result array k has arrived in the staging buffer
+    bool want_done_event = false;         // blocking host-output call: ev1 is recorded whatever the timing setting
     bool keep_ev0 = false;                // second part of such a call: the timing start event stays where the first part put it
     std::vector<uint64_t> work_cache; // launch-plan weight of every critical node (its size; empty: not computed)
     // Scratch of the supergroup pre-pass (allocated on first use).

@@ -1400,7 +1400,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
     ensure_call_resources<F>(s);
     order_after_previous_call(s, stream);
     // allow_graph is false on the host-output path, which waits on ev1 for completion.
-    const bool need_done_event = !allow_graph;
+    const bool need_done_event = !allow_graph || s.want_done_event;
     if (s.timing && !s.keep_ev0) {
         RK_HIP(hipEventRecord(s.ev0, stream));
     }
@@ -1761,6 +1761,11 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                 ++s.graph_stats[2];
             } else {
                 hipGraph_t graph = nullptr;
+                // One capture at a time in the process: since round 5 the blocking host-output call captures too, and the device
+                // threads of a multi-device split make such calls side by side (captures are rare -- once per signature -- so the
+                // lock costs nothing; concurrent captures on logical devices that alias one GPU failed intermittently in round 4).
+                static std::mutex capture_mtx;
+                std::lock_guard<std::mutex> capture_lock(capture_mtx);
                 RK_HIP(hipStreamBeginCapture(s.cap_stream, hipStreamCaptureModeThreadLocal));
                 try {
                     enqueue(s.cap_stream, true);
@@ -2486,11 +2491,29 @@ int rk_acc_pot(rk_state *s, int q, int64_t p_begin, int64_t p_end, void *const *
                 all = v_ptrs[k] != nullptr;
             }
             if (all) {
-                if (s->fp == RK_F32) {
-                    run_impl<float>(*s, q, p_begin, p_end, v_ptrs, mac_value, G, eps2, 0, nullptr, false);
-                } else {
-                    run_impl<double>(*s, q, p_begin, p_end, v_ptrs, mac_value, G, eps2, 0, nullptr, false);
+                // Repeated calls are replayed from a hipGraph like device-output calls (round 5). The four class kernels of a large
+                // call then sit in ONE queue and share the device as the replayed device-output step does; launched directly on four
+                // streams, the R <= 2 kernels (8 waves per SIMD, short waves) take most of the slots first and end at 1.3 ms of a
+                // 2.2 ms step, which leaves the R = 3 / 4 kernels to run among themselves at 6 waves per SIMD and the R = 3 kernel
+                // alone for the last 0.2 ms (tools/seam_timeline.py): 4M 2.303 -> 2.234 ms per call, 1737 -> 1790 Mparticles/s
+                // (tools/jobs_r05/r05_job24.sh; round 4 measured the replay 0.01 ms SLOWER: the kernels were 4 % slower then and
+                // better balanced at 7/7/6/5 waves per SIMD). RK_HOST_GRAPH=0: direct launches.
+                static const bool host_graph = [] {
+                    const char *e = std::getenv("RK_HOST_GRAPH");
+                    return !(e && std::atoi(e) == 0);
+                }();
+                s->want_done_event = true;
+                try {
+                    if (s->fp == RK_F32) {
+                        run_impl<float>(*s, q, p_begin, p_end, v_ptrs, mac_value, G, eps2, 0, nullptr, host_graph);
+                    } else {
+                        run_impl<double>(*s, q, p_begin, p_end, v_ptrs, mac_value, G, eps2, 0, nullptr, host_graph);
+                    }
+                } catch (...) {
+                    s->want_done_event = false;
+                    throw;
                 }
+                s->want_done_event = false;
                 RK_HIP(hipEventSynchronize(s->ev1));
                 return;
             }

@@ -7,7 +7,7 @@
 #  * PMC passes (separate --pmc runs, no tracing domains) and the HBM traffic of one step.
 # usage (through gpurun): tools/collect_profiles.sh <tag>
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
