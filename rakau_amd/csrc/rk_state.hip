@@ -2685,12 +2685,24 @@ int rk_acc_pot(rk_state *s, int q, int64_t p_begin, int64_t p_end, void *const *
                 stream_copy(dst[k] + off, stage + k * arr + off, nb);
             });
         };
+        // (replayed from a hipGraph when the call recurs, like the pinned-output call above: RK_HOST_GRAPH)
+        static const bool staged_graph = [] {
+            const char *e = std::getenv("RK_HOST_GRAPH");
+            return !(e && std::atoi(e) == 0);
+        }();
         auto run = [&](int64_t b, int64_t e, void *const *ptrs) {
-            if (s->fp == RK_F32) {
-                run_impl<float>(*s, q, b, e, ptrs, mac_value, G, eps2, 0, nullptr, false);
-            } else {
-                run_impl<double>(*s, q, b, e, ptrs, mac_value, G, eps2, 0, nullptr, false);
+            s->want_done_event = true;
+            try {
+                if (s->fp == RK_F32) {
+                    run_impl<float>(*s, q, b, e, ptrs, mac_value, G, eps2, 0, nullptr, staged_graph);
+                } else {
+                    run_impl<double>(*s, q, b, e, ptrs, mac_value, G, eps2, 0, nullptr, staged_graph);
+                }
+            } catch (...) {
+                s->want_done_event = false;
+                throw;
             }
+            s->want_done_event = false;
         };
         // Two parts (round 4): the first RK_HOST_SPLIT (0.85) of the range is traversed first and DELIVERED by the host threads
         // while the second part is traversed; only the second part's delivery is left when the kernels end. The cut is a
