@@ -850,13 +850,17 @@ static void launch_list_qm(const rk_state &s, const kparams<F> &p, const int64_t
 #if RK_MAX_R >= 5
     go(std::integral_constant<int, 5>{}, 4); // (R = 5, 6: measured slower, only built when RK_MAX_R asks for them)
 #endif
+    // Order in which the class kernels are handed to the runtime. Replayed from a graph they share one queue, and the kernel
+    // handed over first is served first as slots free up: the R = 3 kernel, which ends last, must lead (round 5, 4M device-resident
+    // kernel ms over two boxes: 3-1-2-4 (rounds 1-4) 2.15-2.17, 3-4-1-2 2.14-2.16, 3-2-4-1 2.15-2.16, 3-4-2-1 / 3-1-4-2 2.17;
+    // with R = 1 or R = 4 first -- 1-2-3-4, 4-3-2-1, 4-3-1-2, 1-3-4-2 -- 2.21-2.24: tools/jobs_r05/r05_job27.sh, _job28).
     go(std::integral_constant<int, 3>{}, 2);
+    go(std::integral_constant<int, 4>{}, 3);
     go(std::integral_constant<int, 1>{}, 0);
     go(std::integral_constant<int, 2>{}, 1);
 #if RK_MAX_R >= 6
     go(std::integral_constant<int, 6>{}, 5);
 #endif
-    go(std::integral_constant<int, 4>{}, 3);
     for (int c = RK_MAX_R; c < big_class; ++c) {
         if (ce[c] != cb[c] && ((class_mask >> c) & 1u)) {
             throw error(RK_ERUNTIME, "internal error: target group in a lane-mapping class beyond RK_MAX_R");
