@@ -327,9 +327,19 @@ __device__ __forceinline__ void pc_node(const kparams<F> &P, pc_lds<F> &L, const
     // Hand the current tile to the consumers and take the other buffer (which they have finished with once they
     // arrive at this barrier).
     [[maybe_unused]] uint32_t n_pub = 0;
-    auto publish = [&](bool last) __attribute__((always_inline)) {
+    // `whole`: the consumers evaluate everything in the tile (masked remainder step); otherwise -- as in the list kernel's
+    // flush(false) with RK_CARRY_REMAINDER -- only whole rounds of NS sources are handed over and the fewer than NS left over
+    // open the next tile: the same tile contents as the list kernel's, hence the same bits.
+    const int inv_ns_p = (65536 + NS - 1) / NS;
+    auto publish = [&](bool last, bool whole) __attribute__((always_inline)) {
+        int n_out = n_src, left = 0;
+        if (RK_CARRY_REMAINDER && !whole && !last) {
+            n_out = ((n_src * inv_ns_p) >> 16) * NS;
+            left = n_src - n_out;
+        }
+        const int from = cur;
         if (lane == 0) {
-            L.tile_n[cur] = static_cast<uint32_t>(n_src) | (last ? PC_LAST : 0u);
+            L.tile_n[cur] = static_cast<uint32_t>(n_out) | (last ? PC_LAST : 0u);
         }
         if constexpr (NB == 2) {
             __syncthreads();
@@ -346,13 +356,20 @@ __device__ __forceinline__ void pc_node(const kparams<F> &P, pc_lds<F> &L, const
             }
         }
         src = L.tile[cur];
-        n_src = 0;
+        if (left > 0) {
+            // (the buffer just handed over is only read by the consumers; the one taken is free: see the waits above)
+            if (lane < left) {
+                src[lane] = L.tile[from][n_out + lane];
+            }
+            wave_sync();
+        }
+        n_src = left;
     };
     // The list kernel evaluates a tile as soon as another batch (up to 64 sources) might not fit; so does this one
     // (identical tile boundaries).
-    auto flush = [&]() __attribute__((always_inline)) {
+    auto flush = [&](bool whole) __attribute__((always_inline)) {
         if (n_src > 0) {
-            publish(false);
+            publish(false, whole);
         }
     };
 
@@ -371,7 +388,7 @@ __device__ __forceinline__ void pc_node(const kparams<F> &P, pc_lds<F> &L, const
             const int m = __builtin_popcountll(m_fit); // leaves [0, m) fit (prefix property)
             if (m == 0) {
                 if (n_src > 0) {
-                    flush();
+                    flush(true); // everything, so that the tile really is empty afterwards
                     continue;
                 }
                 // A single leaf larger than the whole tile: take TILE_CAP of its particles.
@@ -384,7 +401,7 @@ __device__ __forceinline__ void pc_node(const kparams<F> &P, pc_lds<F> &L, const
                 }
                 n_src = TILE_CAP;
                 wave_sync();
-                flush();
+                flush(true);
                 continue;
             }
             // Lane l copies the particles of leaf l, eight loads in flight at a time.
@@ -422,7 +439,7 @@ __device__ __forceinline__ void pc_node(const kparams<F> &P, pc_lds<F> &L, const
             }
             n_lq = tail;
             if (n_src + 64 > TILE_CAP) {
-                flush();
+                flush(false);
             }
         }
     };
@@ -598,7 +615,7 @@ __device__ __forceinline__ void pc_node(const kparams<F> &P, pc_lds<F> &L, const
             base += take;
             wave_sync();
             if (n_src == TILE_CAP) {
-                flush();
+                flush(false);
             }
         }
     }
@@ -632,7 +649,7 @@ __device__ __forceinline__ void pc_node(const kparams<F> &P, pc_lds<F> &L, const
                 break;
             }
             if (n_src + 64 > TILE_CAP) {
-                flush();
+                flush(false);
             }
             if (n_uq >= 64) {
                 process_exact();
@@ -657,7 +674,7 @@ __device__ __forceinline__ void pc_node(const kparams<F> &P, pc_lds<F> &L, const
             process(A);
         }
     }
-    publish(true);
+    publish(true, true);
 }
 
 template <typename F, int Q, int MAC, int R, int ND>

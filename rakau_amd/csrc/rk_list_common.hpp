@@ -27,8 +27,10 @@
 #define RK_QUAD_BODY 1 // quadtrees: interaction body without the z terms (0: the 3-D body on z = 0 data)
 #endif
 #ifndef RK_CARRY_REMAINDER
-#define RK_CARRY_REMAINDER 0 // dense phase: carry the sources that do not fill a round of NS to the next tile instead of a
-                             // masked step per tile (measured slower: 2.30 vs 2.27 ms; the extra LDS shuffle costs more)
+#define RK_CARRY_REMAINDER 1 // dense phase: carry the sources that do not fill a round of NS to the next tile instead of a masked step
+                             // per tile. Round 2 (7 waves per SIMD) measured it slower, 2.30 vs 2.27 ms; on round 5's kernels it is
+                             // ahead: 1M 0.590 -> 0.583 ms, 4M 2.177 -> 2.160 (tools/jobs_r05/r05_job30.sh). The producer of the
+                             // producer / consumer kernel hands over the same tiles (rk_kernels_pc.hip, publish()): same bits
 #endif
 #ifndef RK_EXACT_TRANSPOSED
 #define RK_EXACT_TRANSPOSED 1 // exact MAC test with lane = target when only a few candidates are queued
