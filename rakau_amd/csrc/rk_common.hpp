@@ -40,7 +40,7 @@ __host__ __device__ constexpr int nres_of(int q)
 constexpr uint32_t RK_PLAN_PAD_VALUE = 0xffffffffu; // launch-plan list entry without a critical node (skipped)
 constexpr int n_classes = 7;  // classes 0..5 are served by wave kernels, the last one by the block-per-group kernel
 constexpr int big_class = n_classes - 1;
-constexpr unsigned FIRST_ORDER_MAX = 32768; // critical nodes up to which a tree gets its first-call launch order on the device
+constexpr unsigned FIRST_ORDER_MAX = 49152; // critical nodes up to which a tree gets its first-call launch order on the device (round 4: 32768)
 constexpr int n_list_R = 6;   // variant 2: class c keeps R = c + 1 targets per lane
 __host__ __device__ constexpr int class_R(int c)
 {

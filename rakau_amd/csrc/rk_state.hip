@@ -1442,7 +1442,10 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                 const char *e = std::getenv("RK_PLAN_MAX_GROUPS");
                 // (60000 measured too: 2M particles = 54k nodes 1.19 instead of 1.22 ms, but the two 54k-node shards of the 4M
                 // tree 1.34-1.37 instead of 1.25-1.28: the heavy-first order gives up the L2 locality of neighbouring nodes.)
-                return e ? std::atoll(e) : int64_t(30000);
+                // Round 5: 45000 (rounds 2-4: 30000). With the list kernels' new occupancies the one launch is ahead further up:
+                // whole trees of 31.9k / 38.2k / 44.3k nodes 0.823 / 0.921 / 1.029 -> 0.697 / 0.842 / 0.971 ms; at 54k nodes (2M)
+                // 1.130 -> 1.107 but the 54k-node shards of the 4M tree 1.28 -> 1.32 (tools/jobs_r05/r05_job32.sh).
+                return e ? std::atoll(e) : int64_t(45000);
             }();
             // Between RK_PLAN_MAX_GROUPS and this many nodes: the class-reversed plan for k_list_any (0 = never). Round 3 used it
             // up to 60 000 nodes (equal to the light-tail plan within 2 % then, and free of the outliers forked launches showed

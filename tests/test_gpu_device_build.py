@@ -286,7 +286,7 @@ def test_exact_build_4m_census_and_time():
 
 @pytest.mark.parametrize("n,ncrit", [(3000, 128), (60000, 128), (150000, 256), (150000, 1300), (1500000, 128)])
 def test_first_call_launch_order_made_on_the_device(n, ncrit):
-    """Small trees (at most 32768 critical nodes) come with the launch order of their first call, made on the device with the
+    """Small trees (at most 49152 critical nodes) come with the launch order of their first call, made on the device with the
     tree (rk_build.hip make_first_order): the critical nodes the wave kernels serve by decreasing size (in steps of two), ties in Morton order --
     the heavy-first order repeated calls get from the host -- for trees built on the device, for host trees converted
     there and for replicas; every such node exactly once, oversized nodes (ncrit = 1300) left to their own kernel. The first call over that
@@ -301,7 +301,7 @@ def test_first_call_launch_order_made_on_the_device(n, ncrit):
         cr = st.crit_ranges()
         size = (cr[:, 1] - cr[:, 0]).astype(np.int64)
         ptr, nbytes = st.device_ptr("first_order")
-        if len(cr) > 32768:
+        if len(cr) > 49152:
             assert nbytes == 0
             continue
         wave = np.flatnonzero(size <= 256)
