@@ -168,7 +168,9 @@ RK_EXPORT int rk_acc_pot(rk_state *s, int q, int64_t p_begin, int64_t p_end, voi
  * instead of 3.1 into pageable arrays). The reference's seam takes raw `F *` outputs (detail/rocm_fwd.hpp:38-40), so
  * this is opt-in by where the caller allocates; `rakau_amd::pinned_allocator` (tree.hpp) wraps it for the
  * `std::vector<F, Allocator>` overloads of accs_u()/pots_u()/accs_pots_u() (tree.hpp:3406-3497 of the reference).
- * bytes == 0 yields a null pointer; rk_host_free(NULL) is a no-op.
+ * bytes == 0 yields a null pointer; rk_host_free(NULL) is a no-op. Freed blocks of 1 MiB and more are parked (at most eight,
+ * 512 MiB in all) and handed out again to requests they fit within a factor of two -- pinning costs milliseconds per 16 MiB --;
+ * rk_pool_trim() returns them to the system.
  */
 RK_EXPORT int rk_host_alloc(void **ptr, int64_t bytes);
 RK_EXPORT int rk_host_free(void *ptr);

@@ -347,6 +347,11 @@ inline void parallel_blocks(std::size_t n, std::size_t min_block, Fn &&f)
 // Per-thread staging for results that cannot be written where the caller wants them (original-order outputs, generic output
 // iterators): k arrays of n values, kept between calls and only ever grown. Pinned (rk_host_alloc: the kernels write into them
 // directly) when that succeeds, plain memory otherwise (no device: the CPU engine writes them).
+// Staging a thread keeps between calls, in all (larger sets are released when the call that needed them is over).
+#ifndef RAKAU_AMD_STAGE_KEEP_MB
+#define RAKAU_AMD_STAGE_KEEP_MB 16
+#endif
+constexpr std::size_t stage_keep_bytes = std::size_t(RAKAU_AMD_STAGE_KEEP_MB) << 20;
 template <typename F>
 struct stage_buffers {
     F *p[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -372,7 +377,7 @@ struct stage_buffers {
     }
     static void get(std::size_t n, std::size_t k, F *out[4])
     {
-        thread_local stage_buffers sb;
+        stage_buffers &sb = instance();
         if (sb.cap < n) {
             sb.release();
             sb.cap = n;
@@ -401,6 +406,27 @@ struct stage_buffers {
         for (std::size_t j = 0; j < 4; ++j) {
             out[j] = sb.p[j];
         }
+    }
+    // Called when a staged call is over: buffers beyond `keep_bytes` in all are given back at once, so that a pool of threads
+    // calling the staged overloads on large trees does not keep 4 x nparts x sizeof(F) of PINNED memory per thread for the life of
+    // the process; small ones stay for the next call. trim(0) releases everything the calling thread holds.
+    static void trim(std::size_t keep_bytes)
+    {
+        stage_buffers &sb = instance();
+        std::size_t held = 0;
+        for (const auto *q : sb.p) {
+            held += q ? std::max<std::size_t>(sb.cap, 1) * sizeof(F) : 0;
+        }
+        if (held > keep_bytes) {
+            sb.release();
+        }
+    }
+
+private:
+    static stage_buffers &instance()
+    {
+        thread_local stage_buffers sb;
+        return sb;
     }
 };
 
@@ -1743,6 +1769,7 @@ private:
                     }
                 }
             });
+            detail::stage_buffers<F>::trim(detail::stage_keep_bytes);
         }
     }
     template <bool Ordered, unsigned Q, typename Allocator>

@@ -20,6 +20,7 @@
 #include <memory>
 #include <map>
 #include <mutex>
+#include <unordered_map>
 #include <thread>
 #include <atomic>
 
@@ -2333,6 +2334,35 @@ public:
 
 } // namespace
 
+// rk_host_alloc() / rk_host_free(): pinned, device-visible host memory. Blocks of 1 MiB and more that are freed are parked (at most
+// eight of them, 512 MiB in all) and handed out again to requests they fit within a factor of two: pinning costs milliseconds per
+// 16 MiB, and the C++ header's staged overloads give their buffers back after every call on a large tree (tree.hpp,
+// stage_buffers::trim) instead of keeping them per thread for the life of the process. rk_pool_trim() releases what is parked.
+namespace
+{
+std::mutex g_host_mtx;
+std::unordered_map<void *, size_t> g_host_live; // blocks handed out by rk_host_alloc -> their size
+struct parked_host {
+    void *p;
+    size_t bytes;
+};
+std::vector<parked_host> g_host_parked;
+size_t g_host_parked_bytes = 0;
+} // namespace
+
+void host_blocks_trim()
+{
+    std::vector<parked_host> v;
+    {
+        std::lock_guard<std::mutex> lk(g_host_mtx);
+        v.swap(g_host_parked);
+        g_host_parked_bytes = 0;
+    }
+    for (auto &e : v) {
+        (void)hipHostFree(e.p);
+    }
+}
+
 int rk_host_alloc(void **ptr, int64_t bytes)
 {
     return guard([&] {
@@ -2340,17 +2370,55 @@ int rk_host_alloc(void **ptr, int64_t bytes)
             throw rk::error(RK_EINVAL, "rk_host_alloc: null pointer or negative size");
         }
         *ptr = nullptr;
-        if (bytes) {
-            RK_HIP(hipHostMalloc(ptr, static_cast<size_t>(bytes), hipHostMallocPortable));
+        if (!bytes) {
+            return;
         }
+        const auto need = static_cast<size_t>(bytes);
+        {
+            std::lock_guard<std::mutex> lk(g_host_mtx);
+            size_t best = g_host_parked.size();
+            for (size_t i = 0; i < g_host_parked.size(); ++i) {
+                if (g_host_parked[i].bytes >= need && g_host_parked[i].bytes <= 2 * need
+                    && (best == g_host_parked.size() || g_host_parked[i].bytes < g_host_parked[best].bytes)) {
+                    best = i;
+                }
+            }
+            if (best != g_host_parked.size()) {
+                *ptr = g_host_parked[best].p;
+                g_host_live.emplace(*ptr, g_host_parked[best].bytes);
+                g_host_parked_bytes -= g_host_parked[best].bytes;
+                g_host_parked.erase(g_host_parked.begin() + static_cast<std::ptrdiff_t>(best));
+                return;
+            }
+        }
+        RK_HIP(hipHostMalloc(ptr, need, hipHostMallocPortable));
+        std::lock_guard<std::mutex> lk(g_host_mtx);
+        g_host_live.emplace(*ptr, need);
     });
 }
 
 int rk_host_free(void *ptr)
 {
     return guard([&] {
-        if (ptr) {
-            RK_HIP(hipHostFree(ptr));
+        if (!ptr) {
+            return;
+        }
+        void *drop = ptr;
+        {
+            std::lock_guard<std::mutex> lk(g_host_mtx);
+            const auto it = g_host_live.find(ptr);
+            if (it != g_host_live.end()) {
+                const size_t bytes = it->second;
+                g_host_live.erase(it);
+                if (bytes >= (size_t(1) << 20) && g_host_parked.size() < 8 && g_host_parked_bytes + bytes <= (size_t(512) << 20)) {
+                    g_host_parked.push_back(parked_host{ptr, bytes});
+                    g_host_parked_bytes += bytes;
+                    drop = nullptr;
+                }
+            }
+        }
+        if (drop) {
+            RK_HIP(hipHostFree(drop));
         }
     });
 }
@@ -3295,10 +3363,12 @@ int rk_state_rebuild_device(rk_state *s, const void *const d_parts[4], int64_t n
     });
 }
 
+void host_blocks_trim();
 void rk_pool_trim(void)
 {
     rk::pool_trim();
     stage_trim();
+    host_blocks_trim();
 }
 
 void rk_set_build_exact(int on)
