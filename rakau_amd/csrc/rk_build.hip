@@ -319,7 +319,7 @@ __global__ void k_leaf_levels_windows(const uint8_t *win, uint32_t n, uint32_t m
 // ldiv[i] = first level at which c[i] leaves the cell of c[i-1]; cnt[i] = number of nodes whose first particle is i.
 template <int ND>
 __global__ void k_node_counts(const uint64_t *codes, uint32_t n, const uint8_t *leaf, uint8_t *ldiv, uint32_t *cnt,
-                              ctrl_block *ctrl)
+                              uint8_t *block_max)
 {
     __shared__ unsigned s_max;
     if (threadIdx.x == 0u) {
@@ -345,16 +345,32 @@ __global__ void k_node_counts(const uint64_t *codes, uint32_t n, const uint8_t *
         atomicMax(&s_max, 31u - static_cast<unsigned>(__clz(static_cast<int>(any))));
     }
     __syncthreads();
-    // (Same-address atomics serialise at ~10 ns each: with one per block this line alone was 150 us of a 4M-particle rebuild. The
-    // value only grows, so a block that sees its own maximum already recorded has nothing to add.)
-    if (threadIdx.x == 0u && s_max > __hip_atomic_load(&ctrl->max_level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-        atomicMax(&ctrl->max_level, s_max);
+    // One plain store per block, reduced by k_pack_nodes. (Round 4: one atomicMax per block on ONE word of the control block,
+    // ~10 ns each, serialised: 150 us at 4M particles. Round 5: an agent-scope load of that word per block and the atomic only when
+    // it would raise it -- still 15 600 same-address requests past the L2, 62 us against 20 for the kernel's real work.)
+    if (threadIdx.x == 0u) {
+        block_max[blockIdx.x] = static_cast<uint8_t>(s_max);
     }
 }
 
-__global__ void k_pack_nodes(ctrl_block *ctrl, const uint32_t *off_n)
+// One block: the node count (total of the scan) and the deepest leaf level (maximum over k_node_counts' blocks) for the host.
+__global__ void __launch_bounds__(256) k_pack_nodes(ctrl_block *ctrl, const uint32_t *off_n, const uint8_t *block_max, uint32_t n_blocks)
 {
-    ctrl->n_nonroot = *off_n;
+    __shared__ unsigned s_max;
+    if (threadIdx.x == 0u) {
+        s_max = 0u;
+        ctrl->n_nonroot = *off_n;
+    }
+    __syncthreads();
+    unsigned mx = 0u;
+    for (uint32_t b = threadIdx.x; b < n_blocks; b += blockDim.x) {
+        mx = max(mx, static_cast<unsigned>(block_max[b]));
+    }
+    atomicMax(&s_max, mx);
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        ctrl->max_level = s_max;
+    }
 }
 
 // Emit the nodes whose first particle is i. off[] = exclusive scan of cnt[] (off[n] = number of non-root nodes).
@@ -445,21 +461,26 @@ __global__ void k_emit_nodes(const uint64_t *codes, uint32_t n, const uint8_t *l
     }
 }
 
-// parent[] of every non-root node, written by the parent (children of k: k + 1, then skipping subtrees).
-__global__ void k_parents(const uint4 *topo, uint32_t n_nodes, uint32_t *parent, uint32_t *mask)
+// parent[] of every non-root node and the child-octant mask of every node, both written by the parent (children of k: k + 1,
+// then skipping subtrees). (Rounds 2-5 had every child atomicOr its octant into the parent's mask in k_flags and a k_popc pass
+// count the bits: 1.4M atomics on 0.35M words and one launch more, 42 + 6 us at 4M particles.)
+template <int ND>
+__global__ void k_parents(const uint4 *topo, const uint64_t *ncode, uint32_t n_nodes, uint32_t *parent, uint32_t *mask)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_nodes) {
         return;
     }
-    mask[k] = 0u; // child-octant masks are accumulated with atomicOr by k_flags
     if (k == 0u) {
         mask[n_nodes] = 0u;
     }
     const uint32_t last = k + topo[k].x;
+    uint32_t m = 0;
     for (uint32_t c = k + 1u; c <= last; c += topo[c].x + 1u) {
         parent[c] = k;
+        m |= 1u << (static_cast<unsigned>(ncode[c]) & geo<ND>::DMASK);
     }
+    mask[k] = m;
 }
 
 // ---- node properties --------------------------------------------------------------------------------------
@@ -512,6 +533,13 @@ __global__ void k_up_sums(const uint4 *topo, const uint64_t *ncode, uint32_t n_n
     s.x = sx, s.y = sy, s.z = sz, s.w = mt;
     sums[k] = s;
 }
+
+// (Round 5, built and measured, not kept -- tools/jobs_r05/r05_job37.sh, r05_job38.sh: (1) leaf sums and all levels in ONE launch,
+// the last child to deliver its sum adds up the parent (atomic counters): on eight XCDs every release / acquire pair is an L2
+// write-back + invalidate, 2.1 ms instead of 0.07 at 4M particles; (2) two or three levels per launch, the upper ones recomputing
+// the sums of their internal children instead of reading them: the walk over a node's children is a chain of dependent loads
+// (c += topo[c].x + 1), nested it is 72 deep -- rebuild +0.03 ms at 100k, +0.07 at 4M for two levels, +0.13 / +0.35 for three.
+// A level pass costs what its chain of eight dependent loads costs, 4.5 us, not what an empty launch costs.)
 
 // ---- node sums in the reference's association (exact mode) ----
 // The reference sums a node's particles serially in particle order (tree.hpp:1162-1168). Nodes that start at the same
@@ -784,7 +812,8 @@ struct tri_sum {
     }
 };
 
-template <int ND>
+// MASKS_DONE: the child masks are complete (k_parents of the device build); the child count is taken here, no k_popc pass.
+template <int ND, bool MASKS_DONE = false>
 __global__ void k_flags(const uint4 *topo, const uint64_t *ncode, const uint32_t *parent, uint32_t n_nodes,
                         uint32_t ncrit_clamped, tri *flags, uint32_t *mask)
 {
@@ -801,10 +830,17 @@ __global__ void k_flags(const uint4 *topo, const uint64_t *ncode, const uint32_t
     const bool orphan = k != 0u && par >= k;
     flags[k].a = (c && (k == 0u || orphan || !cand(par))) ? 1u : 0u;
     flags[k].b = topo[k].x != 0u ? 1u : 0u;
-    if (k == 0u) {
-        flags[n_nodes] = tri{0u, 0u, 0u};
-    } else if (!orphan) {
-        atomicOr(&mask[par], 1u << (static_cast<unsigned>(ncode[k]) & geo<ND>::DMASK));
+    if constexpr (MASKS_DONE) {
+        flags[k].c = static_cast<uint32_t>(__popc(mask[k]));
+        if (k == 0u) {
+            flags[n_nodes] = tri{0u, 0u, 0u};
+        }
+    } else {
+        if (k == 0u) {
+            flags[n_nodes] = tri{0u, 0u, 0u};
+        } else if (!orphan) {
+            atomicOr(&mask[par], 1u << (static_cast<unsigned>(ncode[k]) & geo<ND>::DMASK));
+        }
     }
 }
 
@@ -1056,6 +1092,90 @@ void exclusive_scan(const tri *in, tri *out, size_t n, hipStream_t st)
     RK_HIP(hipcub::DeviceScan::ExclusiveScan(tmp.get(), tb, in, out, tri_sum{}, tri{0u, 0u, 0u}, static_cast<int>(n + 1), st));
 }
 
+// ---- Morton sort ------------------------------------------------------------------------------------------
+// Stable LSD radix sort of (63-bit code, index) pairs: rocPRIM's onesweep DEVICE functions (histograms of every digit place in one
+// pass over the keys, then one decoupled-look-back scatter pass per 8-bit digit) under this file's own launch sequence.
+// hipcub::DeviceRadixSort::SortPairs() runs the same device code but resets its look-back states and its ordered-block counter with
+// two memsets in front of EVERY pass plus one for the histograms -- 17 fill kernels of ~5.5 us, a fifth of the sort at 4M
+// particles (profiles/r05/rebuild_timeline_*.txt) -- and below 2^20 items it switches to a merge sort of 1 + 2 log2(n / 4096)
+// launches (21 at 1M). Here the states of all eight passes are laid out side by side and cleared by ONE memset, the passes
+// ping-pong between the two caller-owned buffer pairs (no third copy of the pairs in a scratch allocation), and every size
+// takes the onesweep path. Same result: both are stable sorts of the same keys.
+namespace sortk
+{
+constexpr unsigned BS = 512, IPT = 16, RB = 8, RADIX = 1u << RB, IPB = BS * IPT; // rocPRIM's gfx942 / gfx950 tuning for 8 + 4 byte pairs
+constexpr unsigned END_BIT = 63, PLACES = (END_BIT + RB - 1) / RB;
+static_assert(PLACES % 2 == 0, "an even number of passes leaves the result in the buffers it started from");
+using bid_t = rocprim::detail::block_id_wrapper<unsigned int, true>; // blocks take their index from a counter, in arrival order
+using lookback_t = rocprim::detail::onesweep_lookback_state;
+static_assert(sizeof(lookback_t) == sizeof(uint32_t));
+
+__global__ void __launch_bounds__(BS) k_sort_hist(const uint64_t *keys, uint32_t *counts, uint32_t n, uint32_t full_blocks)
+{
+    rocprim::detail::onesweep_histograms<BS, IPT, RB, false>(keys, counts, n, full_blocks, rocprim::identity_decomposer{}, 0u, END_BIT);
+}
+__global__ void __launch_bounds__(BS) k_sort_scan(uint32_t *counts)
+{
+    rocprim::detail::onesweep_scan_histograms<BS, RB>(counts);
+}
+__global__ void __launch_bounds__(BS) k_sort_pass(const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout, uint32_t n,
+                                                  uint32_t *offs_in, uint32_t *offs_out, lookback_t *lb, unsigned bit, unsigned bits,
+                                                  unsigned full_blocks, bid_t bid)
+{
+    rocprim::detail::onesweep_iteration<BS, IPT, RB, false, rocprim::block_radix_rank_algorithm::match>(
+        kin, kout, vin, vout, n, offs_in, offs_out, lb, rocprim::identity_decomposer{}, bit, bits, full_blocks, bid);
+}
+
+// Words of state for n items: digit counts of every place, a scratch row the last block of a pass writes, one block counter per
+// pass, the look-back states of every pass (8 KiB per 8192 items in all: one byte per item).
+inline size_t state_words(uint32_t n)
+{
+    const size_t blocks = (static_cast<size_t>(n) + IPB - 1) / IPB;
+    return static_cast<size_t>(PLACES) * RADIX + RADIX + 16 + static_cast<size_t>(PLACES) * RADIX * blocks;
+}
+} // namespace sortk
+
+// Sorts the n pairs of (ka, va) by the low 63 bits of the keys, stably; (kb, vb) is scratch of the same size. The result is in (ka, va).
+void sort_codes(uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint32_t n, hipStream_t st)
+{
+    using namespace sortk;
+    if (n < 2u) {
+        return;
+    }
+    static const bool use_hipcub = [] {
+        const char *e = std::getenv("RK_SORT_HIPCUB"); // 1: the library call (A/B, tools/jobs_r05/r05_job37.sh)
+        return e && std::atoi(e) != 0;
+    }();
+    // Below 2^20 items the library's merge sort wins (12-block launches of 8192 items each leave the device empty: 100k +0.11 ms,
+    // 1M +0.055 ms with the onesweep passes; 2M -0.045, 4M -0.057: tools/jobs_r05/r05_job37.sh).
+    if (use_hipcub || n < (1u << 20) || n > (1u << 28)) {
+        size_t tb = 0;
+        RK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, ka, kb, va, vb, static_cast<int>(n), 0, static_cast<int>(END_BIT), st));
+        auto tmp = dalloc<unsigned char>(tb);
+        RK_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.get(), tb, ka, kb, va, vb, static_cast<int>(n), 0, static_cast<int>(END_BIT), st));
+        RK_HIP(hipMemcpyAsync(ka, kb, static_cast<size_t>(n) * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+        RK_HIP(hipMemcpyAsync(va, vb, static_cast<size_t>(n) * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+        return;
+    }
+    const unsigned blocks = (n + IPB - 1u) / IPB, full_blocks = n % IPB == 0u ? blocks : blocks - 1u;
+    const size_t words = state_words(n);
+    auto state = dalloc<uint32_t>(words);
+    RK_HIP(hipMemsetAsync(state.get(), 0, words * sizeof(uint32_t), st));
+    uint32_t *counts = state.get(), *scratch_row = counts + PLACES * RADIX, *bids = scratch_row + RADIX;
+    auto *lb = reinterpret_cast<lookback_t *>(bids + 16);
+    hipLaunchKernelGGL(k_sort_hist, dim3(blocks), dim3(BS), 0, st, ka, counts, n, full_blocks);
+    hipLaunchKernelGGL(k_sort_scan, dim3(PLACES), dim3(BS), 0, st, counts);
+    for (unsigned p = 0; p < PLACES; ++p) {
+        const unsigned bit = p * RB, bits = std::min(RB, END_BIT - bit);
+        const bool fwd = p % 2u == 0u;
+        hipLaunchKernelGGL(k_sort_pass, dim3(blocks), dim3(BS), 0, st, fwd ? ka : kb, fwd ? kb : ka, fwd ? va : vb, fwd ? vb : va, n,
+                           counts + p * RADIX, scratch_row, lb + static_cast<size_t>(p) * RADIX * blocks, bit, bits, full_blocks,
+                           bid_t::create(bids + p));
+    }
+    RK_HIP(hipGetLastError());
+    // (The state goes back to the block cache and is only ever reused on this stream.)
+}
+
 } // namespace bld
 
 // (see k_first_keys)
@@ -1140,6 +1260,8 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     auto ctrl = dalloc<ctrl_block>(1);
     ctrl_block hc{};
     RK_HIP(hipMemsetAsync(ctrl.get(), 0, sizeof(ctrl_block), st));
+    // (Round 5, measured and not kept: the last kernel in front of a look-up storing the block + a sequence number to pinned host
+    // memory that the host polls, instead of a blocking copy -- rebuild +0.025 ms at 100k, +0.045 at 4M, tools/jobs_r05/r05_job39.sh.)
     const auto fetch_ctrl = [&] { RK_HIP(hipMemcpy(&hc, ctrl.get(), sizeof(hc), hipMemcpyDeviceToHost)); };
 
     // ---- box size, encode, sort, permute, leaf levels, node counts: no host round trip ----
@@ -1148,27 +1270,21 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
         hipLaunchKernelGGL((k_maxabs<F>), dim3(std::min(nblk(n), 1024u)), dim3(256), 0, st, dx.get(), dy.get(), dz.get(), n,
                            ctrl.get());
     }
-    auto keys_in = dalloc<uint64_t>(n), keys_out = dalloc<uint64_t>(n);
-    auto vals_in = dalloc<uint32_t>(n), vals_out = dalloc<uint32_t>(n);
+    // (ka, va): the codes and indices, sorted in place; (kb, vb): the other half of the sort's ping-pong.
+    auto keys_a = dalloc<uint64_t>(n), keys_b = dalloc<uint64_t>(n);
+    auto vals_a = dalloc<uint32_t>(n), vals_b = dalloc<uint32_t>(n);
     hipLaunchKernelGGL((k_encode<F, ND>), dim3(nblk(n)), dim3(256), 0, st, dx.get(), dy.get(), dz.get(), n, ctrl.get(),
-                       static_cast<F>(box_size_in), keys_in.get(), vals_in.get());
-    {
-        size_t tb = 0;
-        RK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys_in.get(), keys_out.get(), vals_in.get(),
-                                                  vals_out.get(), static_cast<int>(n), 0, 63, st));
-        auto tmp = dalloc<unsigned char>(tb);
-        RK_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.get(), tb, keys_in.get(), keys_out.get(), vals_in.get(),
-                                                  vals_out.get(), static_cast<int>(n), 0, 63, st));
-    }
-    keys_in.reset();
-    vals_in.reset();
+                       static_cast<F>(box_size_in), keys_a.get(), vals_a.get());
+    sort_codes(keys_a.get(), vals_a.get(), keys_b.get(), vals_b.get(), n, st);
+    keys_b.reset();
+    vals_b.reset();
     void *p4 = pool_alloc(std::max<size_t>(n, 1) * sizeof(v4));
     s.buf[RK_BUF_PART4] = p4;
     s.buf_bytes[RK_BUF_PART4] = static_cast<int64_t>(n * sizeof(v4));
     hipLaunchKernelGGL((k_permute<F>), dim3(nblk(n)), dim3(256), 0, st, dx.get(), dy.get(), dz.get(), dm.get(),
-                       vals_out.get(), n, static_cast<v4 *>(p4));
-    s.bld_codes = keys_out.release();
-    s.bld_perm = vals_out.release();
+                       vals_a.get(), n, static_cast<v4 *>(p4));
+    s.bld_codes = keys_a.release();
+    s.bld_perm = vals_a.release();
     const auto *codes = static_cast<const uint64_t *>(s.bld_codes);
 
     const auto mln = static_cast<uint32_t>(std::min<uint64_t>(max_leaf_n, 0xffffffffu));
@@ -1181,9 +1297,10 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     } else {
         hipLaunchKernelGGL(k_leaf_levels_search<ND>, dim3(nblk(n)), dim3(256), 0, st, codes, n, mln, leaf.get());
     }
-    hipLaunchKernelGGL(k_node_counts<ND>, dim3(nblk(n)), dim3(256), 0, st, codes, n, leaf.get(), ldiv.get(), cnt.get(), ctrl.get());
+    auto block_max = dalloc<uint8_t>(nblk(n));
+    hipLaunchKernelGGL(k_node_counts<ND>, dim3(nblk(n)), dim3(256), 0, st, codes, n, leaf.get(), ldiv.get(), cnt.get(), block_max.get());
     exclusive_scan(cnt.get(), off.get(), n, st);
-    hipLaunchKernelGGL(k_pack_nodes, dim3(1), dim3(1), 0, st, ctrl.get(), off.get() + n);
+    hipLaunchKernelGGL(k_pack_nodes, dim3(1), dim3(256), 0, st, ctrl.get(), off.get() + n, block_max.get(), nblk(n));
 
     // ---- first round trip: input errors (in the reference's order), box, node count ----
     fetch_ctrl();
@@ -1246,16 +1363,16 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     auto mask = dalloc<uint32_t>(nn + 1);
     hipLaunchKernelGGL(k_emit_nodes<ND>, dim3(nblk(n)), dim3(256), 0, st, codes, n, leaf.get(), ldiv.get(), off.get(), topo,
                        ncode, parent.get());
-    hipLaunchKernelGGL(k_parents, dim3(nblk(nn)), dim3(256), 0, st, topo, static_cast<uint32_t>(nn), parent.get(), mask.get());
+    hipLaunchKernelGGL(k_parents<ND>, dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, static_cast<uint32_t>(nn), parent.get(), mask.get());
     leaf.reset(), ldiv.reset(), cnt.reset(), off.reset();
 
     // ---- node properties ----
     auto sums = dalloc<v4>(nn);
-    hipLaunchKernelGGL((k_leaf_sums<F>), dim3(nblk(nn)), dim3(256), 0, st, topo, static_cast<uint32_t>(nn),
-                       static_cast<const v4 *>(p4), sums.get());
     if (exact_node_sums()) {
         // The reference's association (bit-identical node properties): one serial chain per distinct first particle, all
         // at once; the root's N links set the time (~25 ms at 4M particles).
+        hipLaunchKernelGGL((k_leaf_sums<F>), dim3(nblk(nn)), dim3(256), 0, st, topo, static_cast<uint32_t>(nn),
+                           static_cast<const v4 *>(p4), sums.get());
         const auto max_big = static_cast<unsigned>(static_cast<size_t>(n) / EXACT_WAVE_MIN * (CBITS + 1u) + 2u);
         auto big = dalloc<uint32_t>(static_cast<size_t>(max_big) + 1u);
         // Slot 0 is the root's; the counter starts behind it.
@@ -1267,8 +1384,9 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
         hipLaunchKernelGGL((k_exact_chains_wave<F>), dim3(std::min<unsigned>(max_big, static_cast<unsigned>(nn))), dim3(256), 0, st,
                            topo, big.get(), big.get() + max_big, static_cast<const v4 *>(p4), sums.get());
     } else {
-        // Internal nodes live above the deepest leaf level: the passes of the levels below it (a third to a half of the CBITS
-        // launches, ~4 us each: a sixth of a 100k-particle rebuild) are not launched.
+        hipLaunchKernelGGL((k_leaf_sums<F>), dim3(nblk(nn)), dim3(256), 0, st, topo, static_cast<uint32_t>(nn),
+                           static_cast<const v4 *>(p4), sums.get());
+        // Internal nodes live above the deepest leaf level: the passes of the levels below it are not launched.
         const int top = std::min(static_cast<int>(CBITS), static_cast<int>(hc.max_level)) - 1;
         for (int lvl = top; lvl >= 0; --lvl) {
             hipLaunchKernelGGL((k_up_sums<F, ND>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, static_cast<uint32_t>(nn),
@@ -1282,9 +1400,8 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     // ---- critical nodes, child masks: one scan of three counters ----
     const auto ncrit_c = static_cast<uint32_t>(std::min<uint64_t>(s.ncrit, 0xffffffffu));
     auto flags = dalloc<tri>(nn + 1), offs = dalloc<tri>(nn + 1);
-    hipLaunchKernelGGL(k_flags<ND>, dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, parent.get(), static_cast<uint32_t>(nn), ncrit_c,
-                       flags.get(), mask.get());
-    hipLaunchKernelGGL(k_popc, dim3(nblk(nn)), dim3(256), 0, st, mask.get(), static_cast<uint32_t>(nn), flags.get());
+    hipLaunchKernelGGL((k_flags<ND, true>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, parent.get(), static_cast<uint32_t>(nn),
+                       ncrit_c, flags.get(), mask.get());
     exclusive_scan(flags.get(), offs.get(), nn, st);
     hipLaunchKernelGGL(k_pack_counts, dim3(1), dim3(1), 0, st, ctrl.get(), offs.get() + nn);
 

@@ -620,7 +620,7 @@ __device__ __forceinline__ void list_node(const kparams<F> &P, lk_wave_lds<F> &L
 }
 
 template <typename F, int Q, int MAC, int R, int ND, bool BIG = false>
-__global__ void __launch_bounds__(64 * (BIG ? LK_BIG_WPB : RK_WPB), BIG ? (sizeof(F) == 4 ? RK_WBIG : RK_W64) : (sizeof(F) == 4 ? (R <= 2 ? RK_W12 : (R == 3 ? RK_W3 : (R == 4 ? RK_W4 : (R == 5 ? RK_W5 : RK_W6)))) : (R >= 4 ? RK_W64_R4 : (R == 3 ? RK_W64_R3 : RK_W64)))) k_list(const kparams<F> P, const uint32_t *__restrict__ list, int n_list, const uint32_t *__restrict__ n_list_dev = nullptr)
+__global__ void __launch_bounds__(64 * (BIG ? LK_BIG_WPB : RK_WPB), BIG ? (sizeof(F) == 4 ? RK_WBIG : RK_W64_ANY) : (sizeof(F) == 4 ? (R <= 2 ? RK_W12 : (R == 3 ? RK_W3 : (R == 4 ? RK_W4 : (R == 5 ? RK_W5 : RK_W6)))) : (R >= 4 ? RK_W64_R4 : (R == 3 ? RK_W64_R3 : RK_W64)))) k_list(const kparams<F> P, const uint32_t *__restrict__ list, int n_list, const uint32_t *__restrict__ n_list_dev = nullptr)
 {
     __shared__ lk_wave_lds<F> s_lds[BIG ? LK_BIG_WPB : RK_WPB];
 
@@ -652,7 +652,7 @@ __global__ void __launch_bounds__(64 * (BIG ? LK_BIG_WPB : RK_WPB), BIG ? (sizeo
 // picks the R of its node and runs the same list_node<..., R> the class kernels run. Compiled for the registers of the
 // largest R; the launch is too small to fill the device anyway.
 template <typename F, int Q, int MAC, int ND, int RMAX = 4>
-__global__ void __launch_bounds__(64, sizeof(F) == 4 ? (RMAX >= 4 ? RK_WANY : RK_W3) : RK_W64) k_list_any(const kparams<F> P, const uint32_t *__restrict__ list, int n_list)
+__global__ void __launch_bounds__(64, sizeof(F) == 4 ? (RMAX >= 4 ? RK_WANY : RK_W3) : RK_W64_ANY) k_list_any(const kparams<F> P, const uint32_t *__restrict__ list, int n_list)
 {
     __shared__ lk_wave_lds<F> s_lds;
     const int lane = threadIdx.x;

@@ -52,7 +52,10 @@
 #define RK_W64 4 // fp64 kernels (all R): waves per SIMD they are compiled for (3: 63.3 ms, 4: 62.8, 5: 67.3 at 16M)
 #endif
 #ifndef RK_W64_R3
-#define RK_W64_R3 RK_W64 // fp64, R = 3 class kernel
+#define RK_W64_R3 4 // fp64, R = 3 class kernel
+#endif
+#ifndef RK_W64_ANY
+#define RK_W64_ANY 4 // fp64: k_list_any and the kernel for oversized nodes
 #endif
 #ifndef RK_W64_R4
 #define RK_W64_R4 3 // fp64, R = 4 class kernel: 165 VGPRs, no scratch (at 4 waves: 128 VGPRs + 80 bytes of scratch per lane). 16M fp64
