@@ -1103,21 +1103,24 @@ void exclusive_scan(const tri *in, tri *out, size_t n, hipStream_t st)
 // takes the onesweep path. Same result: both are stable sorts of the same keys.
 namespace sortk
 {
-constexpr unsigned BS = 512, IPT = 16, RB = 8, RADIX = 1u << RB, IPB = BS * IPT; // rocPRIM's gfx942 / gfx950 tuning for 8 + 4 byte pairs
+constexpr unsigned RB = 8, RADIX = 1u << RB;
 constexpr unsigned END_BIT = 63, PLACES = (END_BIT + RB - 1) / RB;
 static_assert(PLACES % 2 == 0, "an even number of passes leaves the result in the buffers it started from");
 using bid_t = rocprim::detail::block_id_wrapper<unsigned int, true>; // blocks take their index from a counter, in arrival order
 using lookback_t = rocprim::detail::onesweep_lookback_state;
 static_assert(sizeof(lookback_t) == sizeof(uint32_t));
 
+template <unsigned BS, unsigned IPT>
 __global__ void __launch_bounds__(BS) k_sort_hist(const uint64_t *keys, uint32_t *counts, uint32_t n, uint32_t full_blocks)
 {
     rocprim::detail::onesweep_histograms<BS, IPT, RB, false>(keys, counts, n, full_blocks, rocprim::identity_decomposer{}, 0u, END_BIT);
 }
+template <unsigned BS>
 __global__ void __launch_bounds__(BS) k_sort_scan(uint32_t *counts)
 {
     rocprim::detail::onesweep_scan_histograms<BS, RB>(counts);
 }
+template <unsigned BS, unsigned IPT>
 __global__ void __launch_bounds__(BS) k_sort_pass(const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout, uint32_t n,
                                                   uint32_t *offs_in, uint32_t *offs_out, lookback_t *lb, unsigned bit, unsigned bits,
                                                   unsigned full_blocks, bid_t bid)
@@ -1126,54 +1129,57 @@ __global__ void __launch_bounds__(BS) k_sort_pass(const uint64_t *kin, uint64_t 
         kin, kout, vin, vout, n, offs_in, offs_out, lb, rocprim::identity_decomposer{}, bit, bits, full_blocks, bid);
 }
 
-// Words of state for n items: digit counts of every place, a scratch row the last block of a pass writes, one block counter per
-// pass, the look-back states of every pass (8 KiB per 8192 items in all: one byte per item).
-inline size_t state_words(uint32_t n)
+// State for n items in blocks of BS * IPT: digit counts of every place, a scratch row the last block of a pass writes, one block
+// counter per pass, the look-back states of every pass (256 words per block and pass).
+template <unsigned BS, unsigned IPT>
+void onesweep(uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint32_t n, hipStream_t st)
 {
-    const size_t blocks = (static_cast<size_t>(n) + IPB - 1) / IPB;
-    return static_cast<size_t>(PLACES) * RADIX + RADIX + 16 + static_cast<size_t>(PLACES) * RADIX * blocks;
-}
-} // namespace sortk
-
-// Sorts the n pairs of (ka, va) by the low 63 bits of the keys, stably; (kb, vb) is scratch of the same size. The result is in (ka, va).
-void sort_codes(uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint32_t n, hipStream_t st)
-{
-    using namespace sortk;
-    if (n < 2u) {
-        return;
-    }
-    static const bool use_hipcub = [] {
-        const char *e = std::getenv("RK_SORT_HIPCUB"); // 1: the library call (A/B, tools/jobs_r05/r05_job37.sh)
-        return e && std::atoi(e) != 0;
-    }();
-    // Below 2^20 items the library's merge sort wins (12-block launches of 8192 items each leave the device empty: 100k +0.11 ms,
-    // 1M +0.055 ms with the onesweep passes; 2M -0.045, 4M -0.057: tools/jobs_r05/r05_job37.sh).
-    if (use_hipcub || n < (1u << 20) || n > (1u << 28)) {
-        size_t tb = 0;
-        RK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, ka, kb, va, vb, static_cast<int>(n), 0, static_cast<int>(END_BIT), st));
-        auto tmp = dalloc<unsigned char>(tb);
-        RK_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.get(), tb, ka, kb, va, vb, static_cast<int>(n), 0, static_cast<int>(END_BIT), st));
-        RK_HIP(hipMemcpyAsync(ka, kb, static_cast<size_t>(n) * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
-        RK_HIP(hipMemcpyAsync(va, vb, static_cast<size_t>(n) * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-        return;
-    }
+    constexpr unsigned IPB = BS * IPT;
     const unsigned blocks = (n + IPB - 1u) / IPB, full_blocks = n % IPB == 0u ? blocks : blocks - 1u;
-    const size_t words = state_words(n);
+    const size_t words = static_cast<size_t>(PLACES) * RADIX + RADIX + 16 + static_cast<size_t>(PLACES) * RADIX * blocks;
     auto state = dalloc<uint32_t>(words);
     RK_HIP(hipMemsetAsync(state.get(), 0, words * sizeof(uint32_t), st));
     uint32_t *counts = state.get(), *scratch_row = counts + PLACES * RADIX, *bids = scratch_row + RADIX;
     auto *lb = reinterpret_cast<lookback_t *>(bids + 16);
-    hipLaunchKernelGGL(k_sort_hist, dim3(blocks), dim3(BS), 0, st, ka, counts, n, full_blocks);
-    hipLaunchKernelGGL(k_sort_scan, dim3(PLACES), dim3(BS), 0, st, counts);
+    hipLaunchKernelGGL((k_sort_hist<BS, IPT>), dim3(blocks), dim3(BS), 0, st, ka, counts, n, full_blocks);
+    hipLaunchKernelGGL((k_sort_scan<BS>), dim3(PLACES), dim3(BS), 0, st, counts);
     for (unsigned p = 0; p < PLACES; ++p) {
         const unsigned bit = p * RB, bits = std::min(RB, END_BIT - bit);
         const bool fwd = p % 2u == 0u;
-        hipLaunchKernelGGL(k_sort_pass, dim3(blocks), dim3(BS), 0, st, fwd ? ka : kb, fwd ? kb : ka, fwd ? va : vb, fwd ? vb : va, n,
-                           counts + p * RADIX, scratch_row, lb + static_cast<size_t>(p) * RADIX * blocks, bit, bits, full_blocks,
-                           bid_t::create(bids + p));
+        hipLaunchKernelGGL((k_sort_pass<BS, IPT>), dim3(blocks), dim3(BS), 0, st, fwd ? ka : kb, fwd ? kb : ka, fwd ? va : vb,
+                           fwd ? vb : va, n, counts + p * RADIX, scratch_row, lb + static_cast<size_t>(p) * RADIX * blocks, bit, bits,
+                           full_blocks, bid_t::create(bids + p));
     }
     RK_HIP(hipGetLastError());
     // (The state goes back to the block cache and is only ever reused on this stream.)
+}
+} // namespace sortk
+
+// Sorts the n pairs of (ka, va) by the low 63 bits of the keys, stably; (kb, vb) is scratch of the same size. Returns true when the
+// result is in (kb, vb) instead of (ka, va).
+bool sort_codes(uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint32_t n, hipStream_t st)
+{
+    using namespace sortk;
+    if (n < 2u) {
+        return false;
+    }
+    static const long knob_min = [] {
+        const char *e = std::getenv("RK_SORT_MIN"); // items from which the onesweep sequence replaces the library call (-1: never)
+        return e ? std::atol(e) : (1l << 20);
+    }();
+    // Below 2^20 items the library's merge sort wins (launches of a dozen blocks of 8192 items leave the device empty: 100k +0.11 ms,
+    // 1M +0.055 ms with the onesweep passes; 2M -0.045, 4M -0.057: tools/jobs_r05/r05_job37.sh).
+    if (knob_min < 0 || static_cast<long>(n) < knob_min || n > (1u << 28)) {
+        size_t tb = 0;
+        RK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, ka, kb, va, vb, static_cast<int>(n), 0, static_cast<int>(END_BIT), st));
+        auto tmp = dalloc<unsigned char>(tb);
+        RK_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.get(), tb, ka, kb, va, vb, static_cast<int>(n), 0, static_cast<int>(END_BIT), st));
+        return true;
+    }
+    // rocPRIM's gfx942 / gfx950 block shape for 8 + 4 byte pairs. Smaller blocks for mid-size sorts (256 x 8, 256 x 16, 512 x 8,
+    // 256 x 4 from 100k to 2M items) all lose to the merge sort and to this shape: tools/jobs_r05/r05_job40.sh.
+    onesweep<512, 16>(ka, va, kb, vb, n, st);
+    return false;
 }
 
 } // namespace bld
@@ -1275,7 +1281,10 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     auto vals_a = dalloc<uint32_t>(n), vals_b = dalloc<uint32_t>(n);
     hipLaunchKernelGGL((k_encode<F, ND>), dim3(nblk(n)), dim3(256), 0, st, dx.get(), dy.get(), dz.get(), n, ctrl.get(),
                        static_cast<F>(box_size_in), keys_a.get(), vals_a.get());
-    sort_codes(keys_a.get(), vals_a.get(), keys_b.get(), vals_b.get(), n, st);
+    if (sort_codes(keys_a.get(), vals_a.get(), keys_b.get(), vals_b.get(), n, st)) {
+        keys_a.swap(keys_b);
+        vals_a.swap(vals_b);
+    }
     keys_b.reset();
     vals_b.reset();
     void *p4 = pool_alloc(std::max<size_t>(n, 1) * sizeof(v4));
