@@ -316,6 +316,31 @@ __global__ void k_leaf_levels_windows(const uint8_t *win, uint32_t n, uint32_t m
     leaf[i] = static_cast<uint8_t>(min(best, geo<ND>::CB));
 }
 
+// The two kernels above in one launch: a block computes the windows its 256 particles look at (the m in front of it included)
+// into LDS and takes the maxima from there -- no win[] array, one launch less (4M particles: 11 + 21 us -> 14).
+template <int ND>
+__global__ void __launch_bounds__(256) k_leaf_levels_fused(const uint64_t *codes, uint32_t n, uint32_t m, uint8_t *leaf)
+{
+    __shared__ uint8_t s_win[256 + 64];
+    const uint32_t base = blockIdx.x * 256u;
+    for (uint32_t t = threadIdx.x; t < 256u + m; t += 256u) {
+        // window j = base - m + t (none in front of particle 0)
+        const bool have = base + t >= m;
+        const uint32_t j = base + t - m;
+        s_win[t] = (have && m < n && j < n - m) ? static_cast<uint8_t>(common_levels<ND>(codes[j], codes[j + m]) + 1u) : uint8_t(0);
+    }
+    __syncthreads();
+    const uint32_t i = base + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    unsigned best = 0;
+    for (uint32_t t = threadIdx.x; t <= threadIdx.x + m; ++t) { // windows i - m .. i
+        best = max(best, static_cast<unsigned>(s_win[t]));
+    }
+    leaf[i] = static_cast<uint8_t>(min(best, geo<ND>::CB));
+}
+
 // ldiv[i] = first level at which c[i] leaves the cell of c[i-1]; cnt[i] = number of nodes whose first particle is i.
 template <int ND>
 __global__ void k_node_counts(const uint64_t *codes, uint32_t n, const uint8_t *leaf, uint8_t *ldiv, uint32_t *cnt,
@@ -362,11 +387,23 @@ __global__ void __launch_bounds__(256) k_pack_nodes(ctrl_block *ctrl, const uint
         ctrl->n_nonroot = *off_n;
     }
     __syncthreads();
-    unsigned mx = 0u;
-    for (uint32_t b = threadIdx.x; b < n_blocks; b += blockDim.x) {
-        mx = max(mx, static_cast<unsigned>(block_max[b]));
+    // Sixteen bytes per load (the array is 16-byte aligned: it comes from the block cache): a byte per iteration was 61 dependent
+    // round trips per thread at 4M particles, 18 us. Levels are below 32, the OR of (1 << level) carries the maximum.
+    unsigned any = 1u;
+    const uint32_t n16 = n_blocks / 16u;
+    const auto *v = reinterpret_cast<const uint4 *>(block_max);
+    for (uint32_t g = threadIdx.x; g < n16; g += blockDim.x) {
+        const uint4 q = v[g];
+        const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            any |= (1u << (w[j] & 31u)) | (1u << ((w[j] >> 8) & 31u)) | (1u << ((w[j] >> 16) & 31u)) | (1u << ((w[j] >> 24) & 31u));
+        }
     }
-    atomicMax(&s_max, mx);
+    for (uint32_t b = n16 * 16u + threadIdx.x; b < n_blocks; b += blockDim.x) {
+        any |= 1u << (block_max[b] & 31u);
+    }
+    atomicMax(&s_max, 31u - static_cast<unsigned>(__clz(static_cast<int>(any))));
     __syncthreads();
     if (threadIdx.x == 0u) {
         ctrl->max_level = s_max;
@@ -461,11 +498,17 @@ __global__ void k_emit_nodes(const uint64_t *codes, uint32_t n, const uint8_t *l
     }
 }
 
+template <int ND>
+__device__ inline unsigned level_of(uint64_t code)
+{
+    return (63u - static_cast<unsigned>(__clzll(static_cast<long long>(code)))) / geo<ND>::DB;
+}
+
 // parent[] of every non-root node and the child-octant mask of every node, both written by the parent (children of k: k + 1,
 // then skipping subtrees). (Rounds 2-5 had every child atomicOr its octant into the parent's mask in k_flags and a k_popc pass
 // count the bits: 1.4M atomics on 0.35M words and one launch more, 42 + 6 us at 4M particles.)
 template <int ND>
-__global__ void k_parents(const uint4 *topo, const uint64_t *ncode, uint32_t n_nodes, uint32_t *parent, uint32_t *mask)
+__global__ void k_parents(const uint4 *topo, const uint64_t *ncode, uint32_t n_nodes, uint32_t *parent, uint32_t *mask, uint8_t *ilevel)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_nodes) {
@@ -474,6 +517,9 @@ __global__ void k_parents(const uint4 *topo, const uint64_t *ncode, uint32_t n_n
     if (k == 0u) {
         mask[n_nodes] = 0u;
     }
+    // Level of an internal node, 0xff for a leaf: what a level pass of the node sums has to know about the 1.4M nodes it looks at
+    // (one byte instead of topo[k].x + ncode[k], 24 bytes: eleven passes at 4M particles 70 -> 52 us).
+    ilevel[k] = topo[k].x != 0u ? static_cast<uint8_t>(level_of<ND>(ncode[k])) : uint8_t(0xff);
     const uint32_t last = k + topo[k].x;
     uint32_t m = 0;
     for (uint32_t c = k + 1u; c <= last; c += topo[c].x + 1u) {
@@ -484,12 +530,6 @@ __global__ void k_parents(const uint4 *topo, const uint64_t *ncode, uint32_t n_n
 }
 
 // ---- node properties --------------------------------------------------------------------------------------
-template <int ND>
-__device__ inline unsigned level_of(uint64_t code)
-{
-    return (63u - static_cast<unsigned>(__clzll(static_cast<long long>(code)))) / geo<ND>::DB;
-}
-
 template <typename F>
 __global__ void k_leaf_sums(const uint4 *topo, uint32_t n_nodes, const typename vt<F>::v4 *part4,
                             typename vt<F>::v4 *sums)
@@ -513,11 +553,11 @@ __global__ void k_leaf_sums(const uint4 *topo, uint32_t n_nodes, const typename 
 }
 
 template <typename F, int ND>
-__global__ void k_up_sums(const uint4 *topo, const uint64_t *ncode, uint32_t n_nodes, unsigned lvl,
+__global__ void k_up_sums(const uint4 *topo, const uint8_t *ilevel, uint32_t n_nodes, unsigned lvl,
                           typename vt<F>::v4 *sums)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_nodes || topo[k].x == 0u || level_of<ND>(ncode[k]) != lvl) {
+    if (k >= n_nodes || ilevel[k] != lvl) {
         return;
     }
     F mt = F(0), sx = F(0), sy = F(0), sz = F(0);
@@ -888,12 +928,37 @@ __global__ void __launch_bounds__(256) k_crit_boxes(const uint4 *crit, uint32_t 
         lo.x = fmin(lo.x, p.x), lo.y = fmin(lo.y, p.y), lo.z = fmin(lo.z, p.z);
         hi.x = fmax(hi.x, p.x), hi.y = fmax(hi.y, p.y), hi.z = fmax(hi.z, p.z);
     }
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        lo.x = fmin(lo.x, __shfl_xor(lo.x, d, 64)), lo.y = fmin(lo.y, __shfl_xor(lo.y, d, 64)), lo.z = fmin(lo.z, __shfl_xor(lo.z, d, 64));
-        hi.x = fmax(hi.x, __shfl_xor(hi.x, d, 64)), hi.y = fmax(hi.y, __shfl_xor(hi.y, d, 64)), hi.z = fmax(hi.z, __shfl_xor(hi.z, d, 64));
-    }
-    if (lane == 0u) {
+    // Minima / maxima over the 64 lanes: the DPP network of wave_incl_scan() (row_shr 1, 2, 4, 8 inside the rows of 16, then
+    // row_bcast 15 / 31 across them; lanes without a source keep their own value -- neutral for min and max), total in lane 63.
+    // (Rounds 2-5: six xor-shuffles per component, 36 ds_bpermute round trips per node.)
+    const auto fold = [](F v, auto op) __attribute__((always_inline)) {
+        const auto step = [&](F x, auto ctrl, auto rows) __attribute__((always_inline)) {
+            if constexpr (sizeof(F) == 4) {
+                const int r = __builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), decltype(ctrl)::value,
+                                                          decltype(rows)::value, 0xf, false);
+                return op(x, __int_as_float(r));
+            } else {
+                const long long b = __double_as_longlong(x);
+                const int l = static_cast<int>(b), h = static_cast<int>(b >> 32);
+                const int rl = __builtin_amdgcn_update_dpp(l, l, decltype(ctrl)::value, decltype(rows)::value, 0xf, false);
+                const int rh = __builtin_amdgcn_update_dpp(h, h, decltype(ctrl)::value, decltype(rows)::value, 0xf, false);
+                return op(x, __longlong_as_double((static_cast<long long>(rh) << 32) | static_cast<unsigned>(rl)));
+            }
+        };
+        using std::integral_constant;
+        v = step(v, integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{});
+        v = step(v, integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{});
+        v = step(v, integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{});
+        v = step(v, integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{});
+        v = step(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});
+        v = step(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});
+        return v;
+    };
+    const auto mn = [](F a, F b) { return fmin(a, b); };
+    const auto mx = [](F a, F b) { return fmax(a, b); };
+    lo.x = fold(lo.x, mn), lo.y = fold(lo.y, mn), lo.z = fold(lo.z, mn);
+    hi.x = fold(hi.x, mx), hi.y = fold(hi.y, mx), hi.z = fold(hi.z, mx);
+    if (lane == 63u) {
         lo.w = hi.w = F(0);
         boxes[2u * g] = lo;
         boxes[2u * g + 1u] = hi;
@@ -1300,9 +1365,7 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     auto leaf = dalloc<uint8_t>(n), ldiv = dalloc<uint8_t>(n);
     auto cnt = dalloc<uint32_t>(static_cast<size_t>(n) + 1), off = dalloc<uint32_t>(static_cast<size_t>(n) + 1);
     if (mln <= 64u) {
-        // ldiv doubles as the window scratch until k_node_counts fills it.
-        hipLaunchKernelGGL(k_windows<ND>, dim3(nblk(n)), dim3(256), 0, st, codes, n, mln, ldiv.get());
-        hipLaunchKernelGGL(k_leaf_levels_windows<ND>, dim3(nblk(n)), dim3(256), 0, st, ldiv.get(), n, mln, leaf.get());
+        hipLaunchKernelGGL(k_leaf_levels_fused<ND>, dim3(nblk(n)), dim3(256), 0, st, codes, n, mln, leaf.get());
     } else {
         hipLaunchKernelGGL(k_leaf_levels_search<ND>, dim3(nblk(n)), dim3(256), 0, st, codes, n, mln, leaf.get());
     }
@@ -1372,7 +1435,9 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     auto mask = dalloc<uint32_t>(nn + 1);
     hipLaunchKernelGGL(k_emit_nodes<ND>, dim3(nblk(n)), dim3(256), 0, st, codes, n, leaf.get(), ldiv.get(), off.get(), topo,
                        ncode, parent.get());
-    hipLaunchKernelGGL(k_parents<ND>, dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, static_cast<uint32_t>(nn), parent.get(), mask.get());
+    auto ilevel = dalloc<uint8_t>(nn);
+    hipLaunchKernelGGL(k_parents<ND>, dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, static_cast<uint32_t>(nn), parent.get(), mask.get(),
+                       ilevel.get());
     leaf.reset(), ldiv.reset(), cnt.reset(), off.reset();
 
     // ---- node properties ----
@@ -1398,7 +1463,7 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
         // Internal nodes live above the deepest leaf level: the passes of the levels below it are not launched.
         const int top = std::min(static_cast<int>(CBITS), static_cast<int>(hc.max_level)) - 1;
         for (int lvl = top; lvl >= 0; --lvl) {
-            hipLaunchKernelGGL((k_up_sums<F, ND>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, static_cast<uint32_t>(nn),
+            hipLaunchKernelGGL((k_up_sums<F, ND>), dim3(nblk(nn)), dim3(256), 0, st, topo, ilevel.get(), static_cast<uint32_t>(nn),
                                static_cast<unsigned>(lvl), sums.get());
         }
     }
