@@ -292,34 +292,11 @@ __global__ void k_leaf_levels_search(const uint64_t *codes, uint32_t n, uint32_t
 // Same result without searching, for small max_leaf_n = m: the level-L cell of particle i holds more than m
 // particles iff some window of m + 1 consecutive (sorted) particles containing i shares its first L digits, so
 //   leaf(i) = min(CBITS, 1 + max_{j in [i-m, i], j+m < n} common_levels(c[j], c[j+m]))      (0 without windows).
-// win[j] = common_levels(c[j], c[j+m]) + 1 for a valid window, 0 otherwise.
+// win[j] = common_levels(c[j], c[j+m]) + 1 for a valid window, 0 otherwise. A block computes the windows its 256 particles look
+// at (the m in front of it included) into LDS and takes the maxima from there. (Rounds 2-5: one launch for win[], one for the
+// maxima, 11 + 21 us at 4M particles against 14.)
 template <int ND>
-__global__ void k_windows(const uint64_t *codes, uint32_t n, uint32_t m, uint8_t *win)
-{
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) {
-        return;
-    }
-    win[j] = (m < n && j < n - m) ? static_cast<uint8_t>(common_levels<ND>(codes[j], codes[j + m]) + 1u) : uint8_t(0);
-}
-template <int ND>
-__global__ void k_leaf_levels_windows(const uint8_t *win, uint32_t n, uint32_t m, uint8_t *leaf)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) {
-        return;
-    }
-    unsigned best = 0;
-    for (uint32_t j = i >= m ? i - m : 0u; j <= i; ++j) {
-        best = max(best, static_cast<unsigned>(win[j]));
-    }
-    leaf[i] = static_cast<uint8_t>(min(best, geo<ND>::CB));
-}
-
-// The two kernels above in one launch: a block computes the windows its 256 particles look at (the m in front of it included)
-// into LDS and takes the maxima from there -- no win[] array, one launch less (4M particles: 11 + 21 us -> 14).
-template <int ND>
-__global__ void __launch_bounds__(256) k_leaf_levels_fused(const uint64_t *codes, uint32_t n, uint32_t m, uint8_t *leaf)
+__global__ void __launch_bounds__(256) k_leaf_levels_windows(const uint64_t *codes, uint32_t n, uint32_t m, uint8_t *leaf)
 {
     __shared__ uint8_t s_win[256 + 64];
     const uint32_t base = blockIdx.x * 256u;
@@ -1365,7 +1342,7 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     auto leaf = dalloc<uint8_t>(n), ldiv = dalloc<uint8_t>(n);
     auto cnt = dalloc<uint32_t>(static_cast<size_t>(n) + 1), off = dalloc<uint32_t>(static_cast<size_t>(n) + 1);
     if (mln <= 64u) {
-        hipLaunchKernelGGL(k_leaf_levels_fused<ND>, dim3(nblk(n)), dim3(256), 0, st, codes, n, mln, leaf.get());
+        hipLaunchKernelGGL(k_leaf_levels_windows<ND>, dim3(nblk(n)), dim3(256), 0, st, codes, n, mln, leaf.get());
     } else {
         hipLaunchKernelGGL(k_leaf_levels_search<ND>, dim3(nblk(n)), dim3(256), 0, st, codes, n, mln, leaf.get());
     }
