@@ -387,92 +387,103 @@ __global__ void __launch_bounds__(256) k_pack_nodes(ctrl_block *ctrl, const uint
     }
 }
 
-// Emit the nodes whose first particle is i. off[] = exclusive scan of cnt[] (off[n] = number of non-root nodes).
-// The nodes starting at i are nested (levels ldiv(i)..leaf(i)); their ends are found deepest first by galloping
-// from the end of the child, so a leaf of a dozen particles costs a handful of probes.
-template <int ND>
-__global__ void k_emit_nodes(const uint64_t *codes, uint32_t n, const uint8_t *leaf, const uint8_t *ldiv,
-                             const uint32_t *off, uint4 *topo, uint64_t *ncode, uint32_t *parent)
+// ---- emit the nodes: one thread per NODE ----
+// off[] = exclusive scan of cnt[] (off[n] = number of non-root nodes). The nodes whose first particle is i are nested (levels
+// ldiv(i)..leaf(i)) and consecutive in depth-first order from 1 + off[i]. k_node_starts writes, for every node, its first particle
+// (the thread of a first particle fills the 1..12 slots of its nest -- no searching); k_emit_per_node then finds the end of that one
+// node by galloping from its first particle. Rounds 2-5 gave the whole nest to the thread of the first particle, which found the ends
+// one after the other, each search starting where the previous one ended -- fewer probes in all, but the first particle of a large
+// cell walks up a dozen levels and its wavefront waits for that lane: 128 us at 4M particles against 9 + 35 (rebuild 0.945 -> 0.853 ms,
+// 1M 0.462 -> 0.425; tools/jobs_r05/r05_job47.sh).
+__global__ void k_node_starts(uint32_t n, const uint8_t *leaf, const uint8_t *ldiv, const uint32_t *off, uint32_t *start_of)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) {
         return;
     }
     const unsigned lf = leaf[i], dv = ldiv[i];
-    if (i == 0) {
-        topo[0] = make_uint4(off[n], 0u, n, 0u);
-        ncode[0] = 1ull;
-        parent[0] = 0xffffffffu;
-    }
     if (dv > lf) {
         return;
     }
+    const uint32_t o = off[i];
+    for (unsigned l = dv; l <= lf; ++l) {
+        start_of[o + (l - dv)] = i;
+    }
+}
+template <int ND>
+__global__ void k_emit_per_node(const uint64_t *codes, uint32_t n, const uint8_t *ldiv, const uint32_t *off, const uint32_t *start_of,
+                                uint32_t n_nodes, uint4 *topo, uint64_t *ncode, uint32_t *parent)
+{
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_nodes) {
+        return;
+    }
+    if (d == 0u) {
+        topo[0] = make_uint4(off[n], 0u, n, 0u);
+        ncode[0] = 1ull;
+        parent[0] = 0xffffffffu;
+        return;
+    }
+    const uint32_t i = start_of[d - 1u];
+    const unsigned dv = ldiv[i];
+    const unsigned lvl = dv + (d - 1u - off[i]);
     const uint64_t ci = codes[i];
-    const uint32_t base_dfs = 1u + off[i];
-    uint32_t hi = i + 1u; // every particle in [i, hi) is known to lie in the current node
-    for (unsigned lvl = lf; lvl >= dv; --lvl) {
-        const unsigned shift = geo<ND>::DB * (geo<ND>::CB - lvl);
-        const uint64_t p = ci >> shift;
-        // Smallest j >= hi with j == n or a different level-lvl prefix. The chain of dependent probes sets this kernel's time
-        // (the first particle of a large cell walks up a dozen levels, each probe a memory round trip), so both phases are
-        // 8-ary: the gallop grows its stride by 8, the search issues seven independent probes per step -- a third of the
-        // dependent steps of the binary forms for 2.3 x the loads.
-        uint32_t a = hi, b, step = 1u;
-        for (;;) {
-            b = a + (step - 1u);
-            if (b >= n || b < a) {
-                b = n;
-                break;
-            }
-            if ((codes[b] >> shift) != p) {
-                break;
-            }
-            a = b + 1u;
-            step = step > (1u << 28) ? step : step << 3;
+    const unsigned shift = geo<ND>::DB * (geo<ND>::CB - lvl);
+    const uint64_t p = ci >> shift;
+    // Smallest j > i with j == n or a different level-lvl prefix. Both phases are 8-ary: the gallop grows its stride by 8, the search
+    // issues seven independent probes per step -- a third of the dependent steps of the binary forms for 2.3 x the loads.
+    uint32_t a = i + 1u, b, step = 1u;
+    for (;;) {
+        b = a + (step - 1u);
+        if (b >= n || b < a) {
+            b = n;
+            break;
         }
-        // Invariant: every j < a has the prefix, b has not (or b == n).
-        while (b - a >= 8u) {
-            const uint32_t w = (b - a) >> 3;
-            uint64_t c[7];
+        if ((codes[b] >> shift) != p) {
+            break;
+        }
+        a = b + 1u;
+        step = step > (1u << 28) ? step : step << 3;
+    }
+    while (b - a >= 8u) {
+        const uint32_t w = (b - a) >> 3;
+        uint64_t c[7];
 #pragma unroll
-            for (uint32_t k = 0; k < 7u; ++k) {
-                c[k] = codes[a + w * (k + 1u)];
-            }
-            uint32_t na = a, nb = b;
-            bool found = false;
+        for (uint32_t k = 0; k < 7u; ++k) {
+            c[k] = codes[a + w * (k + 1u)];
+        }
+        uint32_t na = a, nb = b;
+        bool found = false;
 #pragma unroll
-            for (uint32_t k = 0; k < 7u; ++k) {
-                const bool same = (c[k] >> shift) == p;
-                if (!found) {
-                    if (same) {
-                        na = a + w * (k + 1u) + 1u;
-                    } else {
-                        nb = a + w * (k + 1u);
-                        found = true;
-                    }
+        for (uint32_t k = 0; k < 7u; ++k) {
+            const bool same = (c[k] >> shift) == p;
+            if (!found) {
+                if (same) {
+                    na = a + w * (k + 1u) + 1u;
+                } else {
+                    nb = a + w * (k + 1u);
+                    found = true;
                 }
             }
-            a = na, b = nb;
         }
-        {
-            // At most seven candidates left: probe them all, the prefix holds for a leading run of them.
-            uint32_t run = 0;
-            bool open = true;
-#pragma unroll
-            for (uint32_t k = 0; k < 7u; ++k) {
-                const uint32_t j = a + k;
-                const bool same = j < b && (codes[j < n ? j : n - 1u] >> shift) == p;
-                open = open && same;
-                run += open ? 1u : 0u;
-            }
-            a += run;
-        }
-        hi = a;
-        const uint32_t dfs = base_dfs + (lvl - dv);
-        const uint32_t next = 1u + off[hi]; // depth-first index of the first node starting at or after hi
-        topo[dfs] = make_uint4(next - dfs - 1u, i, hi, 0u);
-        ncode[dfs] = (1ull << (geo<ND>::DB * lvl)) | p;
+        a = na, b = nb;
     }
+    {
+        uint32_t run = 0;
+        bool open = true;
+#pragma unroll
+        for (uint32_t k = 0; k < 7u; ++k) {
+            const uint32_t j = a + k;
+            const bool same = j < b && (codes[j < n ? j : n - 1u] >> shift) == p;
+            open = open && same;
+            run += open ? 1u : 0u;
+        }
+        a += run;
+    }
+    const uint32_t hi = a;
+    const uint32_t next = 1u + off[hi]; // depth-first index of the first node starting at or after hi
+    topo[d] = make_uint4(next - d - 1u, i, hi, 0u);
+    ncode[d] = (1ull << (geo<ND>::DB * lvl)) | p;
 }
 
 template <int ND>
@@ -485,7 +496,8 @@ __device__ inline unsigned level_of(uint64_t code)
 // then skipping subtrees). (Rounds 2-5 had every child atomicOr its octant into the parent's mask in k_flags and a k_popc pass
 // count the bits: 1.4M atomics on 0.35M words and one launch more, 42 + 6 us at 4M particles.)
 template <int ND>
-__global__ void k_parents(const uint4 *topo, const uint64_t *ncode, uint32_t n_nodes, uint32_t *parent, uint32_t *mask, uint8_t *ilevel)
+__global__ void k_parents(const uint4 *topo, const uint64_t *ncode, uint32_t n_nodes, uint32_t *parent, uint32_t *mask, uint8_t *ilevel,
+                          uint32_t *kids)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_nodes) {
@@ -497,11 +509,16 @@ __global__ void k_parents(const uint4 *topo, const uint64_t *ncode, uint32_t n_n
     // Level of an internal node, 0xff for a leaf: what a level pass of the node sums has to know about the 1.4M nodes it looks at
     // (one byte instead of topo[k].x + ncode[k], 24 bytes: eleven passes at 4M particles 70 -> 52 us).
     ilevel[k] = topo[k].x != 0u ? static_cast<uint8_t>(level_of<ND>(ncode[k])) : uint8_t(0xff);
+    // kids[8 k ..]: the children of k in child order, so that the level passes of the node sums read them with two independent
+    // loads instead of walking c += topo[c].x + 1, a chain of up to eight dependent loads that set the time of every pass (4.6 us
+    // however few nodes a level has). Indexed by the node itself (32 bytes per node, touched for internal nodes only).
     const uint32_t last = k + topo[k].x;
-    uint32_t m = 0;
+    uint32_t m = 0, j = 0;
     for (uint32_t c = k + 1u; c <= last; c += topo[c].x + 1u) {
         parent[c] = k;
         m |= 1u << (static_cast<unsigned>(ncode[c]) & geo<ND>::DMASK);
+        kids[static_cast<size_t>(k) * 8u + (j & 7u)] = c;
+        ++j;
     }
     mask[k] = m;
 }
@@ -530,21 +547,33 @@ __global__ void k_leaf_sums(const uint4 *topo, uint32_t n_nodes, const typename 
 }
 
 template <typename F, int ND>
-__global__ void k_up_sums(const uint4 *topo, const uint8_t *ilevel, uint32_t n_nodes, unsigned lvl,
+__global__ void k_up_sums(const uint32_t *mask, const uint32_t *kids, const uint8_t *ilevel, uint32_t n_nodes, unsigned lvl,
                           typename vt<F>::v4 *sums)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_nodes || ilevel[k] != lvl) {
         return;
     }
+    const unsigned nch = static_cast<unsigned>(__popc(mask[k]));
+    const auto *kp = reinterpret_cast<const uint4 *>(kids + static_cast<size_t>(k) * 8u);
+    const uint4 k0 = kp[0], k1 = kp[1];
+    const uint32_t kid[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+    typename vt<F>::v4 cs[8];
+#pragma unroll
+    for (unsigned j = 0; j < 8u; ++j) {
+        if (j < nch) {
+            cs[j] = sums[kid[j]];
+        }
+    }
     F mt = F(0), sx = F(0), sy = F(0), sz = F(0);
-    const uint32_t last = k + topo[k].x;
-    for (uint32_t c = k + 1u; c <= last; c += topo[c].x + 1u) {
-        const typename vt<F>::v4 s = sums[c];
-        mt += s.w;
-        sx += s.x;
-        sy += s.y;
-        sz += s.z;
+#pragma unroll
+    for (unsigned j = 0; j < 8u; ++j) {
+        if (j < nch) {
+            mt += cs[j].w;
+            sx += cs[j].x;
+            sy += cs[j].y;
+            sz += cs[j].z;
+        }
     }
     typename vt<F>::v4 s;
     s.x = sx, s.y = sy, s.z = sz, s.w = mt;
@@ -1410,11 +1439,16 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     auto *ncode = static_cast<uint64_t *>(s.bld_node_code);
     auto parent = dalloc<uint32_t>(nn);
     auto mask = dalloc<uint32_t>(nn + 1);
-    hipLaunchKernelGGL(k_emit_nodes<ND>, dim3(nblk(n)), dim3(256), 0, st, codes, n, leaf.get(), ldiv.get(), off.get(), topo,
-                       ncode, parent.get());
+    {
+        auto start_of = dalloc<uint32_t>(nn);
+        hipLaunchKernelGGL(k_node_starts, dim3(nblk(n)), dim3(256), 0, st, n, leaf.get(), ldiv.get(), off.get(), start_of.get());
+        hipLaunchKernelGGL(k_emit_per_node<ND>, dim3(nblk(nn)), dim3(256), 0, st, codes, n, ldiv.get(), off.get(), start_of.get(),
+                           static_cast<uint32_t>(nn), topo, ncode, parent.get());
+    }
     auto ilevel = dalloc<uint8_t>(nn);
+    auto kids = dalloc<uint32_t>(nn * 8u);
     hipLaunchKernelGGL(k_parents<ND>, dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, static_cast<uint32_t>(nn), parent.get(), mask.get(),
-                       ilevel.get());
+                       ilevel.get(), kids.get());
     leaf.reset(), ldiv.reset(), cnt.reset(), off.reset();
 
     // ---- node properties ----
@@ -1440,8 +1474,8 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
         // Internal nodes live above the deepest leaf level: the passes of the levels below it are not launched.
         const int top = std::min(static_cast<int>(CBITS), static_cast<int>(hc.max_level)) - 1;
         for (int lvl = top; lvl >= 0; --lvl) {
-            hipLaunchKernelGGL((k_up_sums<F, ND>), dim3(nblk(nn)), dim3(256), 0, st, topo, ilevel.get(), static_cast<uint32_t>(nn),
-                               static_cast<unsigned>(lvl), sums.get());
+            hipLaunchKernelGGL((k_up_sums<F, ND>), dim3(nblk(nn)), dim3(256), 0, st, mask.get(), kids.get(), ilevel.get(),
+                               static_cast<uint32_t>(nn), static_cast<unsigned>(lvl), sums.get());
         }
     }
     hipLaunchKernelGGL((k_finalize<F, ND>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, static_cast<uint32_t>(nn), sums.get(),
