@@ -495,9 +495,9 @@ __device__ inline unsigned level_of(uint64_t code)
 // parent[] of every non-root node and the child-octant mask of every node, both written by the parent (children of k: k + 1,
 // then skipping subtrees). (Rounds 2-5 had every child atomicOr its octant into the parent's mask in k_flags and a k_popc pass
 // count the bits: 1.4M atomics on 0.35M words and one launch more, 42 + 6 us at 4M particles.)
-template <int ND>
+template <typename F, int ND>
 __global__ void k_parents(const uint4 *topo, const uint64_t *ncode, uint32_t n_nodes, uint32_t *parent, uint32_t *mask, uint8_t *ilevel,
-                          uint32_t *kids)
+                          uint32_t *kids, const typename vt<F>::v4 *part4, typename vt<F>::v4 *sums)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_nodes) {
@@ -505,6 +505,22 @@ __global__ void k_parents(const uint4 *topo, const uint64_t *ncode, uint32_t n_n
     }
     if (k == 0u) {
         mask[n_nodes] = 0u;
+    }
+    const uint4 t = topo[k];
+    if (t.x == 0u) {
+        // A leaf has no children to walk; its thread sums the leaf's particles instead, serially in particle order (tree.hpp:1162-1168
+        // of the reference) -- one launch for the two.
+        F mt = F(0), sx = F(0), sy = F(0), sz = F(0);
+        for (uint32_t i = t.y; i < t.z; ++i) {
+            const typename vt<F>::v4 q = part4[i];
+            mt += q.w;
+            sx = d_fma(q.w, q.x, sx);
+            sy = d_fma(q.w, q.y, sy);
+            sz = d_fma(q.w, q.z, sz);
+        }
+        typename vt<F>::v4 r;
+        r.x = sx, r.y = sy, r.z = sz, r.w = mt;
+        sums[k] = r;
     }
     // Level of an internal node, 0xff for a leaf: what a level pass of the node sums has to know about the 1.4M nodes it looks at
     // (one byte instead of topo[k].x + ncode[k], 24 bytes: eleven passes at 4M particles 70 -> 52 us).
@@ -524,36 +540,10 @@ __global__ void k_parents(const uint4 *topo, const uint64_t *ncode, uint32_t n_n
 }
 
 // ---- node properties --------------------------------------------------------------------------------------
+// Sum of the sums of k's children, in child order.
 template <typename F>
-__global__ void k_leaf_sums(const uint4 *topo, uint32_t n_nodes, const typename vt<F>::v4 *part4,
-                            typename vt<F>::v4 *sums)
+__device__ inline typename vt<F>::v4 children_sum(const uint32_t *mask, const uint32_t *kids, const typename vt<F>::v4 *sums, uint32_t k)
 {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_nodes || topo[k].x != 0u) {
-        return;
-    }
-    // Serial summation in particle order (tree.hpp:1162-1168 of the reference).
-    F mt = F(0), sx = F(0), sy = F(0), sz = F(0);
-    for (uint32_t i = topo[k].y; i < topo[k].z; ++i) {
-        const typename vt<F>::v4 p = part4[i];
-        mt += p.w;
-        sx = d_fma(p.w, p.x, sx);
-        sy = d_fma(p.w, p.y, sy);
-        sz = d_fma(p.w, p.z, sz);
-    }
-    typename vt<F>::v4 s;
-    s.x = sx, s.y = sy, s.z = sz, s.w = mt;
-    sums[k] = s;
-}
-
-template <typename F, int ND>
-__global__ void k_up_sums(const uint32_t *mask, const uint32_t *kids, const uint8_t *ilevel, uint32_t n_nodes, unsigned lvl,
-                          typename vt<F>::v4 *sums)
-{
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_nodes || ilevel[k] != lvl) {
-        return;
-    }
     const unsigned nch = static_cast<unsigned>(__popc(mask[k]));
     const auto *kp = reinterpret_cast<const uint4 *>(kids + static_cast<size_t>(k) * 8u);
     const uint4 k0 = kp[0], k1 = kp[1];
@@ -577,15 +567,26 @@ __global__ void k_up_sums(const uint32_t *mask, const uint32_t *kids, const uint
     }
     typename vt<F>::v4 s;
     s.x = sx, s.y = sy, s.z = sz, s.w = mt;
-    sums[k] = s;
+    return s;
 }
-
+template <typename F, int ND>
+__global__ void k_up_sums(const uint32_t *mask, const uint32_t *kids, const uint8_t *ilevel, uint32_t n_nodes, unsigned lvl,
+                          typename vt<F>::v4 *sums)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_nodes || ilevel[k] != lvl) {
+        return;
+    }
+    sums[k] = children_sum<F>(mask, kids, sums, k);
+}
 // (Round 5, built and measured, not kept -- tools/jobs_r05/r05_job37.sh, r05_job38.sh: (1) leaf sums and all levels in ONE launch,
 // the last child to deliver its sum adds up the parent (atomic counters): on eight XCDs every release / acquire pair is an L2
 // write-back + invalidate, 2.1 ms instead of 0.07 at 4M particles; (2) two or three levels per launch, the upper ones recomputing
 // the sums of their internal children instead of reading them: the walk over a node's children is a chain of dependent loads
 // (c += topo[c].x + 1), nested it is 72 deep -- rebuild +0.03 ms at 100k, +0.07 at 4M for two levels, +0.13 / +0.35 for three.
-// A level pass costs what its chain of eight dependent loads costs, 4.5 us, not what an empty launch costs.)
+// (3) the top five levels in ONE launch of one workgroup (the internal nodes found from the root through the child table into LDS
+// queues, then summed level by level between barriers): 24 us at 100k particles and 52 us at 4M for the five ~5 us passes it replaced --
+// a lone workgroup pays every dependent load in full (tools/jobs_r05/r05_job50.sh, r05_job51.sh).)
 
 // ---- node sums in the reference's association (exact mode) ----
 // The reference sums a node's particles serially in particle order (tree.hpp:1162-1168). Nodes that start at the same
@@ -795,13 +796,9 @@ __global__ void __launch_bounds__(256) k_exact_chains_wave(const uint4 *topo, co
 }
 
 template <typename F, int ND>
-__global__ void k_finalize(const uint4 *topo, const uint64_t *ncode, uint32_t n_nodes, const typename vt<F>::v4 *sums,
-                           F box, int mac, typename vt<F>::v4 *node_com, typename vt<F>::v2 *node_mac, ctrl_block *ctrl)
+__device__ inline void finalize_node(uint32_t k, const uint64_t *ncode, const typename vt<F>::v4 *sums, F box, int mac,
+                                     typename vt<F>::v4 *node_com, typename vt<F>::v2 *node_mac, ctrl_block *ctrl)
 {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_nodes) {
-        return;
-    }
     const uint64_t code = ncode[k];
     const unsigned lvl = level_of<ND>(code);
     const typename vt<F>::v4 s = sums[k];
@@ -859,14 +856,10 @@ struct tri_sum {
 };
 
 // MASKS_DONE: the child masks are complete (k_parents of the device build); the child count is taken here, no k_popc pass.
-template <int ND, bool MASKS_DONE = false>
-__global__ void k_flags(const uint4 *topo, const uint64_t *ncode, const uint32_t *parent, uint32_t n_nodes,
-                        uint32_t ncrit_clamped, tri *flags, uint32_t *mask)
+template <int ND, bool MASKS_DONE>
+__device__ inline void flags_node(uint32_t k, const uint4 *topo, const uint64_t *ncode, const uint32_t *parent, uint32_t n_nodes,
+                                  uint32_t ncrit_clamped, tri *flags, uint32_t *mask)
 {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_nodes) {
-        return;
-    }
     auto cand = [&](uint32_t j) { return (topo[j].z - topo[j].y) <= ncrit_clamped || topo[j].x == 0u; };
     const bool c = cand(k);
     // A parent lies before its children in depth-first order. An index that does not (the sentinel convert_device() leaves in
@@ -890,6 +883,28 @@ __global__ void k_flags(const uint4 *topo, const uint64_t *ncode, const uint32_t
     }
 }
 
+template <int ND>
+__global__ void k_flags(const uint4 *topo, const uint64_t *ncode, const uint32_t *parent, uint32_t n_nodes,
+                        uint32_t ncrit_clamped, tri *flags, uint32_t *mask)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_nodes) {
+        flags_node<ND, false>(k, topo, ncode, parent, n_nodes, ncrit_clamped, flags, mask);
+    }
+}
+// Device build: centre of mass / size of a node and its flags in one launch (two independent things per node).
+template <typename F, int ND>
+__global__ void k_finalize_flags(const uint4 *topo, const uint64_t *ncode, const uint32_t *parent, uint32_t n_nodes,
+                                 const typename vt<F>::v4 *sums, F box, int mac, typename vt<F>::v4 *node_com,
+                                 typename vt<F>::v2 *node_mac, ctrl_block *ctrl, uint32_t ncrit_clamped, tri *flags, uint32_t *mask)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_nodes) {
+        finalize_node<F, ND>(k, ncode, sums, box, mac, node_com, node_mac, ctrl);
+        flags_node<ND, true>(k, topo, ncode, parent, n_nodes, ncrit_clamped, flags, mask);
+    }
+}
+
 __global__ void k_popc(const uint32_t *mask, uint32_t n_nodes, tri *flags)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -905,11 +920,19 @@ __global__ void k_pack_counts(ctrl_block *ctrl, const tri *total)
     ctrl->n_children = total->c;
 }
 
+// (Also clears the child table k_records fills afterwards -- a memset's launch less: thread k takes words [k zper, (k + 1) zper).)
 template <typename F>
-__global__ void k_crit(const uint4 *topo, const tri *flags, const tri *offs, uint32_t n_nodes, uint4 *crit)
+__global__ void k_crit(const uint4 *topo, const tri *flags, const tri *offs, uint32_t n_nodes, uint4 *crit, uint32_t *child_tab,
+                       uint32_t tab_words, uint32_t zper)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_nodes || !flags[k].a) {
+    if (k >= n_nodes) {
+        return;
+    }
+    for (size_t w = static_cast<size_t>(k) * zper, e = min(w + zper, static_cast<size_t>(tab_words)); w < e; ++w) {
+        child_tab[w] = 0u;
+    }
+    if (!flags[k].a) {
         return;
     }
     const uint32_t g = offs[k].a, b = topo[k].y, e = topo[k].z;
@@ -1027,18 +1050,31 @@ __global__ void k_first_keys(const uint4 *crit, uint32_t n_crit, uint32_t *keys,
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g < n_crit) {
         const uint32_t size = crit[g].w;
-        keys[g] = (size == 0u || size > 64u * RK_MAX_R) ? (1u << FIRST_ORDER_KEY_BITS) - 1u : (64u * RK_MAX_R - size) >> 1;
+        keys[g] = (size == 0u || size > 64u * RK_MAX_R) ? (1u << FIRST_ORDER_KEY_BITS) - 1u : (64u * RK_MAX_R - size) >> 1; // = first_key(size)
         vals[g] = g;
     }
 }
 
-__global__ void k_bin_count(const uint4 *crit, uint32_t n_crit, uint32_t *block_hist, ctrl_block *ctrl)
+// The three kernels below also make the first-call launch order of small trees when they are handed key_hist / first_order: the same
+// stable partition over the 256 keys of k_first_keys -- per-block histograms, a scan per key over the blocks, a scatter that ranks
+// every node among the equal keys of its block (wavefront: the lanes with the same key from eight ballots; block: counts per wave
+// in LDS). Rounds 4-5 sorted (key, index) pairs with the library afterwards: 4-8 launches of ~5 us each on a 100k-particle tree.
+constexpr unsigned NKEY = 1u << FIRST_ORDER_KEY_BITS;
+__device__ inline uint32_t first_key(uint32_t size)
+{
+    return (size == 0u || size > 64u * RK_MAX_R) ? NKEY - 1u : (64u * RK_MAX_R - size) >> 1;
+}
+__global__ void __launch_bounds__(256) k_bin_count(const uint4 *crit, uint32_t n_crit, uint32_t *block_hist, ctrl_block *ctrl,
+                                                   uint32_t *key_hist)
 {
     __shared__ uint32_t h[NBIN];
+    __shared__ uint32_t hk[NKEY];
     __shared__ uint32_t mx;
     if (threadIdx.x < NBIN) {
         h[threadIdx.x] = 0u;
     }
+    hk[threadIdx.x] = 0u;
+    static_assert(NKEY == 256u, "one key counter per thread of the block");
     if (threadIdx.x == 0u) {
         mx = 0u;
     }
@@ -1048,10 +1084,16 @@ __global__ void k_bin_count(const uint4 *crit, uint32_t n_crit, uint32_t *block_
         const uint32_t size = crit[g].w;
         atomicAdd(&h[class2_of_compute(size)], 1u);
         atomicMax(&mx, size);
+        if (key_hist) {
+            atomicAdd(&hk[first_key(size)], 1u);
+        }
     }
     __syncthreads();
     if (threadIdx.x < NBIN) {
         block_hist[blockIdx.x * NBIN + threadIdx.x] = h[threadIdx.x];
+    }
+    if (key_hist) {
+        key_hist[blockIdx.x * NKEY + threadIdx.x] = hk[threadIdx.x];
     }
     if (threadIdx.x == 0u) {
         atomicMax(&ctrl->max_group, mx);
@@ -1060,16 +1102,20 @@ __global__ void k_bin_count(const uint4 *crit, uint32_t n_crit, uint32_t *block_
 
 // Exclusive scan of the per-block counts of one bin (blockIdx.x) over the blocks: 256 threads take contiguous runs of
 // blocks each, their run totals are scanned in LDS. (One thread per bin walking all blocks took 57 us at 4M particles and
-// grew with the particle count: 5 % of a tree rebuild.)
-__global__ void __launch_bounds__(256) k_bin_scan(uint32_t *block_hist, uint32_t n_blocks, ctrl_block *ctrl)
+// grew with the particle count: 5 % of a tree rebuild.) Blocks NBIN .. NBIN + NKEY - 1 do the same for the keys of the first-call
+// order (stride NKEY, totals to key_total).
+__global__ void __launch_bounds__(256) k_bin_scan(uint32_t *block_hist, uint32_t n_blocks, ctrl_block *ctrl, uint32_t *key_hist,
+                                                  uint32_t *key_total)
 {
     __shared__ uint32_t part[256];
-    const uint32_t c = blockIdx.x, t = threadIdx.x;
+    const bool keys = blockIdx.x >= NBIN;
+    const uint32_t c = keys ? blockIdx.x - NBIN : blockIdx.x, t = threadIdx.x, stride = keys ? NKEY : NBIN;
+    uint32_t *hist = keys ? key_hist : block_hist;
     const uint32_t per = (n_blocks + 255u) / 256u;
     const uint32_t b0 = t * per < n_blocks ? t * per : n_blocks, b1 = b0 + per < n_blocks ? b0 + per : n_blocks;
     uint32_t sum = 0u;
     for (uint32_t b = b0; b < b1; ++b) {
-        sum += block_hist[b * NBIN + c];
+        sum += hist[b * stride + c];
     }
     part[t] = sum;
     __syncthreads();
@@ -1082,22 +1128,31 @@ __global__ void __launch_bounds__(256) k_bin_scan(uint32_t *block_hist, uint32_t
     }
     uint32_t run = part[t] - sum; // exclusive prefix of this thread's run
     for (uint32_t b = b0; b < b1; ++b) {
-        const uint32_t v = block_hist[b * NBIN + c];
-        block_hist[b * NBIN + c] = run;
+        const uint32_t v = hist[b * stride + c];
+        hist[b * stride + c] = run;
         run += v;
     }
     if (t == 255u) {
-        ctrl->class2_count[c] = part[255];
+        if (keys) {
+            key_total[c] = part[255];
+        } else {
+            ctrl->class2_count[c] = part[255];
+        }
     }
 }
 
 __global__ void __launch_bounds__(256) k_bin_scatter(const uint4 *crit, uint32_t n_crit, const uint32_t *block_base,
-                                                     const ctrl_block *ctrl, uint32_t *lists)
+                                                     const ctrl_block *ctrl, uint32_t *lists, const uint32_t *key_base,
+                                                     const uint32_t *key_total, uint32_t *first_order)
 {
     __shared__ uint32_t wave_cnt[4][NBIN];
+    __shared__ uint32_t wave_key[4][NKEY];
+    __shared__ uint32_t key_off[NKEY];
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    const unsigned c = g < n_crit ? static_cast<unsigned>(class2_of_compute(crit[g].w)) : NBIN;
+    const bool valid = g < n_crit;
+    const uint32_t size = valid ? crit[g].w : 0u;
+    const unsigned c = valid ? static_cast<unsigned>(class2_of_compute(size)) : NBIN;
     uint32_t rank = 0u;
 #pragma unroll
     for (unsigned b = 0; b < NBIN; ++b) {
@@ -1109,8 +1164,38 @@ __global__ void __launch_bounds__(256) k_bin_scatter(const uint4 *crit, uint32_t
             wave_cnt[w][b] = static_cast<uint32_t>(__popcll(m));
         }
     }
+    uint32_t key = 0u, krank = 0u;
+    if (first_order) {
+        // Exclusive scan of the key totals (every block for itself: 256 values) and the counts per wavefront and key.
+        key_off[threadIdx.x] = key_total[threadIdx.x];
+#pragma unroll
+        for (unsigned k = 0; k < 4u; ++k) {
+            wave_key[k][threadIdx.x] = 0u;
+        }
+        __syncthreads();
+        for (uint32_t d = 1u; d < NKEY; d <<= 1) {
+            const uint32_t v = threadIdx.x >= d ? key_off[threadIdx.x - d] : 0u;
+            __syncthreads();
+            key_off[threadIdx.x] += v;
+            __syncthreads();
+        }
+        key = first_key(size);
+        unsigned long long same = __ballot(valid);
+#pragma unroll
+        for (unsigned b = 0; b < FIRST_ORDER_KEY_BITS; ++b) {
+            const bool bit = (key >> b) & 1u;
+            const unsigned long long m = __ballot(valid && bit);
+            same &= bit ? m : ~m;
+        }
+        if (valid) {
+            krank = static_cast<uint32_t>(__popcll(same & ((1ull << lane) - 1ull)));
+            if (krank == 0u) {
+                wave_key[w][key] = static_cast<uint32_t>(__popcll(same));
+            }
+        }
+    }
     __syncthreads();
-    if (c >= NBIN) {
+    if (!valid) {
         return;
     }
     uint32_t pos = block_base[blockIdx.x * NBIN + c] + rank;
@@ -1121,6 +1206,14 @@ __global__ void __launch_bounds__(256) k_bin_scatter(const uint4 *crit, uint32_t
         pos += ctrl->class2_count[b];
     }
     lists[pos] = g;
+    if (first_order) {
+        // (inclusive scan - own total = exclusive offset of the key)
+        uint32_t kpos = key_off[key] - key_total[key] + key_base[blockIdx.x * NKEY + key] + krank;
+        for (unsigned k = 0; k < w; ++k) {
+            kpos += wave_key[k][key];
+        }
+        first_order[kpos] = g;
+    }
 }
 
 struct dev_free {
@@ -1447,17 +1540,15 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     }
     auto ilevel = dalloc<uint8_t>(nn);
     auto kids = dalloc<uint32_t>(nn * 8u);
-    hipLaunchKernelGGL(k_parents<ND>, dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, static_cast<uint32_t>(nn), parent.get(), mask.get(),
-                       ilevel.get(), kids.get());
+    auto sums = dalloc<v4>(nn);
+    hipLaunchKernelGGL((k_parents<F, ND>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, static_cast<uint32_t>(nn), parent.get(),
+                       mask.get(), ilevel.get(), kids.get(), static_cast<const v4 *>(p4), sums.get());
     leaf.reset(), ldiv.reset(), cnt.reset(), off.reset();
 
-    // ---- node properties ----
-    auto sums = dalloc<v4>(nn);
+    // ---- node properties (the leaves have their sums from k_parents) ----
     if (exact_node_sums()) {
         // The reference's association (bit-identical node properties): one serial chain per distinct first particle, all
         // at once; the root's N links set the time (~25 ms at 4M particles).
-        hipLaunchKernelGGL((k_leaf_sums<F>), dim3(nblk(nn)), dim3(256), 0, st, topo, static_cast<uint32_t>(nn),
-                           static_cast<const v4 *>(p4), sums.get());
         const auto max_big = static_cast<unsigned>(static_cast<size_t>(n) / EXACT_WAVE_MIN * (CBITS + 1u) + 2u);
         auto big = dalloc<uint32_t>(static_cast<size_t>(max_big) + 1u);
         // Slot 0 is the root's; the counter starts behind it.
@@ -1469,8 +1560,6 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
         hipLaunchKernelGGL((k_exact_chains_wave<F>), dim3(std::min<unsigned>(max_big, static_cast<unsigned>(nn))), dim3(256), 0, st,
                            topo, big.get(), big.get() + max_big, static_cast<const v4 *>(p4), sums.get());
     } else {
-        hipLaunchKernelGGL((k_leaf_sums<F>), dim3(nblk(nn)), dim3(256), 0, st, topo, static_cast<uint32_t>(nn),
-                           static_cast<const v4 *>(p4), sums.get());
         // Internal nodes live above the deepest leaf level: the passes of the levels below it are not launched.
         const int top = std::min(static_cast<int>(CBITS), static_cast<int>(hc.max_level)) - 1;
         for (int lvl = top; lvl >= 0; --lvl) {
@@ -1478,15 +1567,12 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
                                static_cast<uint32_t>(nn), static_cast<unsigned>(lvl), sums.get());
         }
     }
-    hipLaunchKernelGGL((k_finalize<F, ND>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, static_cast<uint32_t>(nn), sums.get(),
-                       box, s.mac, node_com, node_mac, ctrl.get());
-    sums.reset();
-
-    // ---- critical nodes, child masks: one scan of three counters ----
+    // ---- centres of mass, critical nodes, child counts: one scan of three counters ----
     const auto ncrit_c = static_cast<uint32_t>(std::min<uint64_t>(s.ncrit, 0xffffffffu));
     auto flags = dalloc<tri>(nn + 1), offs = dalloc<tri>(nn + 1);
-    hipLaunchKernelGGL((k_flags<ND, true>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, parent.get(), static_cast<uint32_t>(nn),
-                       ncrit_c, flags.get(), mask.get());
+    hipLaunchKernelGGL((k_finalize_flags<F, ND>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, parent.get(), static_cast<uint32_t>(nn),
+                       sums.get(), box, s.mac, node_com, node_mac, ctrl.get(), ncrit_c, flags.get(), mask.get());
+    sums.reset();
     exclusive_scan(flags.get(), offs.get(), nn, st);
     hipLaunchKernelGGL(k_pack_counts, dim3(1), dim3(1), 0, st, ctrl.get(), offs.get() + nn);
 
@@ -1506,8 +1592,12 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     auto *crit = static_cast<uint4 *>(alloc_buf(RK_BUF_CRIT, static_cast<size_t>(n_crit) * sizeof(uint4)));
     auto *boxes = static_cast<v4 *>(alloc_buf(RK_BUF_CRIT_BOX, static_cast<size_t>(n_crit) * 2 * sizeof(v4)));
     auto *child_tab = static_cast<uint32_t *>(alloc_buf(RK_BUF_CHILD, static_cast<size_t>(n_int) * 8 * sizeof(uint32_t)));
-    RK_HIP(hipMemsetAsync(child_tab, 0, std::max<size_t>(static_cast<size_t>(n_int) * 8 * sizeof(uint32_t), 16), st));
-    hipLaunchKernelGGL((k_crit<F>), dim3(nblk(nn)), dim3(256), 0, st, topo, flags.get(), offs.get(), static_cast<uint32_t>(nn), crit);
+    {
+        const auto tab_words = static_cast<uint32_t>(static_cast<size_t>(n_int) * 8u);
+        const auto zper = static_cast<uint32_t>((static_cast<size_t>(tab_words) + nn - 1u) / nn);
+        hipLaunchKernelGGL((k_crit<F>), dim3(nblk(nn)), dim3(256), 0, st, topo, flags.get(), offs.get(), static_cast<uint32_t>(nn), crit,
+                           child_tab, tab_words, zper);
+    }
     hipLaunchKernelGGL((k_crit_boxes<F>), dim3((n_crit + 3u) / 4u), dim3(256), 0, st, crit, n_crit, static_cast<const v4 *>(p4), boxes);
     hipLaunchKernelGGL((k_records<F, ND>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, parent.get(), mask.get(), offs.get(),
                        static_cast<uint32_t>(nn), node_com, node_mac, recs, child_tab);
@@ -1517,13 +1607,24 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     auto *lists = static_cast<uint32_t *>(alloc_buf(RK_BUF_CLASS, static_cast<size_t>(n_crit) * 2 * sizeof(uint32_t)));
     const unsigned nb = nblk(n_crit);
     auto hist = dalloc<uint32_t>(static_cast<size_t>(nb) * NBIN);
-    hipLaunchKernelGGL(k_bin_count, dim3(nb), dim3(256), 0, st, crit, n_crit, hist.get(), ctrl.get());
-    hipLaunchKernelGGL(k_bin_scan, dim3(NBIN), dim3(256), 0, st, hist.get(), nb, ctrl.get());
-    hipLaunchKernelGGL(k_bin_scatter, dim3(nb), dim3(256), 0, st, crit, n_crit, hist.get(), ctrl.get(), lists + n_crit);
-    s.first_order_valid = false;
-    if (first_order_enabled() && n_crit <= FIRST_ORDER_MAX) {
-        make_first_order(s, crit, n_crit, st);
+    // (with the launch order of the first call on a small tree: see k_first_keys)
+    const bool want_first = first_order_enabled() && n_crit <= FIRST_ORDER_MAX;
+    dptr<uint32_t> key_hist;
+    uint32_t *key_total = nullptr;
+    if (want_first) {
+        if (!s.first_order) {
+            s.first_order = pool_alloc(FIRST_ORDER_MAX * sizeof(uint32_t));
+        }
+        key_hist = dalloc<uint32_t>(static_cast<size_t>(nb) * NKEY + NKEY);
+        key_total = key_hist.get() + static_cast<size_t>(nb) * NKEY;
     }
+    auto *first_order = want_first ? static_cast<uint32_t *>(s.first_order) : nullptr;
+    hipLaunchKernelGGL(k_bin_count, dim3(nb), dim3(256), 0, st, crit, n_crit, hist.get(), ctrl.get(), key_hist.get());
+    hipLaunchKernelGGL(k_bin_scan, dim3(NBIN + (want_first ? NKEY : 0u)), dim3(256), 0, st, hist.get(), nb, ctrl.get(), key_hist.get(),
+                       key_total);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(nb), dim3(256), 0, st, crit, n_crit, hist.get(), ctrl.get(), lists + n_crit, key_hist.get(),
+                       key_total, first_order);
+    s.first_order_valid = want_first;
 
     // ---- third round trip: class sizes (also the final synchronisation) ----
     fetch_ctrl();
@@ -1717,8 +1818,12 @@ void convert_device(rk_state &s, const void *const parts[4], int64_t nparts, con
     auto *crit = static_cast<uint4 *>(alloc_buf(RK_BUF_CRIT, static_cast<size_t>(n_crit) * sizeof(uint4)));
     auto *boxes = static_cast<v4 *>(alloc_buf(RK_BUF_CRIT_BOX, static_cast<size_t>(n_crit) * 2 * sizeof(v4)));
     auto *child_tab = static_cast<uint32_t *>(alloc_buf(RK_BUF_CHILD, static_cast<size_t>(n_int) * 8 * sizeof(uint32_t)));
-    RK_HIP(hipMemsetAsync(child_tab, 0, std::max<size_t>(static_cast<size_t>(n_int) * 8 * sizeof(uint32_t), 16), st));
-    hipLaunchKernelGGL((k_crit<F>), dim3(nblk(nn)), dim3(256), 0, st, topo, flags.get(), offs.get(), static_cast<uint32_t>(nn), crit);
+    {
+        const auto tab_words = static_cast<uint32_t>(static_cast<size_t>(n_int) * 8u);
+        const auto zper = static_cast<uint32_t>((static_cast<size_t>(tab_words) + nn - 1u) / nn);
+        hipLaunchKernelGGL((k_crit<F>), dim3(nblk(nn)), dim3(256), 0, st, topo, flags.get(), offs.get(), static_cast<uint32_t>(nn), crit,
+                           child_tab, tab_words, zper);
+    }
     hipLaunchKernelGGL((k_crit_boxes<F>), dim3((n_crit + 3u) / 4u), dim3(256), 0, st, crit, n_crit, static_cast<const v4 *>(p4), boxes);
     hipLaunchKernelGGL(k_check_tiling, dim3(nblk(n_crit)), dim3(256), 0, st, crit, n_crit, n, ctrl.get());
     hipLaunchKernelGGL((k_records<F, ND>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode.get(), parent.get(), mask.get(), offs.get(),
@@ -1727,13 +1832,24 @@ void convert_device(rk_state &s, const void *const parts[4], int64_t nparts, con
     auto *lists = static_cast<uint32_t *>(alloc_buf(RK_BUF_CLASS, static_cast<size_t>(n_crit) * 2 * sizeof(uint32_t)));
     const unsigned nb = nblk(n_crit);
     auto hist = dalloc<uint32_t>(static_cast<size_t>(nb) * NBIN);
-    hipLaunchKernelGGL(k_bin_count, dim3(nb), dim3(256), 0, st, crit, n_crit, hist.get(), ctrl.get());
-    hipLaunchKernelGGL(k_bin_scan, dim3(NBIN), dim3(256), 0, st, hist.get(), nb, ctrl.get());
-    hipLaunchKernelGGL(k_bin_scatter, dim3(nb), dim3(256), 0, st, crit, n_crit, hist.get(), ctrl.get(), lists + n_crit);
-    s.first_order_valid = false;
-    if (first_order_enabled() && n_crit <= FIRST_ORDER_MAX) {
-        make_first_order(s, crit, n_crit, st);
+    // (with the launch order of the first call on a small tree: see k_first_keys)
+    const bool want_first = first_order_enabled() && n_crit <= FIRST_ORDER_MAX;
+    dptr<uint32_t> key_hist;
+    uint32_t *key_total = nullptr;
+    if (want_first) {
+        if (!s.first_order) {
+            s.first_order = pool_alloc(FIRST_ORDER_MAX * sizeof(uint32_t));
+        }
+        key_hist = dalloc<uint32_t>(static_cast<size_t>(nb) * NKEY + NKEY);
+        key_total = key_hist.get() + static_cast<size_t>(nb) * NKEY;
     }
+    auto *first_order = want_first ? static_cast<uint32_t *>(s.first_order) : nullptr;
+    hipLaunchKernelGGL(k_bin_count, dim3(nb), dim3(256), 0, st, crit, n_crit, hist.get(), ctrl.get(), key_hist.get());
+    hipLaunchKernelGGL(k_bin_scan, dim3(NBIN + (want_first ? NKEY : 0u)), dim3(256), 0, st, hist.get(), nb, ctrl.get(), key_hist.get(),
+                       key_total);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(nb), dim3(256), 0, st, crit, n_crit, hist.get(), ctrl.get(), lists + n_crit, key_hist.get(),
+                       key_total, first_order);
+    s.first_order_valid = want_first;
     fetch_ctrl();
     RK_HIP(hipGetLastError());
     if (hc.pad[2]) {
