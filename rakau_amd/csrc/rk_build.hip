@@ -114,7 +114,7 @@ struct ctrl_block {
     unsigned n_crit, n_int, n_children; // critical nodes, internal nodes, sum of child counts
     unsigned max_group;         // particles in the largest critical node
     unsigned class2_count[8];   // critical nodes per lane-mapping class (list kernel binning)
-    unsigned max_level;         // deepest leaf level of the tree (levels below it have no nodes: their passes are not launched)
+    unsigned max_level;         // (unused since the node sums come from the summation pyramid)
     unsigned pad[4];
 };
 enum { ERR_COORD = 1u, ERR_COM = 2u, ERR_DIM = 4u, ERR_BOX = 8u };
@@ -295,11 +295,21 @@ __global__ void k_leaf_levels_search(const uint64_t *codes, uint32_t n, uint32_t
 // win[j] = common_levels(c[j], c[j+m]) + 1 for a valid window, 0 otherwise. A block computes the windows its 256 particles look
 // at (the m in front of it included) into LDS and takes the maxima from there. (Rounds 2-5: one launch for win[], one for the
 // maxima, 11 + 21 us at 4M particles against 14.)
-template <int ND>
-__global__ void __launch_bounds__(256) k_leaf_levels_windows(const uint64_t *codes, uint32_t n, uint32_t m, uint8_t *leaf)
+// The same launch takes the node counts of k_node_counts (each particle's own leaf level and its two neighbouring codes are all they
+// need) and puts the particles into tree order (k_permute: nothing to do with the levels, but one launch less).
+template <typename F, int ND>
+__global__ void __launch_bounds__(256) k_leaf_levels_windows(const uint64_t *codes, uint32_t n, uint32_t m, uint8_t *leaf, uint8_t *ldiv,
+                                                             uint32_t *cnt, const F *px, const F *py, const F *pz, const F *pm,
+                                                             const uint32_t *order, typename vt<F>::v4 *part4)
 {
     __shared__ uint8_t s_win[256 + 64];
     const uint32_t base = blockIdx.x * 256u;
+    if (base + threadIdx.x < n) {
+        const uint32_t src = order[base + threadIdx.x];
+        typename vt<F>::v4 q;
+        q.x = px[src], q.y = py[src], q.z = pz ? pz[src] : F(0), q.w = pm[src];
+        part4[base + threadIdx.x] = q;
+    }
     for (uint32_t t = threadIdx.x; t < 256u + m; t += 256u) {
         // window j = base - m + t (none in front of particle 0)
         const bool have = base + t >= m;
@@ -315,76 +325,39 @@ __global__ void __launch_bounds__(256) k_leaf_levels_windows(const uint64_t *cod
     for (uint32_t t = threadIdx.x; t <= threadIdx.x + m; ++t) { // windows i - m .. i
         best = max(best, static_cast<unsigned>(s_win[t]));
     }
-    leaf[i] = static_cast<uint8_t>(min(best, geo<ND>::CB));
+    const unsigned lvl = min(best, geo<ND>::CB);
+    leaf[i] = static_cast<uint8_t>(lvl);
+    const unsigned dv = i > 0 ? common_levels<ND>(codes[i - 1], codes[i]) + 1u : 1u; // identical codes never start a node
+    ldiv[i] = static_cast<uint8_t>(dv);
+    cnt[i] = dv <= lvl ? lvl - dv + 1u : 0u;
+    if (i == 0u) {
+        cnt[n] = 0u; // the scan runs over n + 1 values so that off[n] is the total
+    }
 }
 
 // ldiv[i] = first level at which c[i] leaves the cell of c[i-1]; cnt[i] = number of nodes whose first particle is i.
 template <int ND>
-__global__ void k_node_counts(const uint64_t *codes, uint32_t n, const uint8_t *leaf, uint8_t *ldiv, uint32_t *cnt,
-                              uint8_t *block_max)
+__global__ void k_node_counts(const uint64_t *codes, uint32_t n, const uint8_t *leaf, uint8_t *ldiv, uint32_t *cnt)
 {
-    __shared__ unsigned s_max;
-    if (threadIdx.x == 0u) {
-        s_max = 0u;
-    }
-    __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned lvl = 0u;
     if (i < n) {
         // Identical codes never start a node.
         const unsigned dv = i > 0 ? common_levels<ND>(codes[i - 1], codes[i]) + 1u : 1u;
-        lvl = leaf[i];
+        const unsigned lvl = leaf[i];
         ldiv[i] = static_cast<uint8_t>(dv);
         cnt[i] = dv <= lvl ? lvl - dv + 1u : 0u;
         if (i == 0u) {
             cnt[n] = 0u; // the scan runs over n + 1 values so that off[n] is the total
         }
     }
-    // Deepest level of the block: levels are below 32, so the wavefront's maximum is the highest bit of the OR of (1 << level)
-    // over its lanes (a DPP reduction), one LDS atomic per wavefront instead of one per thread.
-    const unsigned any = wave_reduce_or(1u << (lvl & 31u));
-    if ((threadIdx.x & 63u) == 0u) {
-        atomicMax(&s_max, 31u - static_cast<unsigned>(__clz(static_cast<int>(any))));
-    }
-    __syncthreads();
-    // One plain store per block, reduced by k_pack_nodes. (Round 4: one atomicMax per block on ONE word of the control block,
-    // ~10 ns each, serialised: 150 us at 4M particles. Round 5: an agent-scope load of that word per block and the atomic only when
-    // it would raise it -- still 15 600 same-address requests past the L2, 62 us against 20 for the kernel's real work.)
-    if (threadIdx.x == 0u) {
-        block_max[blockIdx.x] = static_cast<uint8_t>(s_max);
-    }
 }
+// (Rounds 2-5 also reduced the deepest leaf level here, for the host to skip the empty level passes of the node sums: first with one
+// atomicMax per block on one word of the control block -- 15 600 same-address atomics, 150 us at 4M particles --, then with an
+// agent-scope load of that word per block, 62 us against 14 for the kernel's own work. The level passes are gone.)
 
-// One block: the node count (total of the scan) and the deepest leaf level (maximum over k_node_counts' blocks) for the host.
-__global__ void __launch_bounds__(256) k_pack_nodes(ctrl_block *ctrl, const uint32_t *off_n, const uint8_t *block_max, uint32_t n_blocks)
+__global__ void k_pack_nodes(ctrl_block *ctrl, const uint32_t *off_n)
 {
-    __shared__ unsigned s_max;
-    if (threadIdx.x == 0u) {
-        s_max = 0u;
-        ctrl->n_nonroot = *off_n;
-    }
-    __syncthreads();
-    // Sixteen bytes per load (the array is 16-byte aligned: it comes from the block cache): a byte per iteration was 61 dependent
-    // round trips per thread at 4M particles, 18 us. Levels are below 32, the OR of (1 << level) carries the maximum.
-    unsigned any = 1u;
-    const uint32_t n16 = n_blocks / 16u;
-    const auto *v = reinterpret_cast<const uint4 *>(block_max);
-    for (uint32_t g = threadIdx.x; g < n16; g += blockDim.x) {
-        const uint4 q = v[g];
-        const unsigned w[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            any |= (1u << (w[j] & 31u)) | (1u << ((w[j] >> 8) & 31u)) | (1u << ((w[j] >> 16) & 31u)) | (1u << ((w[j] >> 24) & 31u));
-        }
-    }
-    for (uint32_t b = n16 * 16u + threadIdx.x; b < n_blocks; b += blockDim.x) {
-        any |= 1u << (block_max[b] & 31u);
-    }
-    atomicMax(&s_max, 31u - static_cast<unsigned>(__clz(static_cast<int>(any))));
-    __syncthreads();
-    if (threadIdx.x == 0u) {
-        ctrl->max_level = s_max;
-    }
+    ctrl->n_nonroot = *off_n;
 }
 
 // ---- emit the nodes: one thread per NODE ----
@@ -495,9 +468,9 @@ __device__ inline unsigned level_of(uint64_t code)
 // parent[] of every non-root node and the child-octant mask of every node, both written by the parent (children of k: k + 1,
 // then skipping subtrees). (Rounds 2-5 had every child atomicOr its octant into the parent's mask in k_flags and a k_popc pass
 // count the bits: 1.4M atomics on 0.35M words and one launch more, 42 + 6 us at 4M particles.)
-template <typename F, int ND>
-__global__ void k_parents(const uint4 *topo, const uint64_t *ncode, uint32_t n_nodes, uint32_t *parent, uint32_t *mask, uint8_t *ilevel,
-                          uint32_t *kids, const typename vt<F>::v4 *part4, typename vt<F>::v4 *sums)
+template <typename F, int ND, bool LEAF_SUMS>
+__global__ void k_parents(const uint4 *topo, const uint64_t *ncode, uint32_t n_nodes, uint32_t *parent, uint32_t *mask,
+                          const typename vt<F>::v4 *part4, typename vt<F>::v4 *sums)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_nodes) {
@@ -507,7 +480,7 @@ __global__ void k_parents(const uint4 *topo, const uint64_t *ncode, uint32_t n_n
         mask[n_nodes] = 0u;
     }
     const uint4 t = topo[k];
-    if (t.x == 0u) {
+    if (LEAF_SUMS && t.x == 0u) {
         // A leaf has no children to walk; its thread sums the leaf's particles instead, serially in particle order (tree.hpp:1162-1168
         // of the reference) -- one launch for the two.
         F mt = F(0), sx = F(0), sy = F(0), sz = F(0);
@@ -522,64 +495,19 @@ __global__ void k_parents(const uint4 *topo, const uint64_t *ncode, uint32_t n_n
         r.x = sx, r.y = sy, r.z = sz, r.w = mt;
         sums[k] = r;
     }
-    // Level of an internal node, 0xff for a leaf: what a level pass of the node sums has to know about the 1.4M nodes it looks at
-    // (one byte instead of topo[k].x + ncode[k], 24 bytes: eleven passes at 4M particles 70 -> 52 us).
-    ilevel[k] = topo[k].x != 0u ? static_cast<uint8_t>(level_of<ND>(ncode[k])) : uint8_t(0xff);
-    // kids[8 k ..]: the children of k in child order, so that the level passes of the node sums read them with two independent
-    // loads instead of walking c += topo[c].x + 1, a chain of up to eight dependent loads that set the time of every pass (4.6 us
-    // however few nodes a level has). Indexed by the node itself (32 bytes per node, touched for internal nodes only).
-    const uint32_t last = k + topo[k].x;
-    uint32_t m = 0, j = 0;
+    const uint32_t last = k + t.x;
+    uint32_t m = 0;
     for (uint32_t c = k + 1u; c <= last; c += topo[c].x + 1u) {
         parent[c] = k;
         m |= 1u << (static_cast<unsigned>(ncode[c]) & geo<ND>::DMASK);
-        kids[static_cast<size_t>(k) * 8u + (j & 7u)] = c;
-        ++j;
     }
     mask[k] = m;
 }
 
 // ---- node properties --------------------------------------------------------------------------------------
-// Sum of the sums of k's children, in child order.
-template <typename F>
-__device__ inline typename vt<F>::v4 children_sum(const uint32_t *mask, const uint32_t *kids, const typename vt<F>::v4 *sums, uint32_t k)
-{
-    const unsigned nch = static_cast<unsigned>(__popc(mask[k]));
-    const auto *kp = reinterpret_cast<const uint4 *>(kids + static_cast<size_t>(k) * 8u);
-    const uint4 k0 = kp[0], k1 = kp[1];
-    const uint32_t kid[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
-    typename vt<F>::v4 cs[8];
-#pragma unroll
-    for (unsigned j = 0; j < 8u; ++j) {
-        if (j < nch) {
-            cs[j] = sums[kid[j]];
-        }
-    }
-    F mt = F(0), sx = F(0), sy = F(0), sz = F(0);
-#pragma unroll
-    for (unsigned j = 0; j < 8u; ++j) {
-        if (j < nch) {
-            mt += cs[j].w;
-            sx += cs[j].x;
-            sy += cs[j].y;
-            sz += cs[j].z;
-        }
-    }
-    typename vt<F>::v4 s;
-    s.x = sx, s.y = sy, s.z = sz, s.w = mt;
-    return s;
-}
-template <typename F, int ND>
-__global__ void k_up_sums(const uint32_t *mask, const uint32_t *kids, const uint8_t *ilevel, uint32_t n_nodes, unsigned lvl,
-                          typename vt<F>::v4 *sums)
-{
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_nodes || ilevel[k] != lvl) {
-        return;
-    }
-    sums[k] = children_sum<F>(mask, kids, sums, k);
-}
-// (Round 5, built and measured, not kept -- tools/jobs_r05/r05_job37.sh, r05_job38.sh: (1) leaf sums and all levels in ONE launch,
+// (Rounds 2-5 aggregated children into parents with one launch per tree level -- 9 launches at 100k particles, 11 at 4M, ~5 us each
+// however little a level holds; the summation pyramid further down replaced them. Variants of the level passes built and measured
+// before that, none kept -- tools/jobs_r05/r05_job37.sh, r05_job38.sh: (1) leaf sums and all levels in ONE launch,
 // the last child to deliver its sum adds up the parent (atomic counters): on eight XCDs every release / acquire pair is an L2
 // write-back + invalidate, 2.1 ms instead of 0.07 at 4M particles; (2) two or three levels per launch, the upper ones recomputing
 // the sums of their internal children instead of reading them: the walk over a node's children is a chain of dependent loads
@@ -795,13 +723,97 @@ __global__ void __launch_bounds__(256) k_exact_chains_wave(const uint4 *topo, co
     }
 }
 
+// ---- node sums without level passes: a summation pyramid over the particles (default association, round 5) ----
+// Level 0 is the particles' (m x, m y, m z, m) in tree order, level l holds the sums of aligned runs of 2^l of them: P[l][i] =
+// P[l-1][2i] + P[l-1][2i+1]. The sum of a node -- of ANY range [a, b) of particles -- is then the sum of the O(log(b - a)) aligned
+// runs the range decomposes into, taken in a fixed order (left ends by ascending level, then the right ends): no node needs another
+// node's result, so every node takes its sum in k_finalize_flags itself and the 9 (100k particles) to 11 (4M) level passes of
+// k_up_sums -- ~5 us of launch each, however little they hold -- become the two or three launches that build the pyramid (nine
+// levels per launch through LDS). Pairwise association: rounding errors grow with log n. (The exact mode keeps the reference's
+// serial association and its chains.)
+struct pyr_desc {
+    uint32_t off[32]; // first entry of level l (1-based) in the pyramid array
+    uint32_t cnt[32]; // entries of level l; cnt[0] = particles
+    uint32_t levels;  // highest level
+};
+template <typename F>
+__device__ inline typename vt<F>::v4 pyr_entry(const typename vt<F>::v4 *part4, const typename vt<F>::v4 *pyr, const pyr_desc &d,
+                                               unsigned lvl, uint32_t i)
+{
+    if (lvl == 0u) {
+        typename vt<F>::v4 q = part4[i];
+        q.x *= q.w, q.y *= q.w, q.z *= q.w;
+        return q;
+    }
+    return pyr[d.off[lvl] + i];
+}
+// Levels base + 1 .. base + 9 from level base: a block takes 512 entries of it.
+template <typename F>
+__global__ void __launch_bounds__(256) k_pyr_pass(const typename vt<F>::v4 *part4, typename vt<F>::v4 *pyr, const pyr_desc d, unsigned base)
+{
+    using v4 = typename vt<F>::v4;
+    __shared__ v4 sm[256];
+    const uint32_t t = threadIdx.x, in0 = blockIdx.x * 512u + 2u * t, n_in = d.cnt[base];
+    v4 v;
+    v.x = v.y = v.z = v.w = F(0);
+    if (in0 < n_in) {
+        v = pyr_entry<F>(part4, pyr, d, base, in0);
+        if (in0 + 1u < n_in) {
+            const v4 u = pyr_entry<F>(part4, pyr, d, base, in0 + 1u);
+            v.x += u.x, v.y += u.y, v.z += u.z, v.w += u.w;
+        }
+    }
+    uint32_t width = 256u; // entries of the current level this block holds
+    for (unsigned l = base + 1u;; ++l) {
+        const uint32_t idx = blockIdx.x * width + t;
+        if (t < width && l <= d.levels && idx < d.cnt[l]) {
+            pyr[d.off[l] + idx] = v;
+        }
+        if (width == 1u || l >= d.levels) {
+            break;
+        }
+        sm[t] = v;
+        __syncthreads();
+        width >>= 1;
+        if (t < width) {
+            const v4 a = sm[2u * t], b = sm[2u * t + 1u];
+            v.x = a.x + b.x, v.y = a.y + b.y, v.z = a.z + b.z, v.w = a.w + b.w;
+        }
+        __syncthreads();
+    }
+}
+// Sum over the particles [a, b).
+template <typename F>
+__device__ inline typename vt<F>::v4 range_sum(const typename vt<F>::v4 *part4, const typename vt<F>::v4 *pyr, const pyr_desc &d,
+                                               uint32_t a, uint32_t b)
+{
+    using v4 = typename vt<F>::v4;
+    v4 left, right;
+    left.x = left.y = left.z = left.w = F(0);
+    right = left;
+    for (unsigned l = 0; a < b; ++l) {
+        if (a & 1u) {
+            const v4 e = pyr_entry<F>(part4, pyr, d, l, a);
+            left.x += e.x, left.y += e.y, left.z += e.z, left.w += e.w;
+            ++a;
+        }
+        if (a < b && (b & 1u)) {
+            --b;
+            const v4 e = pyr_entry<F>(part4, pyr, d, l, b);
+            right.x = e.x + right.x, right.y = e.y + right.y, right.z = e.z + right.z, right.w = e.w + right.w;
+        }
+        a >>= 1, b >>= 1;
+    }
+    left.x += right.x, left.y += right.y, left.z += right.z, left.w += right.w;
+    return left;
+}
+
 template <typename F, int ND>
-__device__ inline void finalize_node(uint32_t k, const uint64_t *ncode, const typename vt<F>::v4 *sums, F box, int mac,
+__device__ inline void finalize_node(uint32_t k, const uint64_t *ncode, const typename vt<F>::v4 s, F box, int mac,
                                      typename vt<F>::v4 *node_com, typename vt<F>::v2 *node_mac, ctrl_block *ctrl)
 {
     const uint64_t code = ncode[k];
     const unsigned lvl = level_of<ND>(code);
-    const typename vt<F>::v4 s = sums[k];
     // Geometric centre (tree.hpp:452-482 of the reference).
     constexpr unsigned DB = geo<ND>::DB, CB = geo<ND>::CB;
     const uint64_t first_cell = (code - (1ull << (DB * lvl))) << (DB * (CB - lvl));
@@ -892,15 +904,23 @@ __global__ void k_flags(const uint4 *topo, const uint64_t *ncode, const uint32_t
         flags_node<ND, false>(k, topo, ncode, parent, n_nodes, ncrit_clamped, flags, mask);
     }
 }
-// Device build: centre of mass / size of a node and its flags in one launch (two independent things per node).
-template <typename F, int ND>
+// Device build: centre of mass / size of a node and its flags in one launch (two independent things per node). PYR: the node takes
+// its sum from the pyramid (sums = the pyramid array), otherwise from sums[k].
+template <typename F, int ND, bool PYR>
 __global__ void k_finalize_flags(const uint4 *topo, const uint64_t *ncode, const uint32_t *parent, uint32_t n_nodes,
-                                 const typename vt<F>::v4 *sums, F box, int mac, typename vt<F>::v4 *node_com,
-                                 typename vt<F>::v2 *node_mac, ctrl_block *ctrl, uint32_t ncrit_clamped, tri *flags, uint32_t *mask)
+                                 const typename vt<F>::v4 *sums, const typename vt<F>::v4 *part4, const pyr_desc d, F box, int mac,
+                                 typename vt<F>::v4 *node_com, typename vt<F>::v2 *node_mac, ctrl_block *ctrl, uint32_t ncrit_clamped,
+                                 tri *flags, uint32_t *mask)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n_nodes) {
-        finalize_node<F, ND>(k, ncode, sums, box, mac, node_com, node_mac, ctrl);
+        typename vt<F>::v4 sk;
+        if constexpr (PYR) {
+            sk = range_sum<F>(part4, sums, d, topo[k].y, topo[k].z);
+        } else {
+            sk = sums[k];
+        }
+        finalize_node<F, ND>(k, ncode, sk, box, mac, node_com, node_mac, ctrl);
         flags_node<ND, true>(k, topo, ncode, parent, n_nodes, ncrit_clamped, flags, mask);
     }
 }
@@ -1454,24 +1474,26 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     void *p4 = pool_alloc(std::max<size_t>(n, 1) * sizeof(v4));
     s.buf[RK_BUF_PART4] = p4;
     s.buf_bytes[RK_BUF_PART4] = static_cast<int64_t>(n * sizeof(v4));
-    hipLaunchKernelGGL((k_permute<F>), dim3(nblk(n)), dim3(256), 0, st, dx.get(), dy.get(), dz.get(), dm.get(),
-                       vals_a.get(), n, static_cast<v4 *>(p4));
     s.bld_codes = keys_a.release();
     s.bld_perm = vals_a.release();
     const auto *codes = static_cast<const uint64_t *>(s.bld_codes);
 
     const auto mln = static_cast<uint32_t>(std::min<uint64_t>(max_leaf_n, 0xffffffffu));
+    if (mln > 64u) {
+        hipLaunchKernelGGL((k_permute<F>), dim3(nblk(n)), dim3(256), 0, st, dx.get(), dy.get(), dz.get(), dm.get(),
+                           static_cast<const uint32_t *>(s.bld_perm), n, static_cast<v4 *>(p4));
+    }
     auto leaf = dalloc<uint8_t>(n), ldiv = dalloc<uint8_t>(n);
     auto cnt = dalloc<uint32_t>(static_cast<size_t>(n) + 1), off = dalloc<uint32_t>(static_cast<size_t>(n) + 1);
     if (mln <= 64u) {
-        hipLaunchKernelGGL(k_leaf_levels_windows<ND>, dim3(nblk(n)), dim3(256), 0, st, codes, n, mln, leaf.get());
+        hipLaunchKernelGGL((k_leaf_levels_windows<F, ND>), dim3(nblk(n)), dim3(256), 0, st, codes, n, mln, leaf.get(), ldiv.get(), cnt.get(),
+                           dx.get(), dy.get(), dz.get(), dm.get(), static_cast<const uint32_t *>(s.bld_perm), static_cast<v4 *>(p4));
     } else {
         hipLaunchKernelGGL(k_leaf_levels_search<ND>, dim3(nblk(n)), dim3(256), 0, st, codes, n, mln, leaf.get());
+        hipLaunchKernelGGL(k_node_counts<ND>, dim3(nblk(n)), dim3(256), 0, st, codes, n, leaf.get(), ldiv.get(), cnt.get());
     }
-    auto block_max = dalloc<uint8_t>(nblk(n));
-    hipLaunchKernelGGL(k_node_counts<ND>, dim3(nblk(n)), dim3(256), 0, st, codes, n, leaf.get(), ldiv.get(), cnt.get(), block_max.get());
     exclusive_scan(cnt.get(), off.get(), n, st);
-    hipLaunchKernelGGL(k_pack_nodes, dim3(1), dim3(256), 0, st, ctrl.get(), off.get() + n, block_max.get(), nblk(n));
+    hipLaunchKernelGGL(k_pack_nodes, dim3(1), dim3(1), 0, st, ctrl.get(), off.get() + n);
 
     // ---- first round trip: input errors (in the reference's order), box, node count ----
     fetch_ctrl();
@@ -1538,17 +1560,34 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
         hipLaunchKernelGGL(k_emit_per_node<ND>, dim3(nblk(nn)), dim3(256), 0, st, codes, n, ldiv.get(), off.get(), start_of.get(),
                            static_cast<uint32_t>(nn), topo, ncode, parent.get());
     }
-    auto ilevel = dalloc<uint8_t>(nn);
-    auto kids = dalloc<uint32_t>(nn * 8u);
-    auto sums = dalloc<v4>(nn);
-    hipLaunchKernelGGL((k_parents<F, ND>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, static_cast<uint32_t>(nn), parent.get(),
-                       mask.get(), ilevel.get(), kids.get(), static_cast<const v4 *>(p4), sums.get());
+    // Node sums: from a summation pyramid over the particles, or -- exact mode -- in an array, in the reference's serial association.
+    const bool pyramid = !exact_node_sums();
+    pyr_desc pd{};
+    pd.cnt[0] = n;
+    size_t pyr_entries = 0;
+    while (pd.cnt[pd.levels] > 1u && pd.levels < 31u) {
+        const unsigned l = ++pd.levels;
+        pd.cnt[l] = (pd.cnt[l - 1u] + 1u) / 2u;
+        pd.off[l] = static_cast<uint32_t>(pyr_entries);
+        pyr_entries += pd.cnt[l];
+    }
+    dptr<v4> sums = dalloc<v4>(pyramid ? std::max<size_t>(pyr_entries, 1) : nn);
+    if (pyramid) {
+        hipLaunchKernelGGL((k_parents<F, ND, false>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, static_cast<uint32_t>(nn), parent.get(),
+                           mask.get(), static_cast<const v4 *>(p4), sums.get());
+        for (unsigned base = 0; base < pd.levels; base += 9u) {
+            hipLaunchKernelGGL((k_pyr_pass<F>), dim3((pd.cnt[base] + 511u) / 512u), dim3(256), 0, st, static_cast<const v4 *>(p4), sums.get(),
+                               pd, base);
+        }
+    } else {
+        hipLaunchKernelGGL((k_parents<F, ND, true>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, static_cast<uint32_t>(nn), parent.get(),
+                           mask.get(), static_cast<const v4 *>(p4), sums.get());
+    }
     leaf.reset(), ldiv.reset(), cnt.reset(), off.reset();
 
-    // ---- node properties (the leaves have their sums from k_parents) ----
     if (exact_node_sums()) {
         // The reference's association (bit-identical node properties): one serial chain per distinct first particle, all
-        // at once; the root's N links set the time (~25 ms at 4M particles).
+        // at once; the root's N links set the time (~25 ms at 4M particles). (The leaves have their sums from k_parents.)
         const auto max_big = static_cast<unsigned>(static_cast<size_t>(n) / EXACT_WAVE_MIN * (CBITS + 1u) + 2u);
         auto big = dalloc<uint32_t>(static_cast<size_t>(max_big) + 1u);
         // Slot 0 is the root's; the counter starts behind it.
@@ -1559,19 +1598,19 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
         // (Chains of one tree level are disjoint in particles: at most n / EXACT_WAVE_MIN long ones per level exist.)
         hipLaunchKernelGGL((k_exact_chains_wave<F>), dim3(std::min<unsigned>(max_big, static_cast<unsigned>(nn))), dim3(256), 0, st,
                            topo, big.get(), big.get() + max_big, static_cast<const v4 *>(p4), sums.get());
-    } else {
-        // Internal nodes live above the deepest leaf level: the passes of the levels below it are not launched.
-        const int top = std::min(static_cast<int>(CBITS), static_cast<int>(hc.max_level)) - 1;
-        for (int lvl = top; lvl >= 0; --lvl) {
-            hipLaunchKernelGGL((k_up_sums<F, ND>), dim3(nblk(nn)), dim3(256), 0, st, mask.get(), kids.get(), ilevel.get(),
-                               static_cast<uint32_t>(nn), static_cast<unsigned>(lvl), sums.get());
-        }
     }
     // ---- centres of mass, critical nodes, child counts: one scan of three counters ----
     const auto ncrit_c = static_cast<uint32_t>(std::min<uint64_t>(s.ncrit, 0xffffffffu));
     auto flags = dalloc<tri>(nn + 1), offs = dalloc<tri>(nn + 1);
-    hipLaunchKernelGGL((k_finalize_flags<F, ND>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, parent.get(), static_cast<uint32_t>(nn),
-                       sums.get(), box, s.mac, node_com, node_mac, ctrl.get(), ncrit_c, flags.get(), mask.get());
+    if (pyramid) {
+        hipLaunchKernelGGL((k_finalize_flags<F, ND, true>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, parent.get(),
+                           static_cast<uint32_t>(nn), sums.get(), static_cast<const v4 *>(p4), pd, box, s.mac, node_com, node_mac, ctrl.get(),
+                           ncrit_c, flags.get(), mask.get());
+    } else {
+        hipLaunchKernelGGL((k_finalize_flags<F, ND, false>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, parent.get(),
+                           static_cast<uint32_t>(nn), sums.get(), static_cast<const v4 *>(p4), pd, box, s.mac, node_com, node_mac, ctrl.get(),
+                           ncrit_c, flags.get(), mask.get());
+    }
     sums.reset();
     exclusive_scan(flags.get(), offs.get(), nn, st);
     hipLaunchKernelGGL(k_pack_counts, dim3(1), dim3(1), 0, st, ctrl.get(), offs.get() + nn);
