@@ -895,22 +895,21 @@ __device__ inline void flags_node(uint32_t k, const uint4 *topo, const uint64_t 
     }
 }
 
-template <int ND>
+template <int ND, bool MASKS_DONE = false>
 __global__ void k_flags(const uint4 *topo, const uint64_t *ncode, const uint32_t *parent, uint32_t n_nodes,
                         uint32_t ncrit_clamped, tri *flags, uint32_t *mask)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n_nodes) {
-        flags_node<ND, false>(k, topo, ncode, parent, n_nodes, ncrit_clamped, flags, mask);
+        flags_node<ND, MASKS_DONE>(k, topo, ncode, parent, n_nodes, ncrit_clamped, flags, mask);
     }
 }
-// Device build: centre of mass / size of a node and its flags in one launch (two independent things per node). PYR: the node takes
-// its sum from the pyramid (sums = the pyramid array), otherwise from sums[k].
+// Device build: centre of mass / size of every node. PYR: the node takes its sum from the pyramid (sums = the pyramid array),
+// otherwise from sums[k]. (Its own launch, behind the flags + scan whose counts the host waits for: it runs while the host looks.)
 template <typename F, int ND, bool PYR>
-__global__ void k_finalize_flags(const uint4 *topo, const uint64_t *ncode, const uint32_t *parent, uint32_t n_nodes,
-                                 const typename vt<F>::v4 *sums, const typename vt<F>::v4 *part4, const pyr_desc d, F box, int mac,
-                                 typename vt<F>::v4 *node_com, typename vt<F>::v2 *node_mac, ctrl_block *ctrl, uint32_t ncrit_clamped,
-                                 tri *flags, uint32_t *mask)
+__global__ void k_finalize(const uint4 *topo, const uint64_t *ncode, uint32_t n_nodes, const typename vt<F>::v4 *sums,
+                           const typename vt<F>::v4 *part4, const pyr_desc d, F box, int mac, typename vt<F>::v4 *node_com,
+                           typename vt<F>::v2 *node_mac, ctrl_block *ctrl)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n_nodes) {
@@ -921,7 +920,6 @@ __global__ void k_finalize_flags(const uint4 *topo, const uint64_t *ncode, const
             sk = sums[k];
         }
         finalize_node<F, ND>(k, ncode, sk, box, mac, node_com, node_mac, ctrl);
-        flags_node<ND, true>(k, topo, ncode, parent, n_nodes, ncrit_clamped, flags, mask);
     }
 }
 
@@ -1408,6 +1406,37 @@ void replica_first_order(rk_state &s)
     }
 }
 
+// The host's view of a build's control block: the block is copied into pinned host memory by an asynchronous copy behind the kernel
+// that completes it, an event marks the copy, and the host waits for the event only when it needs the numbers -- after it has
+// handed the device the work that does not depend on them (a blocking hipMemcpy cost ~15 us of idle device per look-up, three per
+// build). One set of buffers and events per calling thread and device, made on first use, never given back.
+struct lookup_slots {
+    int device = -1;
+    bld::ctrl_block *host = nullptr;
+    hipEvent_t ev[3] = {};
+};
+static lookup_slots &thread_lookup_slots()
+{
+    static thread_local std::vector<lookup_slots> all;
+    int dev = 0;
+    RK_HIP(hipGetDevice(&dev));
+    for (auto &l : all) {
+        if (l.device == dev) {
+            return l;
+        }
+    }
+    lookup_slots l;
+    l.device = dev;
+    void *p = nullptr;
+    RK_HIP(hipHostMalloc(&p, 3 * sizeof(bld::ctrl_block), hipHostMallocDefault));
+    l.host = static_cast<bld::ctrl_block *>(p);
+    for (auto &e : l.ev) {
+        RK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    all.push_back(l);
+    return all.back();
+}
+
 // Builds the tree and fills `s` (buffers, sizes). Host inputs in the caller's original order.
 template <typename F, int ND>
 void build_device(rk_state &s, const void *const parts[4], bool parts_on_device, int64_t nparts, double box_size_in,
@@ -1451,8 +1480,16 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     ctrl_block hc{};
     RK_HIP(hipMemsetAsync(ctrl.get(), 0, sizeof(ctrl_block), st));
     // (Round 5, measured and not kept: the last kernel in front of a look-up storing the block + a sequence number to pinned host
-    // memory that the host polls, instead of a blocking copy -- rebuild +0.025 ms at 100k, +0.045 at 4M, tools/jobs_r05/r05_job39.sh.)
-    const auto fetch_ctrl = [&] { RK_HIP(hipMemcpy(&hc, ctrl.get(), sizeof(hc), hipMemcpyDeviceToHost)); };
+    // memory that the host polls, instead of a copy -- rebuild +0.025 ms at 100k, +0.045 at 4M, tools/jobs_r05/r05_job39.sh.)
+    lookup_slots &lk = thread_lookup_slots();
+    const auto lookup_begin = [&](int slot) {
+        RK_HIP(hipMemcpyAsync(lk.host + slot, ctrl.get(), sizeof(ctrl_block), hipMemcpyDeviceToHost, st));
+        RK_HIP(hipEventRecord(lk.ev[slot], st));
+    };
+    const auto lookup_end = [&](int slot) {
+        RK_HIP(hipEventSynchronize(lk.ev[slot]));
+        std::memcpy(&hc, lk.host + slot, sizeof(hc));
+    };
 
     // ---- box size, encode, sort, permute, leaf levels, node counts: no host round trip ----
     s.box_deduced = box_size_in == 0.;
@@ -1495,8 +1532,29 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     exclusive_scan(cnt.get(), off.get(), n, st);
     hipLaunchKernelGGL(k_pack_nodes, dim3(1), dim3(1), 0, st, ctrl.get(), off.get() + n);
 
-    // ---- first round trip: input errors (in the reference's order), box, node count ----
-    fetch_ctrl();
+    // ---- first look-up: input errors (in the reference's order), box, node count. While the host waits the device builds the
+    // summation pyramid over the particles (node sums; it needs nothing the host is waiting for) ----
+    lookup_begin(0);
+    // Node sums: from a summation pyramid over the particles, or -- exact mode -- in an array, in the reference's serial association.
+    const bool pyramid = !exact_node_sums();
+    pyr_desc pd{};
+    pd.cnt[0] = n;
+    size_t pyr_entries = 0;
+    while (pd.cnt[pd.levels] > 1u && pd.levels < 31u) {
+        const unsigned l = ++pd.levels;
+        pd.cnt[l] = (pd.cnt[l - 1u] + 1u) / 2u;
+        pd.off[l] = static_cast<uint32_t>(pyr_entries);
+        pyr_entries += pd.cnt[l];
+    }
+    dptr<v4> sums;
+    if (pyramid) {
+        sums = dalloc<v4>(std::max<size_t>(pyr_entries, 1));
+        for (unsigned base = 0; base < pd.levels; base += 9u) {
+            hipLaunchKernelGGL((k_pyr_pass<F>), dim3((pd.cnt[base] + 511u) / 512u), dim3(256), 0, st, static_cast<const v4 *>(p4), sums.get(),
+                               pd, base);
+        }
+    }
+    lookup_end(0);
     if (hc.err & ERR_COORD) {
         throw error(RK_EINVAL, "While trying to automatically determine the domain size, a non-finite coordinate "
                                "was encountered");
@@ -1560,26 +1618,11 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
         hipLaunchKernelGGL(k_emit_per_node<ND>, dim3(nblk(nn)), dim3(256), 0, st, codes, n, ldiv.get(), off.get(), start_of.get(),
                            static_cast<uint32_t>(nn), topo, ncode, parent.get());
     }
-    // Node sums: from a summation pyramid over the particles, or -- exact mode -- in an array, in the reference's serial association.
-    const bool pyramid = !exact_node_sums();
-    pyr_desc pd{};
-    pd.cnt[0] = n;
-    size_t pyr_entries = 0;
-    while (pd.cnt[pd.levels] > 1u && pd.levels < 31u) {
-        const unsigned l = ++pd.levels;
-        pd.cnt[l] = (pd.cnt[l - 1u] + 1u) / 2u;
-        pd.off[l] = static_cast<uint32_t>(pyr_entries);
-        pyr_entries += pd.cnt[l];
-    }
-    dptr<v4> sums = dalloc<v4>(pyramid ? std::max<size_t>(pyr_entries, 1) : nn);
     if (pyramid) {
         hipLaunchKernelGGL((k_parents<F, ND, false>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, static_cast<uint32_t>(nn), parent.get(),
                            mask.get(), static_cast<const v4 *>(p4), sums.get());
-        for (unsigned base = 0; base < pd.levels; base += 9u) {
-            hipLaunchKernelGGL((k_pyr_pass<F>), dim3((pd.cnt[base] + 511u) / 512u), dim3(256), 0, st, static_cast<const v4 *>(p4), sums.get(),
-                               pd, base);
-        }
     } else {
+        sums = dalloc<v4>(nn);
         hipLaunchKernelGGL((k_parents<F, ND, true>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, static_cast<uint32_t>(nn), parent.get(),
                            mask.get(), static_cast<const v4 *>(p4), sums.get());
     }
@@ -1599,30 +1642,25 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
         hipLaunchKernelGGL((k_exact_chains_wave<F>), dim3(std::min<unsigned>(max_big, static_cast<unsigned>(nn))), dim3(256), 0, st,
                            topo, big.get(), big.get() + max_big, static_cast<const v4 *>(p4), sums.get());
     }
-    // ---- centres of mass, critical nodes, child counts: one scan of three counters ----
+    // ---- critical nodes, child counts: one scan of three counters; the centres of mass while the host looks at the counts ----
     const auto ncrit_c = static_cast<uint32_t>(std::min<uint64_t>(s.ncrit, 0xffffffffu));
     auto flags = dalloc<tri>(nn + 1), offs = dalloc<tri>(nn + 1);
-    if (pyramid) {
-        hipLaunchKernelGGL((k_finalize_flags<F, ND, true>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, parent.get(),
-                           static_cast<uint32_t>(nn), sums.get(), static_cast<const v4 *>(p4), pd, box, s.mac, node_com, node_mac, ctrl.get(),
-                           ncrit_c, flags.get(), mask.get());
-    } else {
-        hipLaunchKernelGGL((k_finalize_flags<F, ND, false>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, parent.get(),
-                           static_cast<uint32_t>(nn), sums.get(), static_cast<const v4 *>(p4), pd, box, s.mac, node_com, node_mac, ctrl.get(),
-                           ncrit_c, flags.get(), mask.get());
-    }
-    sums.reset();
+    hipLaunchKernelGGL((k_flags<ND, true>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, parent.get(), static_cast<uint32_t>(nn), ncrit_c,
+                       flags.get(), mask.get());
     exclusive_scan(flags.get(), offs.get(), nn, st);
     hipLaunchKernelGGL(k_pack_counts, dim3(1), dim3(1), 0, st, ctrl.get(), offs.get() + nn);
+    lookup_begin(1);
+    if (pyramid) {
+        hipLaunchKernelGGL((k_finalize<F, ND, true>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, static_cast<uint32_t>(nn), sums.get(),
+                           static_cast<const v4 *>(p4), pd, box, s.mac, node_com, node_mac, ctrl.get());
+    } else {
+        hipLaunchKernelGGL((k_finalize<F, ND, false>), dim3(nblk(nn)), dim3(256), 0, st, topo, ncode, static_cast<uint32_t>(nn), sums.get(),
+                           static_cast<const v4 *>(p4), pd, box, s.mac, node_com, node_mac, ctrl.get());
+    }
+    sums.reset();
 
-    // ---- second round trip: node-property errors, counts ----
-    fetch_ctrl();
-    if (hc.err & ERR_COM) {
-        throw error(RK_EINVAL, "The computation of the centre of mass of a node produced a non-finite value");
-    }
-    if (hc.err & ERR_DIM) {
-        throw error(RK_EINVAL, "The computation of the dimension of a node produced a non-finite value");
-    }
+    // ---- second look-up: counts (the node-property errors come with the third: k_finalize may still be running) ----
+    lookup_end(1);
     const uint32_t n_crit = hc.n_crit, n_int = hc.n_int;
     if (static_cast<size_t>(hc.n_children) + 1 != nn) {
         throw error(RK_ERUNTIME, "internal error: inconsistent node count in the device tree build");
@@ -1665,9 +1703,16 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
                        key_total, first_order);
     s.first_order_valid = want_first;
 
-    // ---- third round trip: class sizes (also the final synchronisation) ----
-    fetch_ctrl();
+    // ---- third look-up: node-property errors, class sizes (also the final synchronisation) ----
+    lookup_begin(2);
+    lookup_end(2);
     RK_HIP(hipGetLastError());
+    if (hc.err & ERR_COM) {
+        throw error(RK_EINVAL, "The computation of the centre of mass of a node produced a non-finite value");
+    }
+    if (hc.err & ERR_DIM) {
+        throw error(RK_EINVAL, "The computation of the dimension of a node produced a non-finite value");
+    }
     s.n_crit = n_crit;
     s.max_group = hc.max_group;
     s.mirrors_valid = false;
