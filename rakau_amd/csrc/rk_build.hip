@@ -727,7 +727,7 @@ __global__ void __launch_bounds__(256) k_exact_chains_wave(const uint4 *topo, co
 // Level 0 is the particles' (m x, m y, m z, m) in tree order, level l holds the sums of aligned runs of 2^l of them: P[l][i] =
 // P[l-1][2i] + P[l-1][2i+1]. The sum of a node -- of ANY range [a, b) of particles -- is then the sum of the O(log(b - a)) aligned
 // runs the range decomposes into, taken in a fixed order (left ends by ascending level, then the right ends): no node needs another
-// node's result, so every node takes its sum in k_finalize_flags itself and the 9 (100k particles) to 11 (4M) level passes of
+// node's result, so every node takes its sum in k_finalize itself and the 9 (100k particles) to 11 (4M) level passes of
 // k_up_sums -- ~5 us of launch each, however little they hold -- become the two or three launches that build the pyramid (nine
 // levels per launch through LDS). Pairwise association: rounding errors grow with log n. (The exact mode keeps the reference's
 // serial association and its chains.)
@@ -1349,6 +1349,8 @@ bool sort_codes(uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint32_t
         const char *e = std::getenv("RK_SORT_MIN"); // items from which the onesweep sequence replaces the library call (-1: never)
         return e ? std::atol(e) : (1l << 20);
     }();
+    // (The merge sort itself with tiles of 2048 / 4096 items instead of its 1024 -- fewer merge passes, no copy launches when their number
+    // is even -- moves the rebuild by -14...+9 us between 30k and 1M items, inside the box-to-box noise: tools/jobs_r05/r05_job58.sh.)
     // Below 2^20 items the library's merge sort wins (launches of a dozen blocks of 8192 items leave the device empty: 100k +0.11 ms,
     // 1M +0.055 ms with the onesweep passes; 2M -0.045, 4M -0.057: tools/jobs_r05/r05_job37.sh).
     if (knob_min < 0 || static_cast<long>(n) < knob_min || n > (1u << 28)) {
