@@ -4,7 +4,8 @@
 //
 //   max |coord| -> box size            (tree.hpp:1279-1319)
 //   discretise + Morton encode         (tree.hpp:381-429, 1441-1450)
-//   stable radix sort of (code, index) (tree.hpp:1267-1274; hipCUB DeviceRadixSort)
+//   stable radix sort of (code, index) (tree.hpp:1267-1274; rocPRIM's onesweep passes under this file's launch sequence from
+//                                       2^20 particles, the library's merge sort below: sort_codes())
 //   permute particles, perm            (tree.hpp:1461-1482)
 //   node topology in depth-first order (tree.hpp:723-833)
 //   node mass / centre of mass / size  (tree.hpp:1116-1237)
@@ -14,11 +15,17 @@
 // Topology without a level loop: with sorted codes c[0..n), let ldiv(i) be the first level at which c[i] leaves
 // the cell of c[i-1] and leaf(i) the level of the leaf that holds particle i. Particle i is the first particle of
 // exactly the nodes at levels ldiv(i)..leaf(i); sorting nodes by (first particle, level) IS the depth-first order,
-// so an exclusive scan of max(0, leaf(i) - ldiv(i) + 1) gives every node its depth-first index directly.
+// so an exclusive scan of max(0, leaf(i) - ldiv(i) + 1) gives every node its depth-first index directly; every node then finds
+// its own end (one thread per node).
 //
-// Node properties are aggregated bottom-up (children -> parent, in child order; leaves summed serially in
-// particle order like the reference). The reference sums every node's particles serially; its own SIMD flavour
-// (tree.hpp:1134-1161) already associates differently, so centres of mass agree to rounding, not bit for bit.
+// Node properties: every node takes the sums over its particles from a summation pyramid over the particles (aligned runs of
+// 2^l particles, two or three launches; no level passes). The reference sums every node's particles serially; its own SIMD
+// flavour (tree.hpp:1134-1161) already associates differently, so centres of mass agree to rounding, not bit for bit. Exact
+// mode (rk_set_build_exact) reproduces the reference's serial association instead.
+//
+// The host looks at the build three times (node count; critical / internal node counts; class sizes) through asynchronous copies
+// of a control block; a dependent launch costs ~5 us on this device whatever it holds, so the build is written for few launches
+// (36 at 100k particles, ten of them the library's merge sort).
 #include "rk_common.hpp"
 #include "rk_device.hpp"
 

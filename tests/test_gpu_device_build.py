@@ -1,6 +1,6 @@
 """Device-side tree construction (rk_state_build) against the host builder / oracle: identical topology, codes,
-permutation and critical nodes; node masses and centres of mass to rounding (child -> parent aggregation instead of
-the reference's serial particle sums); traversal results within the reference's tolerances."""
+permutation and critical nodes; node masses and centres of mass to rounding (sums over aligned runs of particles -- a
+summation pyramid -- instead of the reference's serial particle sums); traversal results within the reference's tolerances."""
 import numpy as np
 import pytest
 
