@@ -104,6 +104,26 @@ def test_coincident_and_zero_mass_and_errors():
         rakau_amd.State.build(xb, y, z, m)
 
 
+def test_non_finite_node_properties_are_reported():
+    """A non-finite mass makes a centre of mass non-finite: the build refuses it with the reference's message (tree.hpp:1199-1204).
+    The error bit is raised by the kernel that runs while the host already looks at the node counts, and comes back with the
+    build's last look-up; the next build on the same thread is unaffected."""
+    rng = oracle.Rng(7)
+    for dtype in (np.float32, np.float64):
+        m, x, y, z = rng.uniform_particles(5000, 1.0, dtype)
+        mb = m.copy()
+        mb[17] = np.inf
+        for exact in (0, 1):
+            rakau_amd.set_build_exact(exact)
+            try:
+                with pytest.raises(ValueError, match="centre of mass of a node produced a non-finite value"):
+                    rakau_amd.State.build(x, y, z, mb, box_size=1.0)
+                st = rakau_amd.State.build(x, y, z, m, box_size=1.0)
+                assert st.nparts == 5000
+            finally:
+                rakau_amd.set_build_exact(0)
+
+
 def test_build_time_4m():
     """Not a parity test: records the device build time next to the host build (printed with -s)."""
     import time
