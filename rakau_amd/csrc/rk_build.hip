@@ -32,6 +32,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 
 namespace rk
@@ -121,7 +122,7 @@ struct ctrl_block {
     unsigned n_crit, n_int, n_children; // critical nodes, internal nodes, sum of child counts
     unsigned max_group;         // particles in the largest critical node
     unsigned class2_count[8];   // critical nodes per lane-mapping class (list kernel binning)
-    unsigned max_level;         // (unused since the node sums come from the summation pyramid)
+    unsigned max_level;         // deepest leaf level of the tree (the next rebuild sorts the code bits of that many levels + 1 only)
     unsigned pad[4];
 };
 enum { ERR_COORD = 1u, ERR_COM = 2u, ERR_DIM = 4u, ERR_BOX = 8u };
@@ -304,14 +305,20 @@ __global__ void k_leaf_levels_search(const uint64_t *codes, uint32_t n, uint32_t
 // maxima, 11 + 21 us at 4M particles against 14.)
 // The same launch takes the node counts of k_node_counts (each particle's own leaf level and its two neighbouring codes are all they
 // need) and puts the particles into tree order (k_permute: nothing to do with the levels, but one launch less).
+// block_max[block] = deepest leaf level among the block's particles (for the host: the next rebuild's partial sort). order == null:
+// the particles are put into tree order elsewhere (k_local_sort).
 template <typename F, int ND>
 __global__ void __launch_bounds__(256) k_leaf_levels_windows(const uint64_t *codes, uint32_t n, uint32_t m, uint8_t *leaf, uint8_t *ldiv,
                                                              uint32_t *cnt, const F *px, const F *py, const F *pz, const F *pm,
-                                                             const uint32_t *order, typename vt<F>::v4 *part4)
+                                                             const uint32_t *order, typename vt<F>::v4 *part4, uint8_t *block_max)
 {
     __shared__ uint8_t s_win[256 + 64];
+    __shared__ unsigned s_any;
     const uint32_t base = blockIdx.x * 256u;
-    if (base + threadIdx.x < n) {
+    if (threadIdx.x == 0u) {
+        s_any = 1u;
+    }
+    if (order && base + threadIdx.x < n) {
         const uint32_t src = order[base + threadIdx.x];
         typename vt<F>::v4 q;
         q.x = px[src], q.y = py[src], q.z = pz ? pz[src] : F(0), q.w = pm[src];
@@ -325,21 +332,88 @@ __global__ void __launch_bounds__(256) k_leaf_levels_windows(const uint64_t *cod
     }
     __syncthreads();
     const uint32_t i = base + threadIdx.x;
+    unsigned lvl = 0u;
+    if (i < n) {
+        unsigned best = 0;
+        for (uint32_t t = threadIdx.x; t <= threadIdx.x + m; ++t) { // windows i - m .. i
+            best = max(best, static_cast<unsigned>(s_win[t]));
+        }
+        lvl = min(best, geo<ND>::CB);
+        leaf[i] = static_cast<uint8_t>(lvl);
+        const unsigned dv = i > 0 ? common_levels<ND>(codes[i - 1], codes[i]) + 1u : 1u; // identical codes never start a node
+        ldiv[i] = static_cast<uint8_t>(dv);
+        cnt[i] = dv <= lvl ? lvl - dv + 1u : 0u;
+        if (i == 0u) {
+            cnt[n] = 0u; // the scan runs over n + 1 values so that off[n] is the total
+        }
+    }
+    // Levels are below 32: the OR of (1 << level) over the block carries the maximum (a DPP reduction per wavefront, one LDS atomic each).
+    const unsigned any = wave_reduce_or(1u << (lvl & 31u));
+    if ((threadIdx.x & 63u) == 0u) {
+        atomicOr(&s_any, any);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        block_max[blockIdx.x] = static_cast<uint8_t>(31u - static_cast<unsigned>(__clz(static_cast<int>(s_any))));
+    }
+}
+
+// Completes a sort that looked at the code bits of the first `L` levels only (sort_codes with begin_bit > 0), given that no leaf is
+// deeper than L: particles of different leaves are in their final relative order already (their codes differ inside those bits), the
+// particles of one leaf are contiguous but in the order the stable partial sort left them in -- by original index. Every particle
+// finds its leaf's range by walking to both sides while the codes share the leaf's level (a leaf above the deepest level holds at
+// most max_leaf_n particles), counts the members in front of it by (code, index) and moves its code, index and record there.
+// A leaf of the deepest level holds identical codes only: nothing to do. (If a leaf IS deeper than L the result is garbage
+// inside the arrays' bounds; the host sees the deepest level with the first look-up and builds again with a full sort.)
+template <typename F, int ND>
+__global__ void __launch_bounds__(256) k_local_sort(const uint64_t *codes, const uint32_t *order, const uint8_t *leaf, uint32_t n, uint32_t span,
+                                                    const F *px, const F *py, const F *pz, const F *pm, uint64_t *codes_out,
+                                                    uint32_t *order_out, typename vt<F>::v4 *part4)
+{
+    // The block's codes and indices with `span` (<= 64) neighbours on either side, in LDS: the walks read them from there.
+    __shared__ uint64_t s_code[256 + 128];
+    __shared__ uint32_t s_ord[256 + 128];
+    const uint32_t base = blockIdx.x * 256u;
+    for (uint32_t t = threadIdx.x; t < 256u + 2u * span; t += 256u) {
+        const bool have = base + t >= span && base + t - span < n;
+        const uint32_t j = base + t - span;
+        s_code[t] = have ? codes[j] : ~0ull; // (no level in common with any code: bit 63 is never set)
+        s_ord[t] = have ? order[j] : 0u;
+    }
+    __syncthreads();
+    const uint32_t i = base + threadIdx.x;
     if (i >= n) {
         return;
     }
-    unsigned best = 0;
-    for (uint32_t t = threadIdx.x; t <= threadIdx.x + m; ++t) { // windows i - m .. i
-        best = max(best, static_cast<unsigned>(s_win[t]));
+    const uint32_t me = threadIdx.x + span;
+    const uint64_t c = s_code[me];
+    const uint32_t o = s_ord[me];
+    const unsigned lf = leaf[i];
+    uint32_t dest = i;
+    if (lf < geo<ND>::CB) {
+        uint32_t before = 0, first = i;
+        for (uint32_t k = 1; k <= span; ++k) {
+            const uint64_t cj = s_code[me - k];
+            if (cj == ~0ull || common_levels<ND>(cj, c) < lf) {
+                break;
+            }
+            first = i - k;
+            before += (cj < c || (cj == c && s_ord[me - k] < o)) ? 1u : 0u;
+        }
+        for (uint32_t k = 1; k <= span; ++k) {
+            const uint64_t cj = s_code[me + k];
+            if (cj == ~0ull || common_levels<ND>(cj, c) < lf) {
+                break;
+            }
+            before += (cj < c || (cj == c && s_ord[me + k] < o)) ? 1u : 0u;
+        }
+        dest = first + before;
     }
-    const unsigned lvl = min(best, geo<ND>::CB);
-    leaf[i] = static_cast<uint8_t>(lvl);
-    const unsigned dv = i > 0 ? common_levels<ND>(codes[i - 1], codes[i]) + 1u : 1u; // identical codes never start a node
-    ldiv[i] = static_cast<uint8_t>(dv);
-    cnt[i] = dv <= lvl ? lvl - dv + 1u : 0u;
-    if (i == 0u) {
-        cnt[n] = 0u; // the scan runs over n + 1 values so that off[n] is the total
-    }
+    codes_out[dest] = c;
+    order_out[dest] = o;
+    typename vt<F>::v4 q;
+    q.x = px[o], q.y = py[o], q.z = pz ? pz[o] : F(0), q.w = pm[o];
+    part4[dest] = q;
 }
 
 // ldiv[i] = first level at which c[i] leaves the cell of c[i-1]; cnt[i] = number of nodes whose first particle is i.
@@ -362,9 +436,41 @@ __global__ void k_node_counts(const uint64_t *codes, uint32_t n, const uint8_t *
 // atomicMax per block on one word of the control block -- 15 600 same-address atomics, 150 us at 4M particles --, then with an
 // agent-scope load of that word per block, 62 us against 14 for the kernel's own work. The level passes are gone.)
 
-__global__ void k_pack_nodes(ctrl_block *ctrl, const uint32_t *off_n)
+// One block: the node count (total of the scan) and the deepest leaf level (maximum over the leaf-level kernel's blocks; block_max ==
+// null: not known, the deepest possible) for the host.
+__global__ void __launch_bounds__(256) k_pack_nodes(ctrl_block *ctrl, const uint32_t *off_n, const uint8_t *block_max, uint32_t n_blocks,
+                                                    unsigned deepest)
 {
-    ctrl->n_nonroot = *off_n;
+    __shared__ unsigned s_any;
+    if (threadIdx.x == 0u) {
+        s_any = 1u;
+        ctrl->n_nonroot = *off_n;
+    }
+    __syncthreads();
+    unsigned any = 1u;
+    if (block_max) {
+        // Sixteen bytes per load (the array comes from the block cache, 16-byte aligned).
+        const uint32_t n16 = n_blocks / 16u;
+        const auto *v = reinterpret_cast<const uint4 *>(block_max);
+        for (uint32_t g = threadIdx.x; g < n16; g += blockDim.x) {
+            const uint4 q = v[g];
+            const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                any |= (1u << (w[j] & 31u)) | (1u << ((w[j] >> 8) & 31u)) | (1u << ((w[j] >> 16) & 31u)) | (1u << ((w[j] >> 24) & 31u));
+            }
+        }
+        for (uint32_t b = n16 * 16u + threadIdx.x; b < n_blocks; b += blockDim.x) {
+            any |= 1u << (block_max[b] & 31u);
+        }
+    } else {
+        any = 1u << (deepest & 31u);
+    }
+    atomicOr(&s_any, any);
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        ctrl->max_level = 31u - static_cast<unsigned>(__clz(static_cast<int>(s_any)));
+    }
 }
 
 // ---- emit the nodes: one thread per NODE ----
@@ -1294,15 +1400,15 @@ namespace sortk
 {
 constexpr unsigned RB = 8, RADIX = 1u << RB;
 constexpr unsigned END_BIT = 63, PLACES = (END_BIT + RB - 1) / RB;
-static_assert(PLACES % 2 == 0, "an even number of passes leaves the result in the buffers it started from");
+static_assert(PLACES <= 16, "one block counter per pass in the 16 words set aside for them");
 using bid_t = rocprim::detail::block_id_wrapper<unsigned int, true>; // blocks take their index from a counter, in arrival order
 using lookback_t = rocprim::detail::onesweep_lookback_state;
 static_assert(sizeof(lookback_t) == sizeof(uint32_t));
 
 template <unsigned BS, unsigned IPT>
-__global__ void __launch_bounds__(BS) k_sort_hist(const uint64_t *keys, uint32_t *counts, uint32_t n, uint32_t full_blocks)
+__global__ void __launch_bounds__(BS) k_sort_hist(const uint64_t *keys, uint32_t *counts, uint32_t n, uint32_t full_blocks, unsigned begin_bit)
 {
-    rocprim::detail::onesweep_histograms<BS, IPT, RB, false>(keys, counts, n, full_blocks, rocprim::identity_decomposer{}, 0u, END_BIT);
+    rocprim::detail::onesweep_histograms<BS, IPT, RB, false>(keys, counts, n, full_blocks, rocprim::identity_decomposer{}, begin_bit, END_BIT);
 }
 template <unsigned BS>
 __global__ void __launch_bounds__(BS) k_sort_scan(uint32_t *counts)
@@ -1319,21 +1425,23 @@ __global__ void __launch_bounds__(BS) k_sort_pass(const uint64_t *kin, uint64_t 
 }
 
 // State for n items in blocks of BS * IPT: digit counts of every place, a scratch row the last block of a pass writes, one block
-// counter per pass, the look-back states of every pass (256 words per block and pass).
+// counter per pass, the look-back states of every pass (256 words per block and pass). Bits [begin_bit, END_BIT) of the keys count;
+// returns true when the number of passes is odd, i.e. the result is in (kb, vb).
 template <unsigned BS, unsigned IPT>
-void onesweep(uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint32_t n, hipStream_t st)
+bool onesweep(uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint32_t n, unsigned begin_bit, hipStream_t st)
 {
     constexpr unsigned IPB = BS * IPT;
+    const unsigned places = (END_BIT - begin_bit + RB - 1u) / RB;
     const unsigned blocks = (n + IPB - 1u) / IPB, full_blocks = n % IPB == 0u ? blocks : blocks - 1u;
-    const size_t words = static_cast<size_t>(PLACES) * RADIX + RADIX + 16 + static_cast<size_t>(PLACES) * RADIX * blocks;
+    const size_t words = static_cast<size_t>(places) * RADIX + RADIX + 16 + static_cast<size_t>(places) * RADIX * blocks;
     auto state = dalloc<uint32_t>(words);
     RK_HIP(hipMemsetAsync(state.get(), 0, words * sizeof(uint32_t), st));
-    uint32_t *counts = state.get(), *scratch_row = counts + PLACES * RADIX, *bids = scratch_row + RADIX;
+    uint32_t *counts = state.get(), *scratch_row = counts + places * RADIX, *bids = scratch_row + RADIX;
     auto *lb = reinterpret_cast<lookback_t *>(bids + 16);
-    hipLaunchKernelGGL((k_sort_hist<BS, IPT>), dim3(blocks), dim3(BS), 0, st, ka, counts, n, full_blocks);
-    hipLaunchKernelGGL((k_sort_scan<BS>), dim3(PLACES), dim3(BS), 0, st, counts);
-    for (unsigned p = 0; p < PLACES; ++p) {
-        const unsigned bit = p * RB, bits = std::min(RB, END_BIT - bit);
+    hipLaunchKernelGGL((k_sort_hist<BS, IPT>), dim3(blocks), dim3(BS), 0, st, ka, counts, n, full_blocks, begin_bit);
+    hipLaunchKernelGGL((k_sort_scan<BS>), dim3(places), dim3(BS), 0, st, counts);
+    for (unsigned p = 0; p < places; ++p) {
+        const unsigned bit = begin_bit + p * RB, bits = std::min(RB, END_BIT - bit);
         const bool fwd = p % 2u == 0u;
         hipLaunchKernelGGL((k_sort_pass<BS, IPT>), dim3(blocks), dim3(BS), 0, st, fwd ? ka : kb, fwd ? kb : ka, fwd ? va : vb,
                            fwd ? vb : va, n, counts + p * RADIX, scratch_row, lb + static_cast<size_t>(p) * RADIX * blocks, bit, bits,
@@ -1341,21 +1449,28 @@ void onesweep(uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint32_t n
     }
     RK_HIP(hipGetLastError());
     // (The state goes back to the block cache and is only ever reused on this stream.)
+    return places % 2u == 1u;
 }
 } // namespace sortk
 
-// Sorts the n pairs of (ka, va) by the low 63 bits of the keys, stably; (kb, vb) is scratch of the same size. Returns true when the
-// result is in (kb, vb) instead of (ka, va).
-bool sort_codes(uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint32_t n, hipStream_t st)
+// Sorts the n pairs of (ka, va) by bits [begin_bit, 63) of the keys, stably; (kb, vb) is scratch of the same size. Returns true when the
+// result is in (kb, vb) instead of (ka, va). begin_bit > 0 (the caller completes the order itself, k_local_sort) is honoured on the
+// onesweep path only.
+long sort_onesweep_min()
+{
+    static const long knob_min = [] {
+        const char *e = std::getenv("RK_SORT_MIN"); // items from which the onesweep sequence replaces the library call (-1: never)
+        return e ? std::atol(e) : (1l << 20);
+    }();
+    return knob_min;
+}
+bool sort_codes(uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint32_t n, unsigned begin_bit, hipStream_t st)
 {
     using namespace sortk;
     if (n < 2u) {
         return false;
     }
-    static const long knob_min = [] {
-        const char *e = std::getenv("RK_SORT_MIN"); // items from which the onesweep sequence replaces the library call (-1: never)
-        return e ? std::atol(e) : (1l << 20);
-    }();
+    const long knob_min = sort_onesweep_min();
     // (The merge sort itself with tiles of 2048 / 4096 items instead of its 1024 -- fewer merge passes, no copy launches when their number
     // is even -- moves the rebuild by -14...+9 us between 30k and 1M items, inside the box-to-box noise: tools/jobs_r05/r05_job58.sh.)
     // Below 2^20 items the library's merge sort wins (launches of a dozen blocks of 8192 items leave the device empty: 100k +0.11 ms,
@@ -1369,8 +1484,13 @@ bool sort_codes(uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint32_t
     }
     // rocPRIM's gfx942 / gfx950 block shape for 8 + 4 byte pairs. Smaller blocks for mid-size sorts (256 x 8, 256 x 16, 512 x 8,
     // 256 x 4 from 100k to 2M items) all lose to the merge sort and to this shape: tools/jobs_r05/r05_job40.sh.
-    onesweep<512, 16>(ka, va, kb, vb, n, st);
-    return false;
+    return onesweep<512, 16>(ka, va, kb, vb, n, begin_bit, st);
+}
+// Whether sort_codes() would take the onesweep path (the only one that looks at a sub-range of the bits) for n items.
+bool sort_is_onesweep(uint32_t n)
+{
+    const long knob_min = sort_onesweep_min();
+    return n >= 2u && !(knob_min < 0 || static_cast<long>(n) < knob_min || n > (1u << 28));
 }
 
 } // namespace bld
@@ -1502,48 +1622,26 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
 
     // ---- box size, encode, sort, permute, leaf levels, node counts: no host round trip ----
     s.box_deduced = box_size_in == 0.;
-    if (s.box_deduced) {
-        hipLaunchKernelGGL((k_maxabs<F>), dim3(std::min(nblk(n), 1024u)), dim3(256), 0, st, dx.get(), dy.get(), dz.get(), n,
-                           ctrl.get());
-    }
-    // (ka, va): the codes and indices, sorted in place; (kb, vb): the other half of the sort's ping-pong.
-    auto keys_a = dalloc<uint64_t>(n), keys_b = dalloc<uint64_t>(n);
-    auto vals_a = dalloc<uint32_t>(n), vals_b = dalloc<uint32_t>(n);
-    hipLaunchKernelGGL((k_encode<F, ND>), dim3(nblk(n)), dim3(256), 0, st, dx.get(), dy.get(), dz.get(), n, ctrl.get(),
-                       static_cast<F>(box_size_in), keys_a.get(), vals_a.get());
-    if (sort_codes(keys_a.get(), vals_a.get(), keys_b.get(), vals_b.get(), n, st)) {
-        keys_a.swap(keys_b);
-        vals_a.swap(vals_b);
-    }
-    keys_b.reset();
-    vals_b.reset();
+    const auto mln = static_cast<uint32_t>(std::min<uint64_t>(max_leaf_n, 0xffffffffu));
     void *p4 = pool_alloc(std::max<size_t>(n, 1) * sizeof(v4));
     s.buf[RK_BUF_PART4] = p4;
     s.buf_bytes[RK_BUF_PART4] = static_cast<int64_t>(n * sizeof(v4));
-    s.bld_codes = keys_a.release();
-    s.bld_perm = vals_a.release();
-    const auto *codes = static_cast<const uint64_t *>(s.bld_codes);
-
-    const auto mln = static_cast<uint32_t>(std::min<uint64_t>(max_leaf_n, 0xffffffffu));
-    if (mln > 64u) {
-        hipLaunchKernelGGL((k_permute<F>), dim3(nblk(n)), dim3(256), 0, st, dx.get(), dy.get(), dz.get(), dm.get(),
-                           static_cast<const uint32_t *>(s.bld_perm), n, static_cast<v4 *>(p4));
+    // A REBUILD sorts only the code bits of the levels the tree can be expected to use -- the deepest leaf level of the state's
+    // previous build + 1 -- and completes the order inside the leaves itself (k_local_sort): five onesweep passes instead of eight
+    // for a tree twelve levels deep. The first look-up brings the deepest level actually found; if it is deeper than assumed the
+    // front of the build runs again with the full sort.
+    static const int partial_bias = [] {
+        const char *e = std::getenv("RK_SORT_PARTIAL"); // levels added to the previous build's depth (default 1); -100: full sort always
+        return e ? std::atoi(e) : 1;
+    }();
+    unsigned sort_levels = CBITS;
+    if (s.bld_max_level >= 0 && partial_bias > -100 && mln <= 64u && sort_is_onesweep(n)) {
+        sort_levels = static_cast<unsigned>(std::clamp(s.bld_max_level + partial_bias, 1, static_cast<int>(CBITS)));
     }
-    auto leaf = dalloc<uint8_t>(n), ldiv = dalloc<uint8_t>(n);
-    auto cnt = dalloc<uint32_t>(static_cast<size_t>(n) + 1), off = dalloc<uint32_t>(static_cast<size_t>(n) + 1);
-    if (mln <= 64u) {
-        hipLaunchKernelGGL((k_leaf_levels_windows<F, ND>), dim3(nblk(n)), dim3(256), 0, st, codes, n, mln, leaf.get(), ldiv.get(), cnt.get(),
-                           dx.get(), dy.get(), dz.get(), dm.get(), static_cast<const uint32_t *>(s.bld_perm), static_cast<v4 *>(p4));
-    } else {
-        hipLaunchKernelGGL(k_leaf_levels_search<ND>, dim3(nblk(n)), dim3(256), 0, st, codes, n, mln, leaf.get());
-        hipLaunchKernelGGL(k_node_counts<ND>, dim3(nblk(n)), dim3(256), 0, st, codes, n, leaf.get(), ldiv.get(), cnt.get());
-    }
-    exclusive_scan(cnt.get(), off.get(), n, st);
-    hipLaunchKernelGGL(k_pack_nodes, dim3(1), dim3(1), 0, st, ctrl.get(), off.get() + n);
-
-    // ---- first look-up: input errors (in the reference's order), box, node count. While the host waits the device builds the
-    // summation pyramid over the particles (node sums; it needs nothing the host is waiting for) ----
-    lookup_begin(0);
+    dptr<uint64_t> keys_a;
+    dptr<uint32_t> vals_a;
+    dptr<uint8_t> leaf, ldiv;
+    dptr<uint32_t> cnt, off;
     // Node sums: from a summation pyramid over the particles, or -- exact mode -- in an array, in the reference's serial association.
     const bool pyramid = !exact_node_sums();
     pyr_desc pd{};
@@ -1556,14 +1654,84 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
         pyr_entries += pd.cnt[l];
     }
     dptr<v4> sums;
-    if (pyramid) {
-        sums = dalloc<v4>(std::max<size_t>(pyr_entries, 1));
-        for (unsigned base = 0; base < pd.levels; base += 9u) {
-            hipLaunchKernelGGL((k_pyr_pass<F>), dim3((pd.cnt[base] + 511u) / 512u), dim3(256), 0, st, static_cast<const v4 *>(p4), sums.get(),
-                               pd, base);
+    for (;;) {
+        const bool partial = sort_levels < CBITS;
+        const unsigned begin_bit = partial ? bld::geo<ND>::DB * (CBITS - sort_levels) : 0u;
+        if (s.box_deduced) {
+            hipLaunchKernelGGL((k_maxabs<F>), dim3(std::min(nblk(n), 1024u)), dim3(256), 0, st, dx.get(), dy.get(), dz.get(), n,
+                               ctrl.get());
         }
+        // (ka, va): the codes and indices, sorted in place; (kb, vb): the other half of the sort's ping-pong.
+        keys_a = dalloc<uint64_t>(n);
+        vals_a = dalloc<uint32_t>(n);
+        auto keys_b = dalloc<uint64_t>(n);
+        auto vals_b = dalloc<uint32_t>(n);
+        hipLaunchKernelGGL((k_encode<F, ND>), dim3(nblk(n)), dim3(256), 0, st, dx.get(), dy.get(), dz.get(), n, ctrl.get(),
+                           static_cast<F>(box_size_in), keys_a.get(), vals_a.get());
+        if (sort_codes(keys_a.get(), vals_a.get(), keys_b.get(), vals_b.get(), n, begin_bit, st)) {
+            keys_a.swap(keys_b);
+            vals_a.swap(vals_b);
+        }
+        if (mln > 64u) {
+            hipLaunchKernelGGL((k_permute<F>), dim3(nblk(n)), dim3(256), 0, st, dx.get(), dy.get(), dz.get(), dm.get(), vals_a.get(), n,
+                               static_cast<v4 *>(p4));
+        }
+        leaf = dalloc<uint8_t>(n), ldiv = dalloc<uint8_t>(n);
+        cnt = dalloc<uint32_t>(static_cast<size_t>(n) + 1), off = dalloc<uint32_t>(static_cast<size_t>(n) + 1);
+        dptr<uint8_t> block_max;
+        if (mln <= 64u) {
+            block_max = dalloc<uint8_t>(nblk(n));
+            hipLaunchKernelGGL((k_leaf_levels_windows<F, ND>), dim3(nblk(n)), dim3(256), 0, st, keys_a.get(), n, mln, leaf.get(), ldiv.get(),
+                               cnt.get(), dx.get(), dy.get(), dz.get(), dm.get(), partial ? nullptr : vals_a.get(), static_cast<v4 *>(p4),
+                               block_max.get());
+        } else {
+            hipLaunchKernelGGL(k_leaf_levels_search<ND>, dim3(nblk(n)), dim3(256), 0, st, keys_a.get(), n, mln, leaf.get());
+            hipLaunchKernelGGL(k_node_counts<ND>, dim3(nblk(n)), dim3(256), 0, st, keys_a.get(), n, leaf.get(), ldiv.get(), cnt.get());
+        }
+        exclusive_scan(cnt.get(), off.get(), n, st);
+        hipLaunchKernelGGL(k_pack_nodes, dim3(1), dim3(256), 0, st, ctrl.get(), off.get() + n, block_max.get(), nblk(n), CBITS);
+
+        // ---- first look-up: input errors (in the reference's order), box, node count, deepest level. While the host waits the
+        // device completes a partial sort and builds the summation pyramid over the particles (node sums): neither needs anything the
+        // host is waiting for ----
+        lookup_begin(0);
+        if (partial) {
+            hipLaunchKernelGGL((k_local_sort<F, ND>), dim3(nblk(n)), dim3(256), 0, st, keys_a.get(), vals_a.get(), leaf.get(), n, mln,
+                               dx.get(), dy.get(), dz.get(), dm.get(), keys_b.get(), vals_b.get(), static_cast<v4 *>(p4));
+            keys_a.swap(keys_b);
+            vals_a.swap(vals_b);
+        }
+        keys_b.reset();
+        vals_b.reset();
+        if (pyramid) {
+            sums = dalloc<v4>(std::max<size_t>(pyr_entries, 1));
+            for (unsigned base = 0; base < pd.levels; base += 9u) {
+                hipLaunchKernelGGL((k_pyr_pass<F>), dim3((pd.cnt[base] + 511u) / 512u), dim3(256), 0, st, static_cast<const v4 *>(p4),
+                                   sums.get(), pd, base);
+            }
+        }
+        lookup_end(0);
+        static const bool sort_trace = [] {
+            const char *e = std::getenv("RK_SORT_TRACE"); // 1: one line per build on stderr (tests/test_gpu_leapfrog.py)
+            return e && std::atoi(e) != 0;
+        }();
+        if (sort_trace) {
+            std::fprintf(stderr, "rk_build: n %u sorted levels %u of %u (bits from %u), deepest leaf level %u%s\n", n, sort_levels, CBITS,
+                         begin_bit, hc.max_level, partial && hc.max_level > sort_levels ? " -> again with all bits" : "");
+        }
+        if (partial && hc.max_level > sort_levels && !(hc.err & (ERR_COORD | ERR_BOX)) && hc.bad_inv == 0u) {
+            // A leaf deeper than the sorted bits reach: everything above was computed on an order that is not the full one. Again, with
+            // all bits (the control block starts from zero like the first time).
+            sort_levels = CBITS;
+            RK_HIP(hipMemsetAsync(ctrl.get(), 0, sizeof(ctrl_block), st));
+            continue;
+        }
+        break;
     }
-    lookup_end(0);
+    s.bld_codes = keys_a.release();
+    s.bld_perm = vals_a.release();
+    const auto *codes = static_cast<const uint64_t *>(s.bld_codes);
+    s.bld_max_level = static_cast<int>(hc.max_level);
     if (hc.err & ERR_COORD) {
         throw error(RK_EINVAL, "While trying to automatically determine the domain size, a non-finite coordinate "
                                "was encountered");

@@ -371,6 +371,8 @@ struct rk_state {
     void *bld_codes = nullptr;     // uint64 sorted Morton codes [nparts]
     void *bld_perm = nullptr;      // uint32 original index of the particle at Morton position i [nparts]
     void *bld_node_code = nullptr; // uint64 nodal codes in depth-first order [tree_size]
+    int bld_max_level = -1;        // deepest leaf level of the last device build of this state (-1: none yet): the next rebuild sorts
+                                   // only the code bits of that many levels + 1 and orders the leaves' insides itself (rk_build.hip)
     double box_size = 0.;
     bool box_deduced = false;
     uint64_t max_leaf_n = 0;

@@ -21,10 +21,10 @@ def torch_dev():
     return torch, torch.device("cuda", 0)
 
 
-def same_tree(a, b):
+def same_tree(a, b, ndim=3):
     assert (a.nparts, a.tree_size, a.n_crit, a.max_group) == (b.nparts, b.tree_size, b.n_crit, b.max_group)
     assert a.tree_info() == b.tree_info()
-    for what in ("x", "y", "z", "m", "codes", "perm", "crit"):
+    for what in ("x", "y", "z", "m", "codes", "perm", "crit") if ndim == 3 else ("x", "y", "m", "codes", "perm", "crit"):
         assert np.array_equal(a.download(what), b.download(what)), what
     na, nb = a.download("nodes"), b.download("nodes")
     assert na.tobytes() == nb.tobytes()
@@ -182,6 +182,64 @@ def test_build_from_device_pointers_and_rebuild(dtype):
     rakau_amd._capi.lib().rk_pool_trim()
     st.rebuild_device([t.data_ptr() for t in ts], nparts=40000, box_size=4.0)
     same_tree(st, fresh)
+
+
+PARTIAL_SORT_CODE = r"""
+import sys
+import numpy as np, torch
+import oracle, rakau_amd
+sys.path.insert(0, "tests")
+from test_gpu_leapfrog import same_tree
+dev = torch.device("cuda", 0)
+for dtype, nd in ((np.float32, 3), (np.float64, 3), (np.float32, 2)):
+    m, x, y, z = oracle.plummer(50000, dtype)
+    rs = np.random.RandomState(3)
+    pos = [x.copy(), y.copy()] + ([z.copy()] if nd == 3 else [])
+    tm = torch.as_tensor(m).to(dev)
+    ts = [torch.as_tensor(v).to(dev) for v in pos]
+    torch.cuda.synchronize()
+    st = rakau_amd.State.build_device([t.data_ptr() for t in ts] + [tm.data_ptr()], 50000, dtype)
+    for step in range(6):
+        # small moves: the tree keeps its depth (partial sort, no second try); step 4 squeezes everything into a corner of the box
+        # (a deeper tree: the first try must be found wanting and repeated with all bits)
+        for k in range(nd):
+            pos[k] = (pos[k] * (0.01 if step == 4 else 1.0) + dtype(1e-3) * rs.standard_normal(50000).astype(dtype)).astype(dtype)
+        ts = [torch.as_tensor(v).to(dev) for v in pos]
+        torch.cuda.synchronize()
+        box = 60.0 if step >= 4 else None
+        st.rebuild_device([t.data_ptr() for t in ts] + [tm.data_ptr()], nparts=50000, box_size=box)
+        if nd == 3:
+            fresh = rakau_amd.State.build(pos[0], pos[1], pos[2], m, box_size=box)
+        else:
+            fresh = rakau_amd.State.build(pos[0], pos[1], None, m, box_size=box)
+        same_tree(st, fresh, nd)
+print("PARTIAL_SORT_OK")
+"""
+
+
+@pytest.mark.parametrize("bias", ["1", "2", "-3", "-100"])
+def test_rebuild_with_a_partial_sort_equals_a_fresh_build(bias):
+    """A rebuild sorts only the code bits of the levels the previous tree used (+ bias) and orders the insides of the leaves itself
+    (rk_build.hip k_local_sort); when the new tree turns out deeper, the front of the build runs again with all bits. Either way the
+    state must equal a fresh build bit for bit. RK_SORT_MIN=0 puts these 50k-particle builds on the onesweep path, where the
+    partial sort lives (default: from 2^20 particles); bias -3 makes every first try fail, -100 switches the partial sort off."""
+    import subprocess
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    env = dict(os.environ, RK_SORT_MIN="0", RK_SORT_PARTIAL=bias, RK_SORT_TRACE="1")
+    env["PYTHONPATH"] = os.pathsep.join([root, os.path.join(root, "tests"), env.get("PYTHONPATH", "")])
+    out = subprocess.run([sys.executable, "-c", PARTIAL_SORT_CODE], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0 and "PARTIAL_SORT_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stderr.splitlines() if l.startswith("rk_build:")]
+    import re
+    partial = [l for l in lines if (lambda mm: mm and int(mm.group(1)) < int(mm.group(2)))(re.search(r"sorted levels (\d+) of (\d+)", l))]
+    again = [l for l in lines if "again with all bits" in l]
+    if bias == "-100":
+        assert not partial and not again
+    elif bias == "-3":
+        assert again
+    else:
+        # the small moves keep the depth: partial sorts without a second try; the squeeze needs one
+        assert len(partial) > len(again) >= 1, lines
 
 
 def cpu_leapfrog(x, y, z, vx, vy, vz, m, dt, steps, theta, eps):
