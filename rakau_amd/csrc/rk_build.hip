@@ -1398,24 +1398,22 @@ void exclusive_scan(const tri *in, tri *out, size_t n, hipStream_t st)
 // takes the onesweep path. Same result: both are stable sorts of the same keys.
 namespace sortk
 {
-constexpr unsigned RB = 8, RADIX = 1u << RB;
-constexpr unsigned END_BIT = 63, PLACES = (END_BIT + RB - 1) / RB;
-static_assert(PLACES <= 16, "one block counter per pass in the 16 words set aside for them");
+constexpr unsigned END_BIT = 63;
 using bid_t = rocprim::detail::block_id_wrapper<unsigned int, true>; // blocks take their index from a counter, in arrival order
 using lookback_t = rocprim::detail::onesweep_lookback_state;
 static_assert(sizeof(lookback_t) == sizeof(uint32_t));
 
-template <unsigned BS, unsigned IPT>
+template <unsigned BS, unsigned IPT, unsigned RB>
 __global__ void __launch_bounds__(BS) k_sort_hist(const uint64_t *keys, uint32_t *counts, uint32_t n, uint32_t full_blocks, unsigned begin_bit)
 {
     rocprim::detail::onesweep_histograms<BS, IPT, RB, false>(keys, counts, n, full_blocks, rocprim::identity_decomposer{}, begin_bit, END_BIT);
 }
-template <unsigned BS>
+template <unsigned BS, unsigned RB>
 __global__ void __launch_bounds__(BS) k_sort_scan(uint32_t *counts)
 {
     rocprim::detail::onesweep_scan_histograms<BS, RB>(counts);
 }
-template <unsigned BS, unsigned IPT>
+template <unsigned BS, unsigned IPT, unsigned RB>
 __global__ void __launch_bounds__(BS) k_sort_pass(const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout, uint32_t n,
                                                   uint32_t *offs_in, uint32_t *offs_out, lookback_t *lb, unsigned bit, unsigned bits,
                                                   unsigned full_blocks, bid_t bid)
@@ -1424,13 +1422,13 @@ __global__ void __launch_bounds__(BS) k_sort_pass(const uint64_t *kin, uint64_t 
         kin, kout, vin, vout, n, offs_in, offs_out, lb, rocprim::identity_decomposer{}, bit, bits, full_blocks, bid);
 }
 
-// State for n items in blocks of BS * IPT: digit counts of every place, a scratch row the last block of a pass writes, one block
-// counter per pass, the look-back states of every pass (256 words per block and pass). Bits [begin_bit, END_BIT) of the keys count;
-// returns true when the number of passes is odd, i.e. the result is in (kb, vb).
-template <unsigned BS, unsigned IPT>
+// State for n items in blocks of BS * IPT and digits of RB bits: digit counts of every place, a scratch row the last block of a pass
+// writes, one block counter per pass, the look-back states of every pass (2^RB words per block and pass). Bits [begin_bit, END_BIT)
+// of the keys count; returns true when the number of passes is odd, i.e. the result is in (kb, vb).
+template <unsigned BS, unsigned IPT, unsigned RB>
 bool onesweep(uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint32_t n, unsigned begin_bit, hipStream_t st)
 {
-    constexpr unsigned IPB = BS * IPT;
+    constexpr unsigned IPB = BS * IPT, RADIX = 1u << RB;
     const unsigned places = (END_BIT - begin_bit + RB - 1u) / RB;
     const unsigned blocks = (n + IPB - 1u) / IPB, full_blocks = n % IPB == 0u ? blocks : blocks - 1u;
     const size_t words = static_cast<size_t>(places) * RADIX + RADIX + 16 + static_cast<size_t>(places) * RADIX * blocks;
@@ -1438,12 +1436,12 @@ bool onesweep(uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint32_t n
     RK_HIP(hipMemsetAsync(state.get(), 0, words * sizeof(uint32_t), st));
     uint32_t *counts = state.get(), *scratch_row = counts + places * RADIX, *bids = scratch_row + RADIX;
     auto *lb = reinterpret_cast<lookback_t *>(bids + 16);
-    hipLaunchKernelGGL((k_sort_hist<BS, IPT>), dim3(blocks), dim3(BS), 0, st, ka, counts, n, full_blocks, begin_bit);
-    hipLaunchKernelGGL((k_sort_scan<BS>), dim3(places), dim3(BS), 0, st, counts);
+    hipLaunchKernelGGL((k_sort_hist<BS, IPT, RB>), dim3(blocks), dim3(BS), 0, st, ka, counts, n, full_blocks, begin_bit);
+    hipLaunchKernelGGL((k_sort_scan<BS, RB>), dim3(places), dim3(BS), 0, st, counts);
     for (unsigned p = 0; p < places; ++p) {
         const unsigned bit = begin_bit + p * RB, bits = std::min(RB, END_BIT - bit);
         const bool fwd = p % 2u == 0u;
-        hipLaunchKernelGGL((k_sort_pass<BS, IPT>), dim3(blocks), dim3(BS), 0, st, fwd ? ka : kb, fwd ? kb : ka, fwd ? va : vb,
+        hipLaunchKernelGGL((k_sort_pass<BS, IPT, RB>), dim3(blocks), dim3(BS), 0, st, fwd ? ka : kb, fwd ? kb : ka, fwd ? va : vb,
                            fwd ? vb : va, n, counts + p * RADIX, scratch_row, lb + static_cast<size_t>(p) * RADIX * blocks, bit, bits,
                            full_blocks, bid_t::create(bids + p));
     }
@@ -1484,7 +1482,17 @@ bool sort_codes(uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint32_t
     }
     // rocPRIM's gfx942 / gfx950 block shape for 8 + 4 byte pairs. Smaller blocks for mid-size sorts (256 x 8, 256 x 16, 512 x 8,
     // 256 x 4 from 100k to 2M items) all lose to the merge sort and to this shape: tools/jobs_r05/r05_job40.sh.
-    return onesweep<512, 16>(ka, va, kb, vb, n, begin_bit, st);
+    // Digits of 8 bits (the library's) or 9: whichever takes fewer passes over the bits that count (63 bits: 8 against 7 passes;
+    // 36 bits, a rebuild of a tree eleven levels deep: 5 against 4). A 9-bit pass costs what an 8-bit one does (4M rebuild: 0.706 ->
+    // 0.661 ms partial, 0.787 -> 0.757 full), a 10-bit one 19 us more at 4M -- the runs a block writes per bin get too short
+    // (tools/jobs_r05/r05_job68.sh, r05_job69.sh).
+    static const int knob_rb = [] {
+        const char *e = std::getenv("RK_SORT_RB"); // 8 / 9: digit width (A/B, tools/jobs_r05/r05_job68.sh); default: fewest passes
+        return e ? std::atoi(e) : 0;
+    }();
+    const unsigned bits = END_BIT - begin_bit;
+    const bool nine = knob_rb ? knob_rb == 9 : (bits + 8u) / 9u < (bits + 7u) / 8u;
+    return nine ? onesweep<512, 16, 9>(ka, va, kb, vb, n, begin_bit, st) : onesweep<512, 16, 8>(ka, va, kb, vb, n, begin_bit, st);
 }
 // Whether sort_codes() would take the onesweep path (the only one that looks at a sub-range of the bits) for n items.
 bool sort_is_onesweep(uint32_t n)
