@@ -1452,8 +1452,8 @@ bool onesweep(uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint32_t n
 } // namespace sortk
 
 // Sorts the n pairs of (ka, va) by bits [begin_bit, 63) of the keys, stably; (kb, vb) is scratch of the same size. Returns true when the
-// result is in (kb, vb) instead of (ka, va). begin_bit > 0 (the caller completes the order itself, k_local_sort) is honoured on the
-// onesweep path only.
+// result is in (kb, vb) instead of (ka, va). begin_bit > 0 (the caller completes the order itself, k_local_sort) always takes the
+// onesweep passes.
 long sort_onesweep_min()
 {
     static const long knob_min = [] {
@@ -1473,7 +1473,7 @@ bool sort_codes(uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint32_t
     // is even -- moves the rebuild by -14...+9 us between 30k and 1M items, inside the box-to-box noise: tools/jobs_r05/r05_job58.sh.)
     // Below 2^20 items the library's merge sort wins (launches of a dozen blocks of 8192 items leave the device empty: 100k +0.11 ms,
     // 1M +0.055 ms with the onesweep passes; 2M -0.045, 4M -0.057: tools/jobs_r05/r05_job37.sh).
-    if (knob_min < 0 || static_cast<long>(n) < knob_min || n > (1u << 28)) {
+    if (begin_bit == 0u && (knob_min < 0 || static_cast<long>(n) < knob_min || n > (1u << 28))) {
         size_t tb = 0;
         RK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, ka, kb, va, vb, static_cast<int>(n), 0, static_cast<int>(END_BIT), st));
         auto tmp = dalloc<unsigned char>(tb);
@@ -1494,11 +1494,13 @@ bool sort_codes(uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint32_t
     const bool nine = knob_rb ? knob_rb == 9 : (bits + 8u) / 9u < (bits + 7u) / 8u;
     return nine ? onesweep<512, 16, 9>(ka, va, kb, vb, n, begin_bit, st) : onesweep<512, 16, 8>(ka, va, kb, vb, n, begin_bit, st);
 }
-// Whether sort_codes() would take the onesweep path (the only one that looks at a sub-range of the bits) for n items.
-bool sort_is_onesweep(uint32_t n)
+// Whether a rebuild of n particles may sort a partial key (the onesweep passes look at a sub-range of the bits; the library call
+// does not): from half the size at which full sorts go to the onesweep passes -- four 9-bit passes + k_local_sort against the merge
+// sort: 350k equal, 600k -6 %, 1M -13 % of the rebuild (tools/jobs_r05/r05_job70.sh).
+bool sort_partial_ok(uint32_t n)
 {
     const long knob_min = sort_onesweep_min();
-    return n >= 2u && !(knob_min < 0 || static_cast<long>(n) < knob_min || n > (1u << 28));
+    return n >= 2u && knob_min >= 0 && static_cast<long>(n) >= knob_min / 2 && n <= (1u << 28);
 }
 
 } // namespace bld
@@ -1643,7 +1645,7 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
         return e ? std::atoi(e) : 1;
     }();
     unsigned sort_levels = CBITS;
-    if (s.bld_max_level >= 0 && partial_bias > -100 && mln <= 64u && sort_is_onesweep(n)) {
+    if (s.bld_max_level >= 0 && partial_bias > -100 && mln <= 64u && sort_partial_ok(n)) {
         sort_levels = static_cast<unsigned>(std::clamp(s.bld_max_level + partial_bias, 1, static_cast<int>(CBITS)));
     }
     dptr<uint64_t> keys_a;

@@ -1,0 +1,19 @@
+#!/bin/bash
+# After lowering the partial-sort threshold to 2^19 particles: tests, leapfrog sizes.
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $ROOT
+O=$ROOT/gpurun_out/r05_job71
+mkdir -p $O
+timeout 1200 python3 -m pytest tests/test_gpu_leapfrog.py tests/test_gpu_device_build.py tests/test_gpu_quadtree.py tests/test_gpu_state_create.py -x -q 2>&1 | tail -3 | tee $O/pytest.txt
+make -C examples > /dev/null 2>&1
+for rep in 1 2 3; do
+  for n in 100000 350000 600000 1000000 2000000 4000000; do
+    echo -n "now $n " | tee -a $O/leapfrog.txt
+    timeout 300 examples/leapfrog --nparts $n --steps 40 --warmup 5 2>&1 | tail -1 | python3 -c '
+import sys,re
+l=sys.stdin.read()
+g=lambda k: float(re.search("\"%s\": ([0-9.]+)" % k, l).group(1))
+print("step %.4f rebuild %.4f traversal %.4f" % (g("ms_per_step"), g("ms_rebuild"), g("ms_traversal")))' | tee -a $O/leapfrog.txt
+  done
+done
