@@ -391,10 +391,13 @@ __global__ void __launch_bounds__(256) k_local_sort(const uint64_t *codes, const
     const unsigned lf = leaf[i];
     uint32_t dest = i;
     if (lf < geo<ND>::CB) {
+        // Same leaf <=> the first lf levels of the codes agree <=> nothing of (cj ^ c) is left above the bits of the levels below lf.
+        // (The filler ~0 has bit 63 set, no code has: it never matches.)
+        const unsigned shift = geo<ND>::DB * (geo<ND>::CB - lf);
         uint32_t before = 0, first = i;
         for (uint32_t k = 1; k <= span; ++k) {
             const uint64_t cj = s_code[me - k];
-            if (cj == ~0ull || common_levels<ND>(cj, c) < lf) {
+            if (((cj ^ c) >> shift) != 0ull) {
                 break;
             }
             first = i - k;
@@ -402,7 +405,7 @@ __global__ void __launch_bounds__(256) k_local_sort(const uint64_t *codes, const
         }
         for (uint32_t k = 1; k <= span; ++k) {
             const uint64_t cj = s_code[me + k];
-            if (cj == ~0ull || common_levels<ND>(cj, c) < lf) {
+            if (((cj ^ c) >> shift) != 0ull) {
                 break;
             }
             before += (cj < c || (cj == c && s_ord[me + k] < o)) ? 1u : 0u;
