@@ -437,7 +437,8 @@ __global__ void k_node_counts(const uint64_t *codes, uint32_t n, const uint8_t *
 }
 // (Rounds 2-5 also reduced the deepest leaf level here, for the host to skip the empty level passes of the node sums: first with one
 // atomicMax per block on one word of the control block -- 15 600 same-address atomics, 150 us at 4M particles --, then with an
-// agent-scope load of that word per block, 62 us against 14 for the kernel's own work. The level passes are gone.)
+// agent-scope load of that word per block, 62 us against 14 for the kernel's own work. The level passes are gone; the deepest level
+// -- now the hint for the next rebuild's partial sort -- is taken by the leaf-level kernel, one plain store per block.)
 
 // One block: the node count (total of the scan) and the deepest leaf level (maximum over the leaf-level kernel's blocks; block_max ==
 // null: not known, the deepest possible) for the host.
