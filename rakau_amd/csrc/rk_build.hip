@@ -129,7 +129,7 @@ enum { ERR_COORD = 1u, ERR_COM = 2u, ERR_DIM = 4u, ERR_BOX = 8u };
 
 // ---- box size -------------------------------------------------------------------------------------------
 template <typename F>
-__global__ void k_maxabs(const F *x, const F *y, const F *z, uint32_t n, ctrl_block *ctrl)
+__global__ void __launch_bounds__(1024) k_maxabs(const F *x, const F *y, const F *z, uint32_t n, ctrl_block *ctrl)
 {
     unsigned long long *out_bits = &ctrl->maxbits;
     unsigned *err = &ctrl->err;
@@ -153,8 +153,8 @@ __global__ void k_maxabs(const F *x, const F *y, const F *z, uint32_t n, ctrl_bl
         const unsigned long long other = __shfl_xor(bits, o, 64);
         bits = other > bits ? other : bits;
     }
-    __shared__ unsigned long long s_bits[4];
-    __shared__ int s_bad[4];
+    __shared__ unsigned long long s_bits[16];
+    __shared__ int s_bad[16];
     const unsigned w = threadIdx.x >> 6;
     const bool wave_bad = __ballot(bad) != 0ull;
     if ((threadIdx.x & 63u) == 0u) {
@@ -1672,7 +1672,9 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
         const bool partial = sort_levels < CBITS;
         const unsigned begin_bit = partial ? bld::geo<ND>::DB * (CBITS - sort_levels) : 0u;
         if (s.box_deduced) {
-            hipLaunchKernelGGL((k_maxabs<F>), dim3(std::min(nblk(n), 1024u)), dim3(256), 0, st, dx.get(), dy.get(), dz.get(), n,
+            // (At most one block of 1024 threads per CU: the blocks end with one atomic each on ONE word, ~10 ns apiece -- 1024 blocks
+            // of 256 threads spent half of the kernel's 20 us at 4M particles in them.)
+            hipLaunchKernelGGL((k_maxabs<F>), dim3(std::min(nblk(n, 1024), 256u)), dim3(1024), 0, st, dx.get(), dy.get(), dz.get(), n,
                                ctrl.get());
         }
         // (ka, va): the codes and indices, sorted in place; (kb, vb): the other half of the sort's ping-pong.
