@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """Generate tests/golden/oracle_cases.npz: small input/output vectors for the hot path.
 
-PROVENANCE: the reference cannot be built or run in this image (its mandatory dependencies TBB, xsimd
-and Boost are absent), so these vectors are produced by the CPU oracle (oracle/rakau_oracle.cpp), which is
-itself pinned against the reference outputs recorded in SURVEY.md section 8(c)
-(tests/golden/survey_checkpoints.json) and against the reference's own known-answer tests
-(tests/test_oracle_reference_tests.py). They freeze the oracle's behaviour so that drift is detected, and give
-the GPU tests fixed vectors that do not depend on the oracle library being rebuilt.
+PROVENANCE: PARITY-UNPINNED, as oracle/rakau_oracle.cpp:14 says. The reference cannot be built or run in this image
+(its mandatory dependencies TBB, xsimd and Boost are absent) and ships no input/output vectors, so these vectors are
+produced by the CPU oracle (oracle/rakau_oracle.cpp), a line-level restatement of the reference's scalar CPU path. The
+oracle is constrained by the reference's own property tests restated on it (tests/test_oracle_reference_tests.py); the
+numbers in tests/golden/survey_checkpoints.json come from a survey-time build against stand-in headers and pin nothing.
+These files freeze the oracle's behaviour so that drift is detected, and give the GPU tests fixed vectors that do not
+depend on the oracle library being rebuilt. They are not outputs of the reference.
 
 Run from the repository root:  python tests/golden/make_golden.py
 """

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Generate tests/golden/oracle_cases_nd.npz: frozen vectors for the quadtree (NDim = 2) and 32-bit-code variants.
 
-Same provenance as make_golden.py: produced by the CPU oracle (the reference cannot be built here); for quadtrees the
-oracle is pinned by the reference's node-centre known-answer test and by the accuracy / G / ordering properties
-(tests/test_oracle_quadtree.py).
+Same provenance as make_golden.py (PARITY-UNPINNED): produced by the CPU oracle, not by the reference (which cannot be
+built here); for quadtrees the oracle is constrained -- not pinned -- by the reference's node-centre known-answer test and
+by the accuracy / G / ordering properties restated on it (tests/test_oracle_quadtree.py).
 
 Run from the repository root:  python tests/golden/make_golden_nd.py
 """

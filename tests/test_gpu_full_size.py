@@ -3,7 +3,8 @@ exact G scaling, shard union == full result bit for bit, direct sums) plus the o
 nodes taken from the start, the quartiles and the end of the Morton order and around the innermost and outermost
 particle (core and halo of the Plummer sphere).
 
-  config 2: 4M fp32 theta=0.75 accs_u                     -> test_4m_properties
+  config 2: 4M fp32 theta=0.75 accs_u                     -> test_4m_accs_u_headline (Q = 0, default variant, seven windows),
+                                                             test_4m_properties (Q = 2, variants 0 and 1)
   config 3: 4M fp32 theta=0.75 accs_pots_u with softening -> test_4m_accs_pots_softened
   config 4: 16M fp64 theta=0.5 accs_u                     -> test_16m_fp64_theta05
   config 5: 64M fp32 theta=0.75, whole and as 8 Morton shards run back to back -> test_64m_sharded
@@ -113,6 +114,13 @@ def check_full_size(n, dtype, theta, q, eps, n_shards, width, tol_max, tol_med, 
           % (n, np.dtype(dtype).name, theta, q, len(wins), width, worst, worst_pot))
     del ot, st, t, full
     gc.collect()
+
+
+def test_4m_accs_u_headline():
+    """BASELINE config 2, the configuration the metric is quoted on: accs_u() (Q = 0), unsoftened, default kernel variant,
+    compared with the oracle on the same seven windows as configs 3-5 (start, quartiles, end, core, halo)."""
+    check_full_size(4_000_000, "float32", 0.75, 0, 0.0, n_shards=8, width=600, tol_max=2e-4, tol_med=3e-6,
+                    n_direct=20)
 
 
 def test_4m_accs_pots_softened():

@@ -166,7 +166,7 @@ def test_list_and_producer_consumer_kernels_give_the_same_bits(dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_accs_pots_equal_accs_and_pots(dtype, variant):
     """accs_u(), pots_u() and accs_pots_u() evaluate the same expressions (as the reference's batch_batch_3d_* do,
     tree.hpp:2008-2068): the accelerations of Q = 0 and the potentials of Q = 1 are those of Q = 2, bit for bit."""
