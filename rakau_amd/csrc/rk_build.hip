@@ -1392,6 +1392,18 @@ void exclusive_scan(const tri *in, tri *out, size_t n, hipStream_t st)
 }
 
 // ---- Morton sort ------------------------------------------------------------------------------------------
+// The onesweep launch sequence below calls functions of rocPRIM's PRIVATE namespace (rocprim::detail::onesweep_histograms,
+// onesweep_scan_histograms, onesweep_iteration, onesweep_lookback_state, block_id_wrapper). It was written against -- and its
+// look-back protocol (zero = empty state, offsets_in / offsets_out semantics) checked against -- rocPRIM 4.2.0 (ROCm 7.2.0) only:
+// with any other version of the library, or with -DRK_SORT_LIBRARY_ONLY, it is compiled out, every sort goes through the public
+// hipcub::DeviceRadixSort::SortPairs() and rebuilds sort full keys (sort_partial_ok() is false). RK_SORT_MIN=-1 selects the same
+// path at run time; tests/test_gpu_leapfrog.py compares the two bit for bit.
+#if !defined(RK_SORT_LIBRARY_ONLY) && defined(ROCPRIM_VERSION) && ROCPRIM_VERSION == 400200
+#define RK_ONESWEEP_INTERNALS 1
+#else
+#define RK_ONESWEEP_INTERNALS 0
+#endif
+#if RK_ONESWEEP_INTERNALS
 // Stable LSD radix sort of (63-bit code, index) pairs: rocPRIM's onesweep DEVICE functions (histograms of every digit place in one
 // pass over the keys, then one decoupled-look-back scatter pass per 8-bit digit) under this file's own launch sequence.
 // hipcub::DeviceRadixSort::SortPairs() runs the same device code but resets its look-back states and its ordered-block counter with
@@ -1454,12 +1466,21 @@ bool onesweep(uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint32_t n
     return places % 2u == 1u;
 }
 } // namespace sortk
+#else
+namespace sortk
+{
+constexpr unsigned END_BIT = 63;
+}
+#endif
 
 // Sorts the n pairs of (ka, va) by bits [begin_bit, 63) of the keys, stably; (kb, vb) is scratch of the same size. Returns true when the
 // result is in (kb, vb) instead of (ka, va). begin_bit > 0 (the caller completes the order itself, k_local_sort) always takes the
 // onesweep passes.
 long sort_onesweep_min()
 {
+#if !RK_ONESWEEP_INTERNALS
+    return -1; // (not the rocPRIM this file's onesweep sequence was written against: the public library call for every size)
+#endif
     static const long knob_min = [] {
         const char *e = std::getenv("RK_SORT_MIN"); // items from which the onesweep sequence replaces the library call (-1: never)
         return e ? std::atol(e) : (1l << 20);
@@ -1484,6 +1505,9 @@ bool sort_codes(uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint32_t
         RK_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.get(), tb, ka, kb, va, vb, static_cast<int>(n), 0, static_cast<int>(END_BIT), st));
         return true;
     }
+#if !RK_ONESWEEP_INTERNALS
+    throw error(RK_ERUNTIME, "internal error: a partial-key sort was asked for in a build without the onesweep launch sequence");
+#else
     // rocPRIM's gfx942 / gfx950 block shape for 8 + 4 byte pairs. Smaller blocks for mid-size sorts (256 x 8, 256 x 16, 512 x 8,
     // 256 x 4 from 100k to 2M items) all lose to the merge sort and to this shape: tools/jobs_r05/r05_job40.sh.
     // Digits of 8 bits (the library's) or 9: whichever takes fewer passes over the bits that count (63 bits: 8 against 7 passes;
@@ -1497,6 +1521,7 @@ bool sort_codes(uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint32_t
     const unsigned bits = END_BIT - begin_bit;
     const bool nine = knob_rb ? knob_rb == 9 : (bits + 8u) / 9u < (bits + 7u) / 8u;
     return nine ? onesweep<512, 16, 9>(ka, va, kb, vb, n, begin_bit, st) : onesweep<512, 16, 8>(ka, va, kb, vb, n, begin_bit, st);
+#endif
 }
 // Whether a rebuild of n particles may sort a partial key (the onesweep passes look at a sub-range of the bits; the library call
 // does not): from half the size at which full sorts go to the onesweep passes -- four 9-bit passes + k_local_sort against the merge
@@ -1552,15 +1577,33 @@ void replica_first_order(rk_state &s)
 // The host's view of a build's control block: the block is copied into pinned host memory by an asynchronous copy behind the kernel
 // that completes it, an event marks the copy, and the host waits for the event only when it needs the numbers -- after it has
 // handed the device the work that does not depend on them (a blocking hipMemcpy cost ~15 us of idle device per look-up, three per
-// build). One set of buffers and events per calling thread and device, made on first use, never given back.
+// build). One set of buffers and events per calling thread and device, made on first use, given back when the thread ends
+// (a thread's destructors run before the runtime's own at process exit; errors from a runtime that is already gone are ignored).
 struct lookup_slots {
     int device = -1;
     bld::ctrl_block *host = nullptr;
     hipEvent_t ev[3] = {};
 };
+struct lookup_slots_owner {
+    std::vector<lookup_slots> all;
+    ~lookup_slots_owner()
+    {
+        for (auto &l : all) {
+            for (auto &e : l.ev) {
+                if (e) {
+                    (void)hipEventDestroy(e);
+                }
+            }
+            if (l.host) {
+                (void)hipHostFree(l.host);
+            }
+        }
+    }
+};
 static lookup_slots &thread_lookup_slots()
 {
-    static thread_local std::vector<lookup_slots> all;
+    static thread_local lookup_slots_owner owner;
+    auto &all = owner.all;
     int dev = 0;
     RK_HIP(hipGetDevice(&dev));
     for (auto &l : all) {

@@ -78,6 +78,11 @@ int forked_cap()
 // executables growing (RK_GRAPH_UPDATE=0: never re-target; the cap then ends replay as in round 3).
 std::mutex g_parked_mtx;
 std::map<int, std::vector<hipGraphExec_t>> g_parked;
+// One stream capture (and instantiation / re-targeting of what it captured) at a time in the process, whatever the precision of
+// the state: the blocking host-output call captures too, and the device threads of a multi-device split make such calls side by
+// side (captures are rare -- once per signature --; concurrent captures on logical devices that alias one GPU failed intermittently
+// in round 4). Namespace scope: a static inside the template run_impl<F> was one mutex per precision.
+std::mutex g_capture_mtx;
 bool graph_update_enabled()
 {
     static const bool on = [] {
@@ -276,11 +281,16 @@ void stage_trim()
 // Give the tree-dependent device buffers back to the pool (after a device sync: traversal kernels on other
 // streams may still be reading them) and forget everything derived from them. Streams, events and the output /
 // supergroup scratch survive, so that a state can be rebuilt in place every time step.
-void free_retired_plan_buffers_device_idle(); // (launch-plan buffers parked until the device is idle: see build_plan())
+std::vector<void *> take_retired_plan_buffers(); // (launch-plan buffers parked until the device is idle: see build_plan())
 void release_tree(rk_state *s)
 {
+    // The snapshot is taken BEFORE the drain: a buffer another thread retires while this one is blocked in the synchronisation
+    // may still be read by a kernel the synchronisation does not cover; it waits for the next drain.
+    const std::vector<void *> retired = take_retired_plan_buffers();
     (void)hipDeviceSynchronize();
-    free_retired_plan_buffers_device_idle();
+    for (void *b : retired) {
+        rk::pool_free(b);
+    }
     for (int i = 0; i < RK_NBUF; ++i) {
         rk::pool_free(s->buf[i]);
         s->buf[i] = nullptr;
@@ -334,6 +344,9 @@ void free_state(rk_state *s)
     }
     if (s->ev_mid) {
         (void)hipEventDestroy(s->ev_mid);
+    }
+    if (s->ev_done) {
+        (void)hipEventDestroy(s->ev_done);
     }
     for (auto &e : s->ev_arr) {
         if (e) {
@@ -863,48 +876,58 @@ bool plan_regions_enabled()
 // or 64 of them (a few hundred KB) have piled up, which costs one drain for all.
 std::mutex g_retired_mtx;
 std::vector<std::pair<int, void *>> g_retired_plan_buffers; // (physical device, buffer)
-// The CURRENT device has just been synchronised: its retired buffers go back to the block cache.
-void free_retired_plan_buffers_device_idle()
+// Takes the CURRENT device's retired buffers off the list. The caller synchronises the device AFTERWARDS and only then hands
+// them back to the block cache: whatever is retired during that synchronisation (by another state or thread on the same GPU,
+// possibly while a kernel launched after the drain began still reads it) is not in the snapshot and waits for the next drain.
+std::vector<void *> take_retired_plan_buffers()
 {
+    std::vector<void *> mine;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) {
-        return;
+        return mine;
     }
-    std::vector<void *> mine;
-    {
-        std::lock_guard<std::mutex> lk(g_retired_mtx);
-        auto keep = g_retired_plan_buffers.begin();
-        for (auto &e : g_retired_plan_buffers) {
-            if (e.first == dev) {
-                mine.push_back(e.second);
-            } else {
-                *keep++ = e;
-            }
+    std::lock_guard<std::mutex> lk(g_retired_mtx);
+    auto keep = g_retired_plan_buffers.begin();
+    for (auto &e : g_retired_plan_buffers) {
+        if (e.first == dev) {
+            mine.push_back(e.second);
+        } else {
+            *keep++ = e;
         }
-        g_retired_plan_buffers.erase(keep, g_retired_plan_buffers.end());
     }
-    for (void *b : mine) {
-        rk::pool_free(b);
-    }
+    g_retired_plan_buffers.erase(keep, g_retired_plan_buffers.end());
+    return mine;
 }
 void retire_plan_buffer(int dev, void *b) noexcept
 {
     size_t n = 0;
+    bool listed = false;
     try {
         std::lock_guard<std::mutex> lk(g_retired_mtx);
         g_retired_plan_buffers.emplace_back(dev, b);
+        listed = true;
         for (const auto &e : g_retired_plan_buffers) {
             n += e.first == dev ? 1u : 0u;
         }
     } catch (...) {
-        n = 64; // (out of memory for the list itself: the buffer is in it or not; drain either way, then free it)
+        n = 64; // (out of memory for the list itself: drain, then free the buffer directly if it is not on the list)
     }
     if (n >= 64) {
         int prev = 0;
         (void)hipGetDevice(&prev);
         (void)hipSetDevice(dev);
+        std::vector<void *> mine;
+        try {
+            mine = take_retired_plan_buffers(); // snapshot first, drain second (see above)
+        } catch (...) {
+        }
         (void)hipDeviceSynchronize();
-        free_retired_plan_buffers_device_idle();
+        for (void *r : mine) {
+            rk::pool_free(r);
+        }
+        if (!listed) {
+            rk::pool_free(b);
+        }
         (void)hipSetDevice(prev);
     }
 }
@@ -1765,11 +1788,8 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                 ++s.graph_stats[2];
             } else {
                 hipGraph_t graph = nullptr;
-                // One capture at a time in the process: since round 5 the blocking host-output call captures too, and the device
-                // threads of a multi-device split make such calls side by side (captures are rare -- once per signature -- so the
-                // lock costs nothing; concurrent captures on logical devices that alias one GPU failed intermittently in round 4).
-                static std::mutex capture_mtx;
-                std::lock_guard<std::mutex> capture_lock(capture_mtx);
+                // One capture at a time in the process (g_capture_mtx); released before the launch of what was captured.
+                std::unique_lock<std::mutex> capture_lock(g_capture_mtx);
                 RK_HIP(hipStreamBeginCapture(s.cap_stream, hipStreamCaptureModeThreadLocal));
                 try {
                     enqueue(s.cap_stream, true);
@@ -1850,6 +1870,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                     }
                     s.gcache.push_back(rk_state::graph_entry{key, exec, forked});
                     s.gcache_plan.push_back(uses_plan ? s.plan : rk_state::launch_plan{});
+                    capture_lock.unlock();
                     RK_HIP(hipGraphLaunch(exec, stream));
                     ++s.graph_stats[1];
                     s.graph_stats[3] += updated ? 1u : 0u;

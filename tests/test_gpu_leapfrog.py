@@ -242,6 +242,70 @@ def test_rebuild_with_a_partial_sort_equals_a_fresh_build(bias):
         assert len(partial) > len(again) >= 1, lines
 
 
+def test_rebuild_on_the_public_library_sort_equals_a_fresh_build():
+    """RK_SORT_MIN=-1 is the path a build against another rocPRIM than 4.2.0 takes (rk_build.hip RK_ONESWEEP_INTERNALS): every sort
+    through hipcub::DeviceRadixSort, no partial-key rebuilds. Same sequence of rebuilds as the partial-sort test, same comparison
+    with fresh host builds bit for bit."""
+    import subprocess
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    env = dict(os.environ, RK_SORT_MIN="-1", RK_SORT_TRACE="1")
+    env.pop("RK_SORT_PARTIAL", None)
+    env["PYTHONPATH"] = os.pathsep.join([root, os.path.join(root, "tests"), env.get("PYTHONPATH", "")])
+    out = subprocess.run([sys.executable, "-c", PARTIAL_SORT_CODE], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0 and "PARTIAL_SORT_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+    import re
+    lines = [l for l in out.stderr.splitlines() if l.startswith("rk_build:")]
+    partial = [l for l in lines if (lambda mm: mm and int(mm.group(1)) < int(mm.group(2)))(re.search(r"sorted levels (\d+) of (\d+)", l))]
+    assert not partial, partial
+
+
+SORT_PATHS_CODE = r"""
+import hashlib, sys
+import numpy as np, torch
+import rakau_amd
+from bench import plummer_numpy
+dev = torch.device("cuda", 0)
+n = 2_000_000
+m, x, y, z = plummer_numpy(n, "float32")
+h = hashlib.sha256()
+tm = torch.as_tensor(m).to(dev)
+ts = [torch.as_tensor(v).to(dev) for v in (x, y, z)]
+torch.cuda.synchronize()
+st = rakau_amd.State.build_device([t.data_ptr() for t in ts] + [tm.data_ptr()], n, np.float32)
+rs = np.random.RandomState(11)
+for step in range(3):
+    for what in ("codes", "perm", "crit", "x", "m"):
+        h.update(st.download(what).tobytes())
+    h.update(st.download("nodes").tobytes())
+    for r in st.acc_pot(0, rakau_amd.mac_value_of(0.75, "bh", np.float32)):
+        h.update(r.tobytes())
+    x = (x + np.float32(1e-3) * rs.standard_normal(n).astype(np.float32)).astype(np.float32)
+    ts[0] = torch.as_tensor(x).to(dev)
+    torch.cuda.synchronize()
+    st.rebuild_device([t.data_ptr() for t in ts] + [tm.data_ptr()], nparts=n)
+print("SORT_PATHS_HASH", h.hexdigest(), st.tree_size, st.n_crit)
+"""
+
+
+def test_2m_rebuild_onesweep_and_library_sorts_give_the_same_tree():
+    """2M particles (above 2^20: the default build sorts with the onesweep launch sequence on rocPRIM's internals, 8- and 9-bit
+    digits, partial keys in the rebuilds) against the public-API path (RK_SORT_MIN=-1): codes, permutation, critical nodes, node
+    records and the accelerations of a build and two rebuilds hash to the same value."""
+    import subprocess
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    got = {}
+    for name, extra in (("onesweep", {}), ("library", {"RK_SORT_MIN": "-1"}), ("onesweep8", {"RK_SORT_RB": "8"})):
+        env = dict(os.environ, **extra)
+        if not extra:
+            env.pop("RK_SORT_MIN", None)
+        env["PYTHONPATH"] = os.pathsep.join([root, os.path.join(root, "tests"), env.get("PYTHONPATH", "")])
+        out = subprocess.run([sys.executable, "-c", SORT_PATHS_CODE], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+        line = [l for l in out.stdout.splitlines() if l.startswith("SORT_PATHS_HASH")]
+        assert out.returncode == 0 and line, out.stdout[-2000:] + out.stderr[-4000:]
+        got[name] = line[0]
+    assert got["onesweep"] == got["library"] == got["onesweep8"], got
+
+
 def cpu_leapfrog(x, y, z, vx, vy, vz, m, dt, steps, theta, eps):
     """The same KDK loop with the oracle as force engine (float64 bookkeeping of the same operations)."""
     pos = [x.copy(), y.copy(), z.copy()]
