@@ -124,6 +124,7 @@ struct ctrl_block {
     unsigned class2_count[8];   // critical nodes per lane-mapping class (list kernel binning)
     unsigned max_level;         // deepest leaf level of the tree (the next rebuild sorts the code bits of that many levels + 1 only)
     unsigned pad[4];
+    unsigned first_grid[4];     // light-tail arrangement of a first call: 8 x the longest per-region queue of each wave-kernel class
 };
 enum { ERR_COORD = 1u, ERR_COM = 2u, ERR_DIM = 4u, ERR_BOX = 8u };
 
@@ -484,7 +485,7 @@ __global__ void __launch_bounds__(256) k_pack_nodes(ctrl_block *ctrl, const uint
 // node by galloping from its first particle. Rounds 2-5 gave the whole nest to the thread of the first particle, which found the ends
 // one after the other, each search starting where the previous one ended -- fewer probes in all, but the first particle of a large
 // cell walks up a dozen levels and its wavefront waits for that lane: 128 us at 4M particles against 9 + 35 (rebuild 0.945 -> 0.853 ms,
-// 1M 0.462 -> 0.425; tools/jobs_r05/r05_job47.sh).
+// 1M 0.462 -> 0.425; tools/archive/jobs_r05/r05_job47.sh).
 __global__ void k_node_starts(uint32_t n, const uint8_t *leaf, const uint8_t *ldiv, const uint32_t *off, uint32_t *start_of)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -624,14 +625,14 @@ __global__ void k_parents(const uint4 *topo, const uint64_t *ncode, uint32_t n_n
 // ---- node properties --------------------------------------------------------------------------------------
 // (Rounds 2-5 aggregated children into parents with one launch per tree level -- 9 launches at 100k particles, 11 at 4M, ~5 us each
 // however little a level holds; the summation pyramid further down replaced them. Variants of the level passes built and measured
-// before that, none kept -- tools/jobs_r05/r05_job37.sh, r05_job38.sh: (1) leaf sums and all levels in ONE launch,
+// before that, none kept -- tools/archive/jobs_r05/r05_job37.sh, r05_job38.sh: (1) leaf sums and all levels in ONE launch,
 // the last child to deliver its sum adds up the parent (atomic counters): on eight XCDs every release / acquire pair is an L2
 // write-back + invalidate, 2.1 ms instead of 0.07 at 4M particles; (2) two or three levels per launch, the upper ones recomputing
 // the sums of their internal children instead of reading them: the walk over a node's children is a chain of dependent loads
 // (c += topo[c].x + 1), nested it is 72 deep -- rebuild +0.03 ms at 100k, +0.07 at 4M for two levels, +0.13 / +0.35 for three.
 // (3) the top five levels in ONE launch of one workgroup (the internal nodes found from the root through the child table into LDS
 // queues, then summed level by level between barriers): 24 us at 100k particles and 52 us at 4M for the five ~5 us passes it replaced --
-// a lone workgroup pays every dependent load in full (tools/jobs_r05/r05_job50.sh, r05_job51.sh).)
+// a lone workgroup pays every dependent load in full (tools/archive/jobs_r05/r05_job50.sh, r05_job51.sh).)
 
 // ---- node sums in the reference's association (exact mode) ----
 // The reference sums a node's particles serially in particle order (tree.hpp:1162-1168). Nodes that start at the same
@@ -1180,18 +1181,8 @@ static_assert(NBIN >= static_cast<unsigned>(n_classes));
 // wavefront serves; oversized nodes (their own kernel) get the last key and fall off the end of the list.
 constexpr unsigned FIRST_ORDER_KEY_BITS = 8;
 static_assert(((64 * RK_MAX_R) >> 1) < (1 << FIRST_ORDER_KEY_BITS) - 1);
-__global__ void k_first_keys(const uint4 *crit, uint32_t n_crit, uint32_t *keys, uint32_t *vals)
-{
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < n_crit) {
-        const uint32_t size = crit[g].w;
-        keys[g] = (size == 0u || size > 64u * RK_MAX_R) ? (1u << FIRST_ORDER_KEY_BITS) - 1u : (64u * RK_MAX_R - size) >> 1; // = first_key(size)
-        vals[g] = g;
-    }
-}
-
 // The three kernels below also make the first-call launch order of small trees when they are handed key_hist / first_order: the same
-// stable partition over the 256 keys of k_first_keys -- per-block histograms, a scan per key over the blocks, a scatter that ranks
+// stable partition over the 256 keys of first_key() -- per-block histograms, a scan per key over the blocks, a scatter that ranks
 // every node among the equal keys of its block (wavefront: the lanes with the same key from eight ballots; block: counts per wave
 // in LDS). Rounds 4-5 sorted (key, index) pairs with the library afterwards: 4-8 launches of ~5 us each on a 100k-particle tree.
 constexpr unsigned NKEY = 1u << FIRST_ORDER_KEY_BITS;
@@ -1199,8 +1190,70 @@ __device__ inline uint32_t first_key(uint32_t size)
 {
     return (size == 0u || size > 64u * RK_MAX_R) ? NKEY - 1u : (64u * RK_MAX_R - size) >> 1;
 }
+
+// Trees of FIRST_ORDER_MAX .. FIRST_TAIL_MAX critical nodes get the LIGHT-TAIL arrangement for their first call instead -- what the
+// host makes for repeated calls of that size (rk_state.hip build_plan, arrange_light_tail): per wave-kernel class the nodes in Morton
+// order with the lightest quarter of the class moved to the end, so that the device drains over short waves, and one spatial region
+// of the tree per XCD, the same regions in every class kernel, so that neighbouring nodes share an L2 whatever their class. Same
+// three partition kernels, other key: (class, region, bulk | light). Regions are cut at equal weight = particle count, and the
+// critical nodes tile the particle range, so the region of a node follows from its first particle alone. The size from which a
+// node of class c counts as bulk (the value at the first quartile of the sizes of the class, estimated on a sample: k_tail_thr)
+// is computed first.
+__device__ inline uint32_t tail_key(uint32_t size, uint32_t c, uint32_t begin, uint32_t nparts, const uint32_t (&thr)[RK_MAX_R])
+{
+    if (size == 0u || size > 64u * RK_MAX_R) {
+        return NKEY - 1u;
+    }
+    const uint64_t x8 = static_cast<uint64_t>(begin) * 8u / nparts;
+    return c * 16u + static_cast<uint32_t>(x8 < 7u ? x8 : 7u) * 2u + (size >= thr[c] ? 0u : 1u);
+}
+static_assert(RK_MAX_R * 16 <= NKEY - 1);
+// thr[c] = the size at position floor(n_c / 4) of the ascending sizes of class c among a SAMPLE of the critical nodes -- every
+// tail_stride(n_crit)-th one, at most 8192: one block takes their sizes into an LDS histogram (no global atomics: thousands of nodes
+// share every common size, and same-address atomics cost the 4M rebuild 0.45 ms when every node made one), one thread per size
+// looks its class up, one thread per class finds the quartile. The result goes behind the queue table, first_tab[64 + c].
+__host__ __device__ inline uint32_t tail_stride(uint32_t n_crit)
+{
+    return n_crit / 8192u > 1u ? n_crit / 8192u : 1u;
+}
+__global__ void __launch_bounds__(1024) k_tail_thr(const uint4 *crit, uint32_t n_crit, uint32_t *first_tab)
+{
+    __shared__ uint32_t cnt[64 * RK_MAX_R + 1];
+    __shared__ uint8_t cls[64 * RK_MAX_R + 1];
+    for (unsigned sz = threadIdx.x; sz <= 64u * RK_MAX_R; sz += blockDim.x) {
+        cnt[sz] = 0u;
+        cls[sz] = static_cast<uint8_t>(class2_of_compute(sz ? sz : 1u));
+    }
+    __syncthreads();
+    const uint32_t stride = tail_stride(n_crit);
+    for (uint32_t g = threadIdx.x * stride; g < n_crit; g += blockDim.x * stride) {
+        const uint32_t size = crit[g].w;
+        if (size >= 1u && size <= 64u * RK_MAX_R) {
+            atomicAdd(&cnt[size], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < RK_MAX_R) {
+        const unsigned c = threadIdx.x;
+        uint32_t n_c = 0u;
+        for (uint32_t sz = 1u; sz <= 64u * RK_MAX_R; ++sz) {
+            n_c += cls[sz] == c ? cnt[sz] : 0u;
+        }
+        const uint32_t k = n_c ? (n_c / 4u < n_c - 1u ? n_c / 4u : n_c - 1u) : 0u;
+        uint32_t cum = 0u, t = 0u;
+        for (uint32_t sz = 1u; sz <= 64u * RK_MAX_R && t == 0u; ++sz) {
+            cum += cls[sz] == c ? cnt[sz] : 0u;
+            if (cum > k) {
+                t = sz;
+            }
+        }
+        first_tab[64u + c] = t;
+    }
+}
+
+// tail != 0 (= the number of particles): the keys of the light-tail arrangement instead of those of the heavy-first order.
 __global__ void __launch_bounds__(256) k_bin_count(const uint4 *crit, uint32_t n_crit, uint32_t *block_hist, ctrl_block *ctrl,
-                                                   uint32_t *key_hist)
+                                                   uint32_t *key_hist, uint32_t tail, const uint32_t *first_tab)
 {
     __shared__ uint32_t h[NBIN];
     __shared__ uint32_t hk[NKEY];
@@ -1213,14 +1266,23 @@ __global__ void __launch_bounds__(256) k_bin_count(const uint4 *crit, uint32_t n
     if (threadIdx.x == 0u) {
         mx = 0u;
     }
+    uint32_t thr[RK_MAX_R] = {};
+    if (tail) {
+#pragma unroll
+        for (int k = 0; k < RK_MAX_R; ++k) {
+            thr[k] = first_tab[64 + k]; // (k_tail_thr)
+        }
+    }
     __syncthreads();
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g < n_crit) {
-        const uint32_t size = crit[g].w;
-        atomicAdd(&h[class2_of_compute(size)], 1u);
+        const uint4 c4 = crit[g];
+        const uint32_t size = c4.w;
+        const auto c = static_cast<uint32_t>(class2_of_compute(size));
+        atomicAdd(&h[c], 1u);
         atomicMax(&mx, size);
         if (key_hist) {
-            atomicAdd(&hk[first_key(size)], 1u);
+            atomicAdd(&hk[tail ? tail_key(size, c, c4.x, tail, thr) : first_key(size)], 1u);
         }
     }
     __syncthreads();
@@ -1277,8 +1339,8 @@ __global__ void __launch_bounds__(256) k_bin_scan(uint32_t *block_hist, uint32_t
 }
 
 __global__ void __launch_bounds__(256) k_bin_scatter(const uint4 *crit, uint32_t n_crit, const uint32_t *block_base,
-                                                     const ctrl_block *ctrl, uint32_t *lists, const uint32_t *key_base,
-                                                     const uint32_t *key_total, uint32_t *first_order)
+                                                     ctrl_block *ctrl, uint32_t *lists, const uint32_t *key_base,
+                                                     const uint32_t *key_total, uint32_t *first_order, uint32_t tail, uint32_t *first_tab)
 {
     __shared__ uint32_t wave_cnt[4][NBIN];
     __shared__ uint32_t wave_key[4][NKEY];
@@ -1286,7 +1348,15 @@ __global__ void __launch_bounds__(256) k_bin_scatter(const uint4 *crit, uint32_t
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     const bool valid = g < n_crit;
-    const uint32_t size = valid ? crit[g].w : 0u;
+    const uint4 c4 = valid ? crit[g] : make_uint4(0u, 0u, 0u, 0u);
+    const uint32_t size = c4.w;
+    uint32_t thr[RK_MAX_R] = {};
+    if (tail) {
+#pragma unroll
+        for (int k = 0; k < RK_MAX_R; ++k) {
+            thr[k] = first_tab[64 + k]; // (k_tail_thr)
+        }
+    }
     const unsigned c = valid ? static_cast<unsigned>(class2_of_compute(size)) : NBIN;
     uint32_t rank = 0u;
 #pragma unroll
@@ -1314,7 +1384,23 @@ __global__ void __launch_bounds__(256) k_bin_scatter(const uint4 *crit, uint32_t
             key_off[threadIdx.x] += v;
             __syncthreads();
         }
-        key = first_key(size);
+        key = tail ? tail_key(size, c, c4.x, tail, thr) : first_key(size);
+        if (tail && blockIdx.x == 0u) {
+            // The table the class kernels read (rk_common.hpp FIRST_TAB_WORDS) and the grids of their launches.
+            if (threadIdx.x < RK_MAX_R * 8u) {
+                const unsigned c = threadIdx.x >> 3, x = threadIdx.x & 7u, k0 = c * 16u + x * 2u;
+                first_tab[c * 16u + x] = key_off[k0] - key_total[k0];
+                first_tab[c * 16u + 8u + x] = key_total[k0] + key_total[k0 + 1u];
+            }
+            if (threadIdx.x < RK_MAX_R) {
+                uint32_t longest = 0u;
+                for (unsigned x = 0; x < 8u; ++x) {
+                    const unsigned k0 = threadIdx.x * 16u + x * 2u;
+                    longest = max(longest, key_total[k0] + key_total[k0 + 1u]);
+                }
+                ctrl->first_grid[threadIdx.x] = 8u * longest;
+            }
+        }
         unsigned long long same = __ballot(valid);
 #pragma unroll
         for (unsigned b = 0; b < FIRST_ORDER_KEY_BITS; ++b) {
@@ -1333,14 +1419,16 @@ __global__ void __launch_bounds__(256) k_bin_scatter(const uint4 *crit, uint32_t
     if (!valid) {
         return;
     }
-    uint32_t pos = block_base[blockIdx.x * NBIN + c] + rank;
-    for (unsigned k = 0; k < w; ++k) {
-        pos += wave_cnt[k][c];
+    if (lists) {
+        uint32_t pos = block_base[blockIdx.x * NBIN + c] + rank;
+        for (unsigned k = 0; k < w; ++k) {
+            pos += wave_cnt[k][c];
+        }
+        for (unsigned b = 0; b < c; ++b) {
+            pos += ctrl->class2_count[b];
+        }
+        lists[pos] = g;
     }
-    for (unsigned b = 0; b < c; ++b) {
-        pos += ctrl->class2_count[b];
-    }
-    lists[pos] = g;
     if (first_order) {
         // (inclusive scan - own total = exclusive offset of the key)
         uint32_t kpos = key_off[key] - key_total[key] + key_base[blockIdx.x * NKEY + key] + krank;
@@ -1495,9 +1583,9 @@ bool sort_codes(uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint32_t
     }
     const long knob_min = sort_onesweep_min();
     // (The merge sort itself with tiles of 2048 / 4096 items instead of its 1024 -- fewer merge passes, no copy launches when their number
-    // is even -- moves the rebuild by -14...+9 us between 30k and 1M items, inside the box-to-box noise: tools/jobs_r05/r05_job58.sh.)
+    // is even -- moves the rebuild by -14...+9 us between 30k and 1M items, inside the box-to-box noise: tools/archive/jobs_r05/r05_job58.sh.)
     // Below 2^20 items the library's merge sort wins (launches of a dozen blocks of 8192 items leave the device empty: 100k +0.11 ms,
-    // 1M +0.055 ms with the onesweep passes; 2M -0.045, 4M -0.057: tools/jobs_r05/r05_job37.sh).
+    // 1M +0.055 ms with the onesweep passes; 2M -0.045, 4M -0.057: tools/archive/jobs_r05/r05_job37.sh).
     if (begin_bit == 0u && (knob_min < 0 || static_cast<long>(n) < knob_min || n > (1u << 28))) {
         size_t tb = 0;
         RK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, ka, kb, va, vb, static_cast<int>(n), 0, static_cast<int>(END_BIT), st));
@@ -1509,23 +1597,19 @@ bool sort_codes(uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint32_t
     throw error(RK_ERUNTIME, "internal error: a partial-key sort was asked for in a build without the onesweep launch sequence");
 #else
     // rocPRIM's gfx942 / gfx950 block shape for 8 + 4 byte pairs. Smaller blocks for mid-size sorts (256 x 8, 256 x 16, 512 x 8,
-    // 256 x 4 from 100k to 2M items) all lose to the merge sort and to this shape: tools/jobs_r05/r05_job40.sh.
+    // 256 x 4 from 100k to 2M items) all lose to the merge sort and to this shape: tools/archive/jobs_r05/r05_job40.sh.
     // Digits of 8 bits (the library's) or 9: whichever takes fewer passes over the bits that count (63 bits: 8 against 7 passes;
     // 36 bits, a rebuild of a tree eleven levels deep: 5 against 4). A 9-bit pass costs what an 8-bit one does (4M rebuild: 0.706 ->
     // 0.661 ms partial, 0.787 -> 0.757 full), a 10-bit one 19 us more at 4M -- the runs a block writes per bin get too short
-    // (tools/jobs_r05/r05_job68.sh, r05_job69.sh).
-    static const int knob_rb = [] {
-        const char *e = std::getenv("RK_SORT_RB"); // 8 / 9: digit width (A/B, tools/jobs_r05/r05_job68.sh); default: fewest passes
-        return e ? std::atoi(e) : 0;
-    }();
+    // (tools/archive/jobs_r05/r05_job68.sh, r05_job69.sh).
     const unsigned bits = END_BIT - begin_bit;
-    const bool nine = knob_rb ? knob_rb == 9 : (bits + 8u) / 9u < (bits + 7u) / 8u;
+    const bool nine = (bits + 8u) / 9u < (bits + 7u) / 8u;
     return nine ? onesweep<512, 16, 9>(ka, va, kb, vb, n, begin_bit, st) : onesweep<512, 16, 8>(ka, va, kb, vb, n, begin_bit, st);
 #endif
 }
 // Whether a rebuild of n particles may sort a partial key (the onesweep passes look at a sub-range of the bits; the library call
 // does not): from half the size at which full sorts go to the onesweep passes -- four 9-bit passes + k_local_sort against the merge
-// sort: 350k equal, 600k -6 %, 1M -13 % of the rebuild (tools/jobs_r05/r05_job70.sh).
+// sort: 350k equal, 600k -6 %, 1M -13 % of the rebuild (tools/archive/jobs_r05/r05_job70.sh).
 bool sort_partial_ok(uint32_t n)
 {
     const long knob_min = sort_onesweep_min();
@@ -1534,43 +1618,87 @@ bool sort_partial_ok(uint32_t n)
 
 } // namespace bld
 
-// (see k_first_keys)
-static bool first_order_enabled();
-static void make_first_order(rk_state &s, const uint4 *crit, uint32_t n_crit, hipStream_t st)
-{
-    using namespace bld;
-    if (!s.first_order) {
-        s.first_order = pool_alloc(FIRST_ORDER_MAX * sizeof(uint32_t));
-    }
-    auto keys_in = dalloc<uint32_t>(n_crit), keys_out = dalloc<uint32_t>(n_crit), vals_in = dalloc<uint32_t>(n_crit);
-    hipLaunchKernelGGL(k_first_keys, dim3((n_crit + 255u) / 256u), dim3(256), 0, st, crit, n_crit, keys_in.get(), vals_in.get());
-    size_t tb = 0;
-    RK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys_in.get(), keys_out.get(), vals_in.get(),
-                                              static_cast<uint32_t *>(s.first_order), static_cast<int>(n_crit), 0,
-                                              static_cast<int>(FIRST_ORDER_KEY_BITS), st));
-    auto tmp = dalloc<unsigned char>(tb);
-    RK_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.get(), tb, keys_in.get(), keys_out.get(), vals_in.get(),
-                                              static_cast<uint32_t *>(s.first_order), static_cast<int>(n_crit), 0,
-                                              static_cast<int>(FIRST_ORDER_KEY_BITS), st));
-    s.first_order_valid = true;
-}
-
 static bool first_order_enabled()
 {
     static const bool on = [] {
-        const char *e = std::getenv("RK_FIRST_ORDER"); // 0: first calls on small trees read the class lists backwards instead
+        const char *e = std::getenv("RK_FIRST_ORDER"); // 0: no launch order for first calls is made with the tree (they read the class lists)
         return !(e && std::atoi(e) == 0);
     }();
     return on;
 }
 
-// The same for a replica (rk_state_clone / import / broadcast: the critical nodes are on its device already).
+static bool want_first_tail(uint32_t n_crit, uint32_t nparts)
+{
+    return first_order_enabled() && n_crit > FIRST_ORDER_MAX && n_crit <= FIRST_TAIL_MAX && nparts > 0u && RK_MAX_R == 4;
+}
+
+// The lane-mapping classes of the critical nodes (second half of RK_BUF_CLASS; `lists` null: a replica has them already) and, with
+// them, the launch order of the FIRST call on the tree: heavy-first up to FIRST_ORDER_MAX critical nodes (first_key()), the light-tail
+// arrangement up to FIRST_TAIL_MAX (tail_key(); its grids arrive in ctrl->first_grid with the caller's next look-up of the control
+// block: take_first_grid()). Returns the temporaries the kernels work on; the caller keeps them until it has synchronised.
+struct bin_tmp {
+    bld::dptr<uint32_t> hist, key_hist;
+};
+static bin_tmp bin_classes(rk_state &s, const uint4 *crit, uint32_t n_crit, uint32_t nparts, uint32_t *lists, bld::ctrl_block *ctrl,
+                           hipStream_t st)
+{
+    using namespace bld;
+    bin_tmp t;
+    const unsigned nb = nblk(n_crit);
+    t.hist = dalloc<uint32_t>(static_cast<size_t>(nb) * NBIN);
+    const bool want_first = first_order_enabled() && n_crit <= FIRST_ORDER_MAX;
+    const bool want_tail = want_first_tail(n_crit, nparts);
+    uint32_t *key_total = nullptr, *first_order = nullptr;
+    if (want_first || want_tail) {
+        const int64_t need = std::max<int64_t>(FIRST_ORDER_MAX, n_crit);
+        if (!s.first_order || s.first_order_cap < need) {
+            // (the caller has synchronised the device since the last traversal of the old tree: release_tree())
+            pool_free(s.first_order);
+            s.first_order = nullptr;
+            s.first_order = pool_alloc(static_cast<size_t>(need) * sizeof(uint32_t));
+            s.first_order_cap = need;
+        }
+        first_order = static_cast<uint32_t *>(s.first_order);
+        t.key_hist = dalloc<uint32_t>(static_cast<size_t>(nb) * NKEY + NKEY);
+        key_total = t.key_hist.get() + static_cast<size_t>(nb) * NKEY;
+    }
+    if (want_tail) {
+        if (!s.first_tab) {
+            s.first_tab = pool_alloc(FIRST_TAB_WORDS * sizeof(uint32_t));
+        }
+        hipLaunchKernelGGL(k_tail_thr, dim3(1), dim3(1024), 0, st, crit, n_crit, static_cast<uint32_t *>(s.first_tab));
+    }
+    const uint32_t tail = want_tail ? nparts : 0u;
+    hipLaunchKernelGGL(k_bin_count, dim3(nb), dim3(256), 0, st, crit, n_crit, t.hist.get(), ctrl, t.key_hist.get(), tail,
+                       static_cast<const uint32_t *>(s.first_tab));
+    hipLaunchKernelGGL(k_bin_scan, dim3(NBIN + (first_order ? NKEY : 0u)), dim3(256), 0, st, t.hist.get(), nb, ctrl, t.key_hist.get(),
+                       key_total);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(nb), dim3(256), 0, st, crit, n_crit, t.hist.get(), ctrl, lists, t.key_hist.get(), key_total,
+                       first_order, tail, static_cast<uint32_t *>(s.first_tab));
+    s.first_order_valid = want_first;
+    s.first_tail_valid = want_tail;
+    return t;
+}
+static void take_first_grid(rk_state &s, const bld::ctrl_block &hc)
+{
+    for (int c = 0; c < 4; ++c) {
+        s.first_grid[c] = s.first_tail_valid ? hc.first_grid[c] : 0u;
+    }
+}
+
+// The same for a replica (rk_state_clone / import / broadcast: the critical nodes and their class lists are on its device already).
 void replica_first_order(rk_state &s)
 {
-    s.first_order_valid = false;
-    if (first_order_enabled() && s.n_crit > 0 && s.n_crit <= static_cast<int64_t>(FIRST_ORDER_MAX) && s.buf[RK_BUF_CRIT]) {
-        make_first_order(s, static_cast<const uint4 *>(s.buf[RK_BUF_CRIT]), static_cast<uint32_t>(s.n_crit), nullptr);
-        RK_HIP(hipStreamSynchronize(nullptr)); // (the temporaries of the sort go back to the pool)
+    using namespace bld;
+    s.first_order_valid = s.first_tail_valid = false;
+    if (first_order_enabled() && s.n_crit > 0 && s.n_crit <= static_cast<int64_t>(FIRST_TAIL_MAX) && s.buf[RK_BUF_CRIT]) {
+        auto ctrl = dalloc<ctrl_block>(1);
+        RK_HIP(hipMemsetAsync(ctrl.get(), 0, sizeof(ctrl_block), nullptr));
+        const bin_tmp tmp = bin_classes(s, static_cast<const uint4 *>(s.buf[RK_BUF_CRIT]), static_cast<uint32_t>(s.n_crit),
+                                        static_cast<uint32_t>(s.nparts), nullptr, ctrl.get(), nullptr);
+        ctrl_block hc{};
+        RK_HIP(hipMemcpy(&hc, ctrl.get(), sizeof(ctrl_block), hipMemcpyDeviceToHost)); // (also: the temporaries may go back to the pool)
+        take_first_grid(s, hc);
     }
 }
 
@@ -1666,7 +1794,7 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     ctrl_block hc{};
     RK_HIP(hipMemsetAsync(ctrl.get(), 0, sizeof(ctrl_block), st));
     // (Round 5, measured and not kept: the last kernel in front of a look-up storing the block + a sequence number to pinned host
-    // memory that the host polls, instead of a copy -- rebuild +0.025 ms at 100k, +0.045 at 4M, tools/jobs_r05/r05_job39.sh.)
+    // memory that the host polls, instead of a copy -- rebuild +0.025 ms at 100k, +0.045 at 4M, tools/archive/jobs_r05/r05_job39.sh.)
     lookup_slots &lk = thread_lookup_slots();
     const auto lookup_begin = [&](int slot) {
         RK_HIP(hipMemcpyAsync(lk.host + slot, ctrl.get(), sizeof(ctrl_block), hipMemcpyDeviceToHost, st));
@@ -1918,26 +2046,8 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     // ---- group lists of the list kernel (second half of RK_BUF_CLASS; the first half, the cross-check kernel's
     // binning, is filled with the host mirrors on demand) ----
     auto *lists = static_cast<uint32_t *>(alloc_buf(RK_BUF_CLASS, static_cast<size_t>(n_crit) * 2 * sizeof(uint32_t)));
-    const unsigned nb = nblk(n_crit);
-    auto hist = dalloc<uint32_t>(static_cast<size_t>(nb) * NBIN);
-    // (with the launch order of the first call on a small tree: see k_first_keys)
-    const bool want_first = first_order_enabled() && n_crit <= FIRST_ORDER_MAX;
-    dptr<uint32_t> key_hist;
-    uint32_t *key_total = nullptr;
-    if (want_first) {
-        if (!s.first_order) {
-            s.first_order = pool_alloc(FIRST_ORDER_MAX * sizeof(uint32_t));
-        }
-        key_hist = dalloc<uint32_t>(static_cast<size_t>(nb) * NKEY + NKEY);
-        key_total = key_hist.get() + static_cast<size_t>(nb) * NKEY;
-    }
-    auto *first_order = want_first ? static_cast<uint32_t *>(s.first_order) : nullptr;
-    hipLaunchKernelGGL(k_bin_count, dim3(nb), dim3(256), 0, st, crit, n_crit, hist.get(), ctrl.get(), key_hist.get());
-    hipLaunchKernelGGL(k_bin_scan, dim3(NBIN + (want_first ? NKEY : 0u)), dim3(256), 0, st, hist.get(), nb, ctrl.get(), key_hist.get(),
-                       key_total);
-    hipLaunchKernelGGL(k_bin_scatter, dim3(nb), dim3(256), 0, st, crit, n_crit, hist.get(), ctrl.get(), lists + n_crit, key_hist.get(),
-                       key_total, first_order);
-    s.first_order_valid = want_first;
+    // (with the launch order of the first call: see bin_classes())
+    const bin_tmp bin_scratch = bin_classes(s, crit, n_crit, n, lists + n_crit, ctrl.get(), st);
 
     // ---- third look-up: node-property errors, class sizes (also the final synchronisation) ----
     lookup_begin(2);
@@ -1951,6 +2061,7 @@ void build_device(rk_state &s, const void *const parts[4], bool parts_on_device,
     }
     s.n_crit = n_crit;
     s.max_group = hc.max_group;
+    take_first_grid(s, hc);
     s.mirrors_valid = false;
     s.crit_begin.clear();
     s.crit_end.clear();
@@ -2150,26 +2261,8 @@ void convert_device(rk_state &s, const void *const parts[4], int64_t nparts, con
                        static_cast<uint32_t>(nn), node_com, node_mac, recs, child_tab);
     // ---- lane-mapping classes (second half of RK_BUF_CLASS; the first half is filled with the host mirrors on demand) ----
     auto *lists = static_cast<uint32_t *>(alloc_buf(RK_BUF_CLASS, static_cast<size_t>(n_crit) * 2 * sizeof(uint32_t)));
-    const unsigned nb = nblk(n_crit);
-    auto hist = dalloc<uint32_t>(static_cast<size_t>(nb) * NBIN);
-    // (with the launch order of the first call on a small tree: see k_first_keys)
-    const bool want_first = first_order_enabled() && n_crit <= FIRST_ORDER_MAX;
-    dptr<uint32_t> key_hist;
-    uint32_t *key_total = nullptr;
-    if (want_first) {
-        if (!s.first_order) {
-            s.first_order = pool_alloc(FIRST_ORDER_MAX * sizeof(uint32_t));
-        }
-        key_hist = dalloc<uint32_t>(static_cast<size_t>(nb) * NKEY + NKEY);
-        key_total = key_hist.get() + static_cast<size_t>(nb) * NKEY;
-    }
-    auto *first_order = want_first ? static_cast<uint32_t *>(s.first_order) : nullptr;
-    hipLaunchKernelGGL(k_bin_count, dim3(nb), dim3(256), 0, st, crit, n_crit, hist.get(), ctrl.get(), key_hist.get());
-    hipLaunchKernelGGL(k_bin_scan, dim3(NBIN + (want_first ? NKEY : 0u)), dim3(256), 0, st, hist.get(), nb, ctrl.get(), key_hist.get(),
-                       key_total);
-    hipLaunchKernelGGL(k_bin_scatter, dim3(nb), dim3(256), 0, st, crit, n_crit, hist.get(), ctrl.get(), lists + n_crit, key_hist.get(),
-                       key_total, first_order);
-    s.first_order_valid = want_first;
+    // (with the launch order of the first call: see bin_classes())
+    const bin_tmp bin_scratch = bin_classes(s, crit, n_crit, n, lists + n_crit, ctrl.get(), st);
     fetch_ctrl();
     RK_HIP(hipGetLastError());
     if (hc.pad[2]) {
@@ -2177,6 +2270,7 @@ void convert_device(rk_state &s, const void *const parts[4], int64_t nparts, con
     }
     s.n_crit = n_crit;
     s.max_group = hc.max_group;
+    take_first_grid(s, hc);
     s.mirrors_valid = false;
     s.crit_begin.clear();
     s.crit_end.clear();

@@ -40,6 +40,13 @@ __host__ __device__ constexpr int nres_of(int q)
 constexpr uint32_t RK_PLAN_PAD_VALUE = 0xffffffffu; // launch-plan list entry without a critical node (skipped)
 constexpr int n_classes = 7;  // classes 0..5 are served by wave kernels, the last one by the block-per-group kernel
 constexpr int big_class = n_classes - 1;
+// Beyond FIRST_ORDER_MAX and up to this many critical nodes a tree gets the LIGHT-TAIL arrangement of a first call instead (per
+// class and per XCD region: the nodes in Morton order, the lightest quarter of the class at the end; rk_build.hip k_tail_sizes).
+// The limit is RK_PLAN_TAIL_MAX_GROUPS' default: beyond it the plain Morton slices per XCD win (rk_state.hip).
+constexpr unsigned FIRST_TAIL_MAX = 250000;
+// Table of the light-tail arrangement (uint32, device memory): per wave-kernel class c (R = c + 1) and XCD region x the start
+// [c * 16 + x] and the length [c * 16 + 8 + x] of its queue inside first_order; [64 + c] = size from which a node of class c is bulk.
+constexpr unsigned FIRST_TAB_WORDS = 72;
 constexpr unsigned FIRST_ORDER_MAX = 49152; // critical nodes up to which a tree gets its first-call launch order on the device (round 4: 32768)
 constexpr int n_list_R = 6;   // variant 2: class c keeps R = c + 1 targets per lane
 __host__ __device__ constexpr int class_R(int c)
@@ -174,7 +181,8 @@ struct kparams {
     const uint32_t *perm; // non-null: original-order output, results of Morton particle i go to out[perm[i]]
     unsigned long long *dbg; // diagnostic builds only (RK_STAMPS): per-section cycle totals
     int mac;                 // RK_MAC_BH | RK_MAC_BH_GEOM (the list kernels read it at run time: one code object for both)
-    int xcd_mode;            // block -> group-list mapping (see xcd_map_block)
+    int xcd_mode;            // block -> group-list mapping (see xcd_map_block); 3: the queues of first_tab (class kernels only)
+    const uint32_t *first_tab; // xcd_mode 3: queue starts / lengths per (class, XCD region), see rk_state::first_tab
     int any_rev;             // one-launch kernels: block i serves list entry n - 1 - i (class lists read backwards: R = 4 first)
     // Supergroup pre-pass (k_super): K consecutive target groups share the upper part of list building.
     // super_k == 0 disables it. Per supergroup S: sup_common[S * SUP_CAPC ...] = sources {x, y, z, m} accepted for every
@@ -338,13 +346,20 @@ struct rk_state {
     hipStream_t last_stream = nullptr;
     bool has_last_stream = false, multi_stream = false;
     hipEvent_t ev_done = nullptr, last_done = nullptr;
-    int super_k = -1;      // -1 = not initialised (read RK_SUPER_K, default 8)
+    int super_k = -1;      // members per supergroup of the pre-pass; -1 = not initialised yet (16)
     // Split traversal (variant 4): list pool and control words, sized per call (grown, never shrunk, until the state goes).
     void *sl_idx = nullptr, *sl_next = nullptr, *sl_cnt = nullptr, *sl_ctl = nullptr, *sl_fb = nullptr;
     // Launch order of the first call on a small tree (rk_build.hip k_first_order): the nodes of the wave kernels' classes by
     // decreasing size, made on the device with the tree. Valid for the tree it was made with only.
     void *first_order = nullptr;
+    int64_t first_order_cap = 0; // entries allocated
     bool first_order_valid = false;
+    // ... or, for trees of FIRST_ORDER_MAX .. FIRST_TAIL_MAX critical nodes, the light-tail arrangement: first_order holds the queues
+    // of every (class, XCD region), first_tab their starts and lengths, first_grid[c] = 8 x the longest queue of class c (the grid of
+    // its class kernel: block i serves entry i / 8 of the queue of region i % 8, blocks past the end of their queue exit).
+    bool first_tail_valid = false;
+    void *first_tab = nullptr;
+    uint32_t first_grid[4] = {};
     int64_t sl_nseg = 0, sl_ncnt = 0;   // segments / per-node counters allocated
     void *sl_pbase = nullptr, *sl_part = nullptr;
     int64_t sl_npart = 0, sl_part_hint = 0; // partial-sum slots allocated / asked for by the last reports

@@ -640,7 +640,18 @@ __global__ void __launch_bounds__(64 * (BIG ? LK_BIG_WPB : RK_WPB), BIG ? (sizeo
     if (wave >= n_list) {
         return;
     }
-    const uint32_t g = __builtin_amdgcn_readfirstlane(list[wave]);
+    uint32_t entry = static_cast<uint32_t>(wave);
+    if (!BIG && RK_WPB == 1 && P.xcd_mode == 3) {
+        // First call on a large tree: block i serves entry i / 8 of the queue of (this kernel's class, XCD region i % 8) -- the
+        // blocks are dealt round-robin to the XCDs, so a region's queue runs on one XCD in every class kernel.
+        const uint32_t x = blk & 7u, pos = blk >> 3;
+        const uint32_t *tab = P.first_tab + (R - 1) * 16;
+        if (pos >= tab[8u + x]) {
+            return; // past the end of this region's queue
+        }
+        entry = tab[x] + pos;
+    }
+    const uint32_t g = __builtin_amdgcn_readfirstlane(list[entry]);
     if (g == RK_PLAN_PAD_VALUE) {
         return; // padding of a launch plan
     }
@@ -853,7 +864,7 @@ static void launch_list_qm(const rk_state &s, const kparams<F> &p, const int64_t
     // Order in which the class kernels are handed to the runtime. Replayed from a graph they share one queue, and the kernel
     // handed over first is served first as slots free up: the R = 3 kernel, which ends last, must lead (round 5, 4M device-resident
     // kernel ms over two boxes: 3-1-2-4 (rounds 1-4) 2.15-2.17, 3-4-1-2 2.14-2.16, 3-2-4-1 2.15-2.16, 3-4-2-1 / 3-1-4-2 2.17;
-    // with R = 1 or R = 4 first -- 1-2-3-4, 4-3-2-1, 4-3-1-2, 1-3-4-2 -- 2.21-2.24: tools/jobs_r05/r05_job27.sh, _job28).
+    // with R = 1 or R = 4 first -- 1-2-3-4, 4-3-2-1, 4-3-1-2, 1-3-4-2 -- 2.21-2.24: tools/archive/jobs_r05/r05_job27.sh, _job28).
     go(std::integral_constant<int, 3>{}, 2);
     go(std::integral_constant<int, 4>{}, 3);
     go(std::integral_constant<int, 1>{}, 0);

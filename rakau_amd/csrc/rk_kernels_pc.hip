@@ -463,7 +463,7 @@ __device__ __forceinline__ void pc_node(const kparams<F> &P, pc_lds<F> &L, const
     };
     // Pop up to 8 sibling runs and issue the loads of their records. Returns the number of entries popped.
     // `pending` = number of entries a batch already in flight may still push (no batch is prefetched at present: two
-    // batches in flight were measured on trees of 30k-1M particles and changed nothing, tools/archive_r02/r02_job10.sh).
+    // batches in flight were measured on trees of 30k-1M particles and changed nothing, tools/archive/jobs_r02/r02_job10.sh).
     auto pop_and_load = [&](batch_t &bt, int pending) __attribute__((always_inline)) -> int {
         if (size == 0) {
             return 0;

@@ -29,7 +29,7 @@
 #ifndef RK_CARRY_REMAINDER
 #define RK_CARRY_REMAINDER 1 // dense phase: carry the sources that do not fill a round of NS to the next tile instead of a masked step
                              // per tile. Round 2 (7 waves per SIMD) measured it slower, 2.30 vs 2.27 ms; on round 5's kernels it is
-                             // ahead: 1M 0.590 -> 0.583 ms, 4M 2.177 -> 2.160 (tools/jobs_r05/r05_job30.sh). The producer of the
+                             // ahead: 1M 0.590 -> 0.583 ms, 4M 2.177 -> 2.160 (tools/archive/jobs_r05/r05_job30.sh). The producer of the
                              // producer / consumer kernel hands over the same tiles (rk_kernels_pc.hip, publish()): same bits
 #endif
 #ifndef RK_EXACT_TRANSPOSED
@@ -37,12 +37,12 @@
 #endif
 #ifndef RK_LEAF_LANE_PARTICLE
 #define RK_LEAF_LANE_PARTICLE 1 // leaf gathering: lane = particle (1) or lane = leaf with eight records in flight (0: rounds 1-4).
-                                // 4M 2.235 -> 2.213 ms, 1M 0.612 -> 0.592, 0.5M 0.321 -> 0.317 (tools/jobs_r05/r05_job6.sh)
+                                // 4M 2.235 -> 2.213 ms, 1M 0.612 -> 0.592, 0.5M 0.321 -> 0.317 (tools/archive/jobs_r05/r05_job6.sh)
 #endif
 #ifndef RK_MASK_IDLE
 #define RK_MASK_IDLE 1 // dense phase: the lanes left over by TP x NS < 64 are switched off for the tile (1) or shadow split 0 (0:
                        // rounds 1-4). Same instruction count, 0.7 % less time at 4M, 1.5-2 % on 100k-350k launches
-                       // (tools/jobs_r05/r05_job4.sh): 6.8 % of the lanes no longer read LDS and burn issue power for nothing
+                       // (tools/archive/jobs_r05/r05_job4.sh): 6.8 % of the lanes no longer read LDS and burn issue power for nothing
 #endif
 #ifndef RK_WPB
 #define RK_WPB 1 // wavefronts (= target groups) per workgroup. Measured 4 -> 2.58 ms, 2 -> 2.45, 1 -> 2.35 at 4M: a block keeps its
@@ -59,24 +59,24 @@
 #endif
 #ifndef RK_W64_R4
 #define RK_W64_R4 3 // fp64, R = 4 class kernel: 165 VGPRs, no scratch (at 4 waves: 128 VGPRs + 80 bytes of scratch per lane). 16M fp64
-                    // theta 0.5: 59.05 against 59.65 ms per step, same box, two rounds (tools/jobs_r04/r04_job36.sh); the R = 3
+                    // theta 0.5: 59.05 against 59.65 ms per step, same box, two rounds (tools/archive/jobs_r04/r04_job36.sh); the R = 3
                     // kernel at 3 waves as well: 60.0
 #endif
 #ifndef RK_W12
 #define RK_W12 8 // waves per SIMD the R <= 2 kernels are compiled for. Round 5: 8 (64 VGPRs, 12 / 44 bytes of scratch, 5 KiB of LDS per
                  // wave) once the DPP prefix sum had freed six address registers and six lane masks: 4M 2.215 -> 2.195 ms, the
-                 // seam's call 1717-1728 -> 1759-1767 Mparticles/s (tools/jobs_r05/r05_job11.sh); rounds 1-4: 7 (8 spilled 50-60 B)
+                 // seam's call 1717-1728 -> 1759-1767 Mparticles/s (tools/archive/jobs_r05/r05_job11.sh); rounds 1-4: 7 (8 spilled 50-60 B)
 #endif
 #ifndef RK_W3
 #define RK_W3 6 // R = 3
 #endif
 #ifndef RK_W4
 #define RK_W4 6 // R = 4 (round 5: 80 VGPRs, 36 bytes of scratch: 4M 2.189 -> 2.156 ms over four alternating rounds,
-                // tools/jobs_r05/r05_job19.sh; rounds 1-4: 5)
+                // tools/archive/jobs_r05/r05_job19.sh; rounds 1-4: 5)
 #endif
 #ifndef RK_WANY
 #define RK_WANY 5 // k_list_any (one launch over all classes), compiled for the registers of its largest R at 5 waves per SIMD (6: 1M
-                  // 0.596 -> 0.576 ms but 350k 0.224 -> 0.236, shards of the 4M tree equal: tools/jobs_r05/r05_job12.sh, _job18)
+                  // 0.596 -> 0.576 ms but 350k 0.224 -> 0.236, shards of the 4M tree equal: tools/archive/jobs_r05/r05_job12.sh, _job18)
 #endif
 #ifndef RK_W5
 #define RK_W5 4 // R = 5
@@ -91,7 +91,7 @@
 // criterion, hence the same bits, and half the code objects (-4 MB of library) -- but NOT the default: the R = 1 and R = 3 list
 // kernels then spill 8 more bytes per lane (28 / 32 instead of 20 / 24; they are compiled at the 72 / 80-register cliff), which
 // leaves results-in-HBM calls unchanged and makes calls whose epilogue stores cross PCIe (host outputs) 1.5-2 % slower
-// (4M: 2.36-2.39 against 2.32-2.33 ms, same box, tools/jobs_r04/r04_job7.sh, r04_job11.sh).
+// (4M: 2.36-2.39 against 2.32-2.33 ms, same box, tools/archive/jobs_r04/r04_job7.sh, r04_job11.sh).
 #ifndef RK_MAC_RUNTIME
 #define RK_MAC_RUNTIME 0
 #endif
@@ -162,7 +162,7 @@ constexpr int LK_UQ_CAP = 128;
 // Critical nodes too large for one wavefront (k_list<..., BIG>): wavefronts per workgroup, targets per chunk.
 #ifndef RK_BIG_WPB
 #define RK_BIG_WPB 4 // 8: 1.9 instead of 3.2 ms when only 512 such nodes exist, 2.86 instead of 2.44 s on the 256M tree of
-                     // profiles/r02/big_runs.txt (tools/archive_r02/r02_job33.sh)
+                     // profiles/r02/big_runs.txt (tools/archive/jobs_r02/r02_job33.sh)
 #endif
 #ifndef RK_WBIG
 #define RK_WBIG 7 // waves per SIMD the BIG kernels are compiled for (5: spill-free, equal or slower)
@@ -196,12 +196,13 @@ __device__ __forceinline__ unsigned xcd_chunked_block(unsigned b, unsigned nb)
 // mode 0: XCD x walks chunks x, x + 8, x + 16, ... of XCD_CHUNK consecutive blocks (L2 locality inside a
 // chunk, work spread evenly over the XCDs whatever the spatial variation of the group costs);
 // mode 1: one contiguous slice per XCD; mode 2: identity (hardware round-robin: block i on XCD i % 8; the light-tail launch
-// plan of rk_state.hip lays its list out for this).
+// plan of rk_state.hip lays its list out for this); mode 3: identity too -- the light-tail arrangement made on the device for
+// FIRST calls (rk_build.hip k_tail_sizes), whose per-XCD queues are not interleaved into one padded list but found through a table.
 constexpr unsigned XCD_CHUNK = 16;
 __device__ __forceinline__ unsigned xcd_map_block(unsigned b, unsigned nb, int mode)
 {
-    if (mode == 2) {
-        return b;
+    if (mode >= 2) {
+        return b; // (3: the class kernels look their node up in the queue table themselves, k_list)
     }
     if (mode == 1) {
         return xcd_chunked_block(b, nb);

@@ -57,16 +57,13 @@ const bool g_crash_handler_installed = [] {
 // inside libamdhip64 (tools/stress_graph_capture.py: within 500 key changes in every run, also with the device idle at the
 // destroy; never when they are kept; never with linear graphs -- profiles/r03/graph_destroy_crash.txt). They are parked until
 // the process ends instead, and only RK_GRAPH_FORKED_MAX (64) of them are ever made per process: after that, forked
-// sequences are launched directly (1-4 % slower between 2M and 6M particles). RK_GRAPH_FORKED=0: never capture them.
+// sequences are launched directly (1-4 % slower between 2M and 6M particles). RK_GRAPH_FORKED_MAX=0: never capture them.
 int phys(int device);
 std::atomic<int> g_forked_execs{0};
 int forked_cap()
 {
     static const int cap = [] {
-        const char *e = std::getenv("RK_GRAPH_FORKED"), *m = std::getenv("RK_GRAPH_FORKED_MAX");
-        if (e && std::atoi(e) == 0) {
-            return 0;
-        }
+        const char *m = std::getenv("RK_GRAPH_FORKED_MAX");
         return m ? std::max(std::atoi(m), 0) : 64;
     }();
     return cap;
@@ -75,7 +72,7 @@ int forked_cap()
 // physical device. They are not destroyed -- see above -- but RE-TARGETED: a new forked capture first tries
 // hipGraphExecUpdate() on one of them (same topology -- pre-pass, fork, the class kernels, join -- with other kernel
 // arguments), so a long-lived process that keeps meeting new signatures keeps replaying graphs without the number of
-// executables growing (RK_GRAPH_UPDATE=0: never re-target; the cap then ends replay as in round 3).
+// executables growing.
 std::mutex g_parked_mtx;
 std::map<int, std::vector<hipGraphExec_t>> g_parked;
 // One stream capture (and instantiation / re-targeting of what it captured) at a time in the process, whatever the precision of
@@ -83,13 +80,9 @@ std::map<int, std::vector<hipGraphExec_t>> g_parked;
 // side (captures are rare -- once per signature --; concurrent captures on logical devices that alias one GPU failed intermittently
 // in round 4). Namespace scope: a static inside the template run_impl<F> was one mutex per precision.
 std::mutex g_capture_mtx;
-bool graph_update_enabled()
+constexpr bool graph_update_enabled()
 {
-    static const bool on = [] {
-        const char *e = std::getenv("RK_GRAPH_UPDATE");
-        return !(e && std::atoi(e) == 0);
-    }();
-    return on;
+    return true;
 }
 bool forked_capture_allowed(int phys_dev)
 {
@@ -215,7 +208,7 @@ int user_nres(const rk_state &s, int q)
 // Pinned staging buffers of the host-output path outlive their state: hipHostMalloc / hipHostFree of 48 MB (4M particles) cost
 // 10-20 ms each, which a caller that rebuilds its tree -- and with it the state -- every time step would pay per step (the
 // reference re-creates its rocm_state after every update_particles()). A few buffers are parked (per physical device; at most
-// RK_STAGE_KEEP = 4, the smallest that fits is handed out); rk_pool_trim() frees them.
+// four, the smallest that fits is handed out); rk_pool_trim() frees them.
 std::mutex g_stage_mtx;
 struct parked_stage {
     int dev;
@@ -246,10 +239,7 @@ void stage_give(int dev, void *p, size_t bytes)
     if (!p) {
         return;
     }
-    static const size_t keep = [] {
-        const char *e = std::getenv("RK_STAGE_KEEP");
-        return static_cast<size_t>(e ? std::max(std::atoi(e), 0) : 4);
-    }();
+    constexpr size_t keep = 4;
     void *drop = p;
     {
         std::lock_guard<std::mutex> lk(g_stage_mtx);
@@ -308,6 +298,7 @@ void release_tree(rk_state *s)
     s->sl_rep_pending = false; // the device was synchronised above
     s->sl_clean_valid = false;
     s->first_order_valid = false;
+    s->first_tail_valid = false;
 }
 
 void free_state(rk_state *s)
@@ -320,7 +311,7 @@ void free_state(rk_state *s)
     (void)hipSetDevice(phys(s->device));
     release_tree(s);
     for (void *b : {s->d_out, s->sup_common, s->sup_resid, s->sup_cnt, s->z_scratch, s->sl_idx, s->sl_next,
-                    s->sl_cnt, s->sl_ctl, s->sl_fb, s->sl_pbase, s->sl_part, s->first_order}) {
+                    s->sl_cnt, s->sl_ctl, s->sl_fb, s->sl_pbase, s->sl_part, s->first_order, s->first_tab}) {
         rk::pool_free(b);
     }
     if (s->sl_host) {
@@ -523,7 +514,12 @@ void create_impl(rk_state &s, const void *const parts[4], int64_t nparts, const 
 {
     using v4 = typename rk::vt<F>::v4;
     using v2 = typename rk::vt<F>::v2;
-    static const bool timing = std::getenv("RK_BUILD_TIMING") != nullptr; // diagnostic: phase times on stderr
+    
+#ifdef RK_BUILD_TIMING
+    constexpr bool timing = true; // diagnostic build (-DRK_BUILD_TIMING): phase times on stderr
+#else
+    constexpr bool timing = false;
+#endif
     const auto t_start = std::chrono::steady_clock::now();
     auto t_prev = t_start;
     const auto lap = [&](const char *what) {
@@ -856,20 +852,11 @@ void census_impl(rk_state &s, int64_t p_begin, int64_t p_end, double mac_value, 
 //  * lpt (calls of at most RK_PLAN_MAX_GROUPS nodes): sorted by decreasing work (longest processing time first), so
 //    that a launch of only a few rounds of waves ends with its lightest nodes. (Sorting whole supergroups by their mean
 //    work instead -- spatially compact runs that share the pre-pass lists -- measured 3-7 % slower from 100k particles
-//    to the 0.5M-particle shards of the 4M tree: tools/archive_r02/r02_job27.sh.)
+//    to the 0.5M-particle shards of the 4M tree: tools/archive/jobs_r02/r02_job27.sh.)
 //  * otherwise: Morton order (neighbouring nodes share tree nodes and leaves in the L2), but the lightest quarter of the
 //    nodes goes last: the device then drains over the duration of short waves instead of average ones (4M: 2.32-2.33
-//    -> 2.27-2.28 ms; a full LPT order costs 60 % there: tools/archive_r02/r02_job41.sh), and every XCD works through one spatial
-//    region of the range in ALL class kernels (same time, 8.5 % fewer bytes fetched past the L2: tools/archive_r02/r02_job46.sh).
-bool plan_regions_enabled()
-{
-    static const bool on = [] {
-        const char *e = std::getenv("RK_PLAN_REGIONS"); // 0: one Morton-ordered list per class, dealt to the XCDs in chunks
-        return !(e && std::atoi(e) == 0);
-    }();
-    return on;
-}
-
+//    -> 2.27-2.28 ms; a full LPT order costs 60 % there: tools/archive/jobs_r02/r02_job41.sh), and every XCD works through one spatial
+//    region of the range in ALL class kernels (same time, 8.5 % fewer bytes fetched past the L2: tools/archive/jobs_r02/r02_job46.sh).
 // Launch-plan list buffers that nothing refers to any more. A launch still in flight (on a stream this library knows nothing about
 // by then) may be reading one, so they are not handed back to the block cache at once -- rounds 2-4 drained the whole device for
 // every one of them -- but parked here until the device is known to be idle anyway (release_tree(): a rebuild, a destroyed state)
@@ -935,12 +922,11 @@ void retire_plan_buffer(int dev, void *b) noexcept
 template <typename F>
 void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64_t g_hi, double mac_value, int mode)
 {
-    // mode 1: heavy-first (sorted by decreasing work); 2: class lists in Morton order + ONE merged list that reads them
-    // backwards, R = 4 first (heavy-first by class, neighbours stay together); 0: light-tail arrangement per class.
-    const bool lpt = mode == 1, rev = mode == 2;
+    // mode 1: heavy-first (sorted by decreasing work); 0: light-tail arrangement per class.
+    const bool lpt = mode == 1;
     ensure_mirrors(s);
     // Weight of a node = its number of particles: as good a predictor of a wave's duration as the interaction census
-    // (4M: 2.24-2.26 ms either way; tools/archive_r02/r02_job54.sh) and free, where the census is a traversal of its own (13 ms at 4M).
+    // (4M: 2.24-2.26 ms either way; tools/archive/jobs_r02/r02_job54.sh) and free, where the census is a traversal of its own (13 ms at 4M).
     if (s.work_cache.size() != static_cast<size_t>(s.n_crit)) {
         s.work_cache.resize(static_cast<size_t>(s.n_crit));
         for (int64_t g = 0; g < s.n_crit; ++g) {
@@ -956,7 +942,7 @@ void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64
     auto arrange_light_tail = [&](const std::ptrdiff_t first) {
 
             // Morton order, the lightest quarter of the nodes moved to the end (in Morton order among themselves).
-            constexpr double tail_frac = 0.25; // (2, 4 or 8 work quantiles instead: no better, tools/archive_r02/r02_job45.sh)
+            constexpr double tail_frac = 0.25; // (2, 4 or 8 work quantiles instead: no better, tools/archive/jobs_r02/r02_job45.sh)
             std::vector<uint64_t> w;
             w.reserve(lists.size() - static_cast<size_t>(first));
             for (auto it = lists.begin() + first; it != lists.end(); ++it) {
@@ -965,7 +951,7 @@ void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64
             const size_t k = std::min(w.size() - 1u, static_cast<size_t>(static_cast<double>(w.size()) * tail_frac));
             std::nth_element(w.begin(), w.begin() + static_cast<std::ptrdiff_t>(k), w.end());
             const uint64_t thr = w[k];
-            if (plan_regions_enabled()) {
+            {
                 // One spatial region of the range per XCD, the SAME regions for every class kernel: the members of a
                 // supergroup (and neighbouring nodes generally) then run on one XCD whatever their class, and the
                 // pre-pass lists, tree nodes and leaves they share are fetched into one L2 instead of several.
@@ -1009,8 +995,6 @@ void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64
                         lists.push_back(pos < v.size() ? v[pos] : rk::RK_PLAN_PAD_VALUE);
                     }
                 }
-            } else {
-                std::stable_partition(lists.begin() + first, lists.end(), [&](uint32_t a) { return s.work_cache[a] >= thr; });
             }
             };
     for (int c = 0; c < rk::n_classes; ++c) {
@@ -1026,21 +1010,12 @@ void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64
         if (lpt) {
             std::stable_sort(lists.begin() + first, lists.end(),
                              [&](uint32_t a, uint32_t b2) { return s.work_cache[a] > s.work_cache[b2]; });
-        } else if (!rev && lists.size() - static_cast<size_t>(first) > 1u) {
+        } else if (lists.size() - static_cast<size_t>(first) > 1u) {
             arrange_light_tail(first);
         }
     }
     s.plan.off[rk::n_classes] = static_cast<int64_t>(lists.size());
     s.plan.off_all = s.plan.n_all = s.plan.off_oth = s.plan.n_oth = s.plan.off_123 = s.plan.n_123 = 0;
-    if (rev) {
-        const auto first = static_cast<std::ptrdiff_t>(lists.size());
-        for (int c = RK_MAX_R - 1; c >= 0; --c) {
-            const std::vector<uint32_t> part(lists.begin() + s.plan.off[c], lists.begin() + s.plan.off[c + 1]);
-            lists.insert(lists.end(), part.rbegin(), part.rend());
-        }
-        s.plan.off_all = first;
-        s.plan.n_all = static_cast<int64_t>(lists.size()) - first;
-    }
     if (lpt) {
         // Merged heavy-first lists over the wave-kernel classes (stable: equal weights keep class, then Morton order): all
         // of them, all but R = 2, all but R = 4.
@@ -1083,11 +1058,7 @@ void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64
 // fp64: 2.9k 0.194 / 0.245, 4.2k 0.257 / 0.281, 5.6k 0.328 / 0.305, 6.5k 0.405 / 0.343 (tools/pc_ring_probe.py).
 int64_t pc_any_below_nodes(bool fp64)
 {
-    static const int64_t env = [] {
-        const char *e = std::getenv("RK_PC_ANY_BELOW");
-        return e ? std::atoll(e) : int64_t(-1);
-    }();
-    return env >= 0 ? env : (fp64 ? int64_t(5000) : int64_t(6000));
+    return fp64 ? int64_t(5000) : int64_t(6000);
 }
 
 bool super_cache_enabled()
@@ -1100,27 +1071,14 @@ bool super_cache_enabled()
 }
 
 // ---- split traversal (variant 4, rk_kernels_split.hip): scratch of a call ----
-bool split_default()
-{
-    // The automatic variant keeps to the fused kernels: measured on MI355X the split traversal is slower at every size
-    // (DESIGN.md section 3.5); RK_SPLIT=1 makes it the automatic choice, rk_set_kernel_variant(state, 4) selects it per state.
-    static const bool on = [] {
-        const char *e = std::getenv("RK_SPLIT");
-        return e && std::atoi(e) != 0;
-    }();
-    return on;
-}
+// (The automatic variant keeps to the fused kernels: measured on MI355X the split traversal is slower at every size;
+// rk_set_kernel_variant(state, 4) selects it per state.)
 
 // Longest list k_lists writes; longer ones (tiny opening angles) go to the fused kernel. A property of the call's
 // parameters only, so that a node is served by the same kernel in every launch.
 uint32_t split_max_len()
 {
-    static const uint32_t v = [] {
-        const char *e = std::getenv("RK_SL_MAX_LEN");
-        const long long x = e ? std::atoll(e) : 32768;
-        return static_cast<uint32_t>(std::min<long long>(std::max<long long>(x, rk::SL_SEG), 1ll << 24));
-    }();
-    return v;
+    return 32768u;
 }
 
 // Sizes the list pool for the critical nodes [g_lo, g_hi) of this call, (re)allocates it if it has to grow, digests the
@@ -1160,11 +1118,7 @@ bool prepare_split(rk_state &s, rk::kparams<F> &p, int64_t p_begin, int64_t p_en
     const double est_len = std::min(900. * std::pow(0.75 / std::max(theta, 1e-3), 3.), static_cast<double>(split_max_len()));
     // (each of the two lists of a node holds about half of that; the first segment of each is fixed.)
     const int64_t extra_per_node = 2 * std::max<int64_t>(static_cast<int64_t>(std::ceil(0.75 * est_len / rk::SL_SEG)) - 1, 1);
-    static const int64_t pool_max_seg = [] {
-        const char *e = std::getenv("RK_SL_POOL_MB"); // upper bound of the list pool
-        const long long mb = e ? std::atoll(e) : 24576;
-        return static_cast<int64_t>(std::max<long long>(mb, 16)) * (1ll << 20) / (rk::SL_SEG * 4);
-    }();
+    constexpr int64_t pool_max_seg = int64_t(24576) * (1ll << 20) / (rk::SL_SEG * 4); // the list pool is at most 24 GiB
     int64_t extra = std::max<int64_t>(n_slot * extra_per_node + 4096, s.sl_extra_hint);
     extra = std::min(extra, std::max<int64_t>(pool_max_seg - 2 * n_slot, 4096));
     const int64_t nseg = 2 * n_slot + extra;
@@ -1249,11 +1203,7 @@ void ensure_call_resources(rk_state &s)
         RK_HIP(hipEventCreate(&s.ev1));
     }
     if (s.super_k < 0) {
-        const char *e = std::getenv("RK_SUPER_K");
-        s.super_k = e ? std::atoi(e) : 16;
-        if (s.super_k < 0 || s.super_k > 64) {
-            s.super_k = 16;
-        }
+        s.super_k = 16; // (8 ... 32 measure the same within 1 % at every size, round 5)
     }
     if (s.super_k > 0 && s.n_crit > 0) {
         const int64_t n_super = (s.n_crit + s.super_k - 1) / s.super_k;
@@ -1356,6 +1306,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
     {
         p.xcd_mode = 1; // a contiguous slice of the list per XCD (launch plans choose their own mapping below)
         p.any_rev = 0;
+        p.first_tab = nullptr;
     }
 #ifdef RK_STAMPS
     {
@@ -1435,7 +1386,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
     p.sup_resid = nullptr;
     p.sup_cnt = nullptr;
     if (v2) {
-        // Supergroup pre-pass: K consecutive groups share the upper part of list building (RK_SUPER_K=0 disables).
+        // Supergroup pre-pass: K consecutive groups share the upper part of list building (16 of them).
         if (s.super_k > 0 && s.n_crit > 0) {
             p.super_k = static_cast<uint32_t>(s.super_k);
             p.sup_common = static_cast<typename rk::vt<F>::v4 *>(s.sup_common);
@@ -1468,17 +1419,8 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                 // tree 1.34-1.37 instead of 1.25-1.28: the heavy-first order gives up the L2 locality of neighbouring nodes.)
                 // Round 5: 45000 (rounds 2-4: 30000). With the list kernels' new occupancies the one launch is ahead further up:
                 // whole trees of 31.9k / 38.2k / 44.3k nodes 0.823 / 0.921 / 1.029 -> 0.697 / 0.842 / 0.971 ms; at 54k nodes (2M)
-                // 1.130 -> 1.107 but the 54k-node shards of the 4M tree 1.28 -> 1.32 (tools/jobs_r05/r05_job32.sh).
+                // 1.130 -> 1.107 but the 54k-node shards of the 4M tree 1.28 -> 1.32 (tools/archive/jobs_r05/r05_job32.sh).
                 return e ? std::atoll(e) : int64_t(45000);
-            }();
-            // Between RK_PLAN_MAX_GROUPS and this many nodes: the class-reversed plan for k_list_any (0 = never). Round 3 used it
-            // up to 60 000 nodes (equal to the light-tail plan within 2 % then, and free of the outliers forked launches showed
-            // when they were not replayed from graphs); with the graph cache of round 4 the light-tail plan on the class kernels
-            // is ahead there -- ms per call, reversed / light-tail: 34k nodes 0.833 / 0.809, 38k 0.936 / 0.905, 47k 1.142 / 1.058,
-            // 54k 1.218 / 1.147, 58k 1.406 / 1.327 (tools/size_scan.py, tools/jobs_r04/r04_job64.sh) -- so nothing takes it by default.
-            static const int64_t plan_rev_max_groups = [] {
-                const char *e = std::getenv("RK_PLAN_REV_MAX_GROUPS");
-                return e ? std::atoll(e) : int64_t(30000);
             }();
             bool cached = s.plan.d_lists && s.plan.p_begin == p_begin && s.plan.p_end == p_end
                           && s.plan.mac_value == mac_value;
@@ -1509,17 +1451,14 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
             }
             // Beyond this many nodes the launch is so many rounds of waves deep that its tail no longer matters, and the
             // contiguous slice of the Morton order per XCD (xcd_mode 1) wins: 16M fp64 +0.6 %, 64M +1.5 % with a plan.
-            static const int64_t plan_tail_max_groups = [] {
-                const char *e = std::getenv("RK_PLAN_TAIL_MAX_GROUPS");
-                return e ? std::atoll(e) : int64_t(250000);
-            }();
+            constexpr int64_t plan_tail_max_groups = rk::FIRST_TAIL_MAX;
             const bool want = g_hi > g_lo
                               && (plan_mode == 2
                                   || (plan_mode == 1 && g_hi - g_lo <= plan_tail_max_groups && (cached || repeats)));
             if (want) {
                 if (!cached) {
                     build_plan<F>(s, p_begin, p_end, g_lo, g_hi, mac_value,
-                                  g_hi - g_lo <= plan_max_groups ? 1 : (g_hi - g_lo <= plan_rev_max_groups ? 2 : 0));
+                                  g_hi - g_lo <= plan_max_groups ? 1 : 0);
                     // Remember it (four plans; the oldest goes -- its buffer once nothing else holds it).
                     if (s.plans.size() >= 4) {
                         s.plans.erase(s.plans.begin());
@@ -1535,7 +1474,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                 // Heavy-first order: deal chunks of consecutive list entries round-robin to the XCDs.
                 p.xcd_mode = 0;
                 // Light-tail order: the plan list interleaves the per-XCD queues itself (block i serves entry i).
-                if (g_hi - g_lo > std::max(plan_max_groups, plan_rev_max_groups) && plan_regions_enabled()) {
+                if (g_hi - g_lo > plan_max_groups) {
                     p.xcd_mode = 2;
                 }
             }
@@ -1549,8 +1488,8 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
         const bool sup_cache = super_cache_enabled();
         // (The cached pre-pass output may have been written, or be in use, on another stream: order_after_previous_call() has
         // put this call behind the previous one in that case, so it may reuse or extend the lists.)
-        // Variant 4 (and the automatic variant unless RK_SPLIT=0): list building and dense evaluation as two kernels.
-        const bool split = g_hi > g_lo && (s.variant == 4 || (s.variant == 0 && split_default()));
+        // Variant 4: list building and dense evaluation as two kernels.
+        const bool split = g_hi > g_lo && s.variant == 4;
         const bool need_super = se > sb && !(sup_cache && s.sup_mac == mac_value && s.sup_b <= sb && se <= s.sup_e);
         ran_super = need_super;
         bool split_fb = false;
@@ -1562,7 +1501,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
         // ends with its longest serial chains running alone. Such calls hand lane-mapping classes to the producer /
         // consumer kernel (1 + R waves per node): all of them below 5 000 critical nodes, the class with the longest
         // chains (R = 2: 64 < T <= 128 targets on one wave) below 20 000. Both kernels give the same bits, so this is
-        // a pure scheduling decision (measured: tools/archive_r02/r02_job11.sh, r02_job12.sh).
+        // a pure scheduling decision (measured: tools/archive/jobs_r02/r02_job11.sh, r02_job12.sh).
         constexpr int64_t pc_all_below = 5000, pc_r2_below = 20000;
         unsigned pc_mask = 0u;
         if (s.variant == 3) {
@@ -1580,7 +1519,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
         int any_mode = 0;
         if (!split && s.variant == 0 && any_env != 0 && s.cur_lists == static_cast<const uint32_t *>(s.plan.d_lists)
             && s.plan.n_all > 0 && s.plan.n_all == g_hi - g_lo - (big_e - big_b)) {
-            // Measured (tools/any_probe.py, profiles/r03/one_launch_kernels.txt): k_pc_any at 2.9k nodes 0.134 ms (class
+            // Measured (tools/archive/any_probe.py, profiles/r03/one_launch_kernels.txt): k_pc_any at 2.9k nodes 0.134 ms (class
             // launches 0.140, k_list_any 0.173); k_list_any at 9.4k nodes 0.23 (0.29-0.30; with R = 2 on k_pc 0.27), on the
             // 13.4k-node shards of the 4M tree 0.373-0.379 (0.406-0.412; 0.40), at 26k nodes 0.62 (0.66).
             // 4.2k nodes: class launches on the producer / consumer kernel 0.173, k_pc_any 0.196 (its five-wave workgroups
@@ -1589,8 +1528,25 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
             const int64_t pc_any_below = pc_any_below_nodes(sizeof(F) == 8);
             // (Since forked launch sequences are no longer replayed from a graph, the class launches of 3.2k-5k nodes lost
             // their place -- queued calls, ms: 3.6k nodes 0.167, k_pc_any 0.155, k_list_any 0.177; 3.9k: 0.275 / 0.178 / 0.181;
-            // 4.5k: 0.202 / 0.202 / 0.186; 5.1k: 0.335 / 0.230 / 0.192 -- tools/any_probe3.py.)
+            // 4.5k: 0.202 / 0.202 / 0.186; 5.1k: 0.335 / 0.230 / 0.192 -- tools/archive/any_probe3.py.)
             any_mode = any_env > 0 ? any_env : (g_hi - g_lo <= pc_any_below ? 1 : 3);
+        }
+        // A call WITHOUT a plan over all critical nodes of a tree that came with the light-tail arrangement of a first call (made on the
+        // device with the tree, rk_build.hip: trees of FIRST_ORDER_MAX .. FIRST_TAIL_MAX critical nodes): the class kernels take their
+        // nodes from its per-region queues -- every traversal of a time-stepping loop on 2M-8M particles is such a call.
+        // Measured against what such calls ran before (examples/leapfrog, traversal ms, tools/jobs_r06/r06_job5.sh): 1.9M particles
+        // (51k nodes; one launch over the class lists read backwards) 0.986 -> 0.973, 2.2M (60k) 1.13 -> 1.08, 3M (class kernels,
+        // one Morton slice per XCD) 1.48 -> 1.42, 4M 1.92 -> 1.85, 6M 2.88 -> 2.80; the rebuild pays 20-30 us for it.
+        if (s.cur_lists == static_cast<const uint32_t *>(s.buf[RK_BUF_CLASS]) && s.first_tail_valid && s.first_order && s.first_tab
+            && s.variant == 0 && any_mode == 0 && !split && pc_mask == 0u && g_lo == 0 && g_hi == s.n_crit) {
+            s.cur_lists = static_cast<const uint32_t *>(s.first_order);
+            for (int c = 0; c < RK_MAX_R; ++c) {
+                s.cur_off[c] = 0;
+                cb[c] = 0;
+                ce[c] = static_cast<int64_t>(s.first_grid[c]);
+            }
+            p.xcd_mode = 3;
+            p.first_tab = static_cast<const uint32_t *>(s.first_tab);
         }
         // A small call WITHOUT a plan (the first call on a tree: every step of a time-stepping loop) that covers all critical
         // nodes: one launch too, over the state's own class lists read backwards -- R = 4 first, the lightest class last, which
@@ -1598,12 +1554,9 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
         const uint32_t *first_list = nullptr;
         int64_t first_n = 0;
         {
-            static const bool any_first = [] {
-                const char *e = std::getenv("RK_ANY_FIRST"); // 0: class launches for calls without a plan
-                return !(e && std::atoi(e) == 0);
-            }();
+            constexpr bool any_first = true; // (RK_ANY=0 keeps the class launches for these calls too)
             static const int64_t any_first_max = [] {
-                // First calls, ms (tools/first_call_probe.py, Plummer; class launches -> this): 100k 0.191 -> 0.178, 350k
+                // First calls, ms (tools/archive/first_call_probe.py, Plummer; class launches -> this): 100k 0.191 -> 0.178, 350k
                 // 0.488 -> 0.360, 1M 0.83 -> 0.76, 1.8M (47.6k nodes) 1.51 -> 1.25; leapfrog harness 100k 0.187 -> 0.166,
                 // 2M (~50k nodes) 1.082 -> 1.069; beyond, the class kernels with a Morton slice per XCD win: 4M 1.97 vs 2.05.
                 return int64_t(60000);
@@ -1692,17 +1645,9 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                 }
             }
             // Critical nodes too large for one wavefront: a workgroup each, cut into chunks of targets (k_list<BIG>).
-            // RK_BIG_DFS=1 selects the scalar block-per-node walk of variant 1 instead (cross-check).
-            static const bool big_dfs = [] {
-                const char *e = std::getenv("RK_BIG_DFS");
-                return e && std::atoi(e) != 0;
-            }();
+            // (Variant 1 walks them with its scalar block-per-node kernel instead: the cross-check, rk_kernels_xcheck.hip.)
             const auto *big_list = static_cast<const uint32_t *>(s.buf[RK_BUF_CLASS]) + s.class2_off[rk::big_class] + big_b;
-            if (big_dfs) {
-                rk::launch_block<F>(s, q, p, big_list, big_e - big_b, st);
-            } else {
-                rk::launch_list_big<F>(s, q, p, big_list, big_e - big_b, st);
-            }
+            rk::launch_list_big<F>(s, q, p, big_list, big_e - big_b, st);
             if (split && split_fb) {
                 // Nodes whose list k_lists did not complete (longer than the cap, or the pool ran out): the chunked form of
                 // the fused kernel, over a list whose length is only known on the device. Skipped once a report of this
@@ -1720,7 +1665,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
         };
         // The one-launch sequences (pre-pass + k_pc_any / k_list_any on one stream) are launched directly: replayed from a graph
         // they are 3-8 us slower per call (device-resident ms per step, graph / direct: 100k 0.1141-0.1153 / 0.1109-0.1115, 350k
-        // 0.2598-0.2608 / 0.2522-0.2532, 1M 0.668 / 0.653-0.664; tools/jobs_r04/r04_job57.sh) -- round 2 measured the opposite for
+        // 0.2598-0.2608 / 0.2522-0.2532, 1M 0.668 / 0.653-0.664; tools/archive/jobs_r04/r04_job57.sh) -- round 2 measured the opposite for
         // the four forked class kernels these sizes ran then. RK_GRAPH_LINEAR=1 captures them too.
         static const bool graph_linear = [] {
             const char *e = std::getenv("RK_GRAPH_LINEAR");
@@ -2572,12 +2517,8 @@ int rk_acc_pot(rk_state *s, int q, int64_t p_begin, int64_t p_end, void *const *
         // Output arrays in pinned host memory (rk_host_alloc(), rakau_amd::pinned_allocator, hipHostRegister): the kernels
         // write the results where the caller wants them, nothing is staged or copied.
         {
-            static const bool direct = [] {
-                const char *e = std::getenv("RK_HOST_DIRECT"); // 0: treat pinned arrays like pageable ones
-                return !(e && std::atoi(e) == 0);
-            }();
             void *v_ptrs[4] = {};
-            bool all = direct;
+            bool all = true;
             for (int k = 0; all && k < nres; ++k) {
                 v_ptrs[k] = device_view_of_host_range(dst[k], count * fsz);
                 all = v_ptrs[k] != nullptr;
@@ -2588,12 +2529,9 @@ int rk_acc_pot(rk_state *s, int q, int64_t p_begin, int64_t p_end, void *const *
                 // streams, the R <= 2 kernels (8 waves per SIMD, short waves) take most of the slots first and end at 1.3 ms of a
                 // 2.2 ms step, which leaves the R = 3 / 4 kernels to run among themselves at 6 waves per SIMD and the R = 3 kernel
                 // alone for the last 0.2 ms (tools/seam_timeline.py): 4M 2.303 -> 2.234 ms per call, 1737 -> 1790 Mparticles/s
-                // (tools/jobs_r05/r05_job24.sh; round 4 measured the replay 0.01 ms SLOWER: the kernels were 4 % slower then and
-                // better balanced at 7/7/6/5 waves per SIMD). RK_HOST_GRAPH=0: direct launches.
-                static const bool host_graph = [] {
-                    const char *e = std::getenv("RK_HOST_GRAPH");
-                    return !(e && std::atoi(e) == 0);
-                }();
+                // (tools/archive/jobs_r05/r05_job24.sh; round 4 measured the replay 0.01 ms SLOWER: the kernels were 4 % slower then and
+                // better balanced at 7/7/6/5 waves per SIMD).
+                constexpr bool host_graph = true;
                 s->want_done_event = true;
                 try {
                     if (s->fp == RK_F32) {
@@ -2644,16 +2582,13 @@ int rk_acc_pot(rk_state *s, int q, int64_t p_begin, int64_t p_end, void *const *
         // "Memory access fault by GPU ... Write access to a read-only page" or of a fault when the cached pin is evicted
         // (tools/stress_host_register.py: every run with the registration on aborts within seconds, none without;
         // profiles/r03/host_register_overlap.txt). Only for applications that never hand pageable memory to HIP copies.
-        // With it on: always for arrays the previous call on this state wrote, otherwise up to RK_HOST_REGISTER_MAX_MB (256).
+        // With it on: always for arrays the previous call on this state wrote, otherwise up to 256 MB.
         {
             static const bool reg = [] {
                 const char *e = std::getenv("RK_HOST_REGISTER");
                 return e && std::atoi(e) != 0;
             }();
-            static const size_t reg_max = [] {
-                const char *e = std::getenv("RK_HOST_REGISTER_MAX_MB");
-                return static_cast<size_t>(e ? std::max(std::atoll(e), 0ll) : 256) << 20;
-            }();
+            constexpr size_t reg_max = size_t(256) << 20;
             bool seen = true;
             for (int k = 0; k < nres; ++k) {
                 seen = seen && s->last_host_out[k] == dst[k];
@@ -2777,11 +2712,8 @@ int rk_acc_pot(rk_state *s, int q, int64_t p_begin, int64_t p_end, void *const *
                 stream_copy(dst[k] + off, stage + k * arr + off, nb);
             });
         };
-        // (replayed from a hipGraph when the call recurs, like the pinned-output call above: RK_HOST_GRAPH)
-        static const bool staged_graph = [] {
-            const char *e = std::getenv("RK_HOST_GRAPH");
-            return !(e && std::atoi(e) == 0);
-        }();
+        // (replayed from a hipGraph when the call recurs, like the pinned-output call above)
+        constexpr bool staged_graph = true;
         auto run = [&](int64_t b, int64_t e, void *const *ptrs) {
             s->want_done_event = true;
             try {
@@ -2796,18 +2728,14 @@ int rk_acc_pot(rk_state *s, int q, int64_t p_begin, int64_t p_end, void *const *
             }
             s->want_done_event = false;
         };
-        // Two parts (round 4): the first RK_HOST_SPLIT (0.85) of the range is traversed first and DELIVERED by the host threads
+        // Two parts (round 4): the first 85 % of the range is traversed first and DELIVERED by the host threads
         // while the second part is traversed; only the second part's delivery is left when the kernels end. The cut is a
         // critical-node boundary, the two parts are ordinary sub-range calls (their union equals the one-part result bit for
         // bit), and two launches cost about 0.1 ms more than one at 4M, where the delivery of 85 % of the results costs
         // 0.3-0.5: 2.65 -> 2.53-2.54 ms per call (fractions 0.7 / 0.8 / 0.85 / 0.9: 2.68 / 2.56 / 2.54 / 2.53-2.80), 2M 1.59 -> 1.39,
-        // 4M accelerations + potentials 3.32 -> 2.79 (tools/jobs_r04/r04_job39.sh). RK_HOST_SPLIT=0 (or results below
-        // 16 MB): one part, delivered at the end.
-        static const double split_frac = [] {
-            const char *e = std::getenv("RK_HOST_SPLIT");
-            const double v = e ? std::atof(e) : 0.85;
-            return (v > 0.05 && v < 0.95) ? v : 0.0;
-        }();
+        // 4M accelerations + potentials 3.32 -> 2.79 (tools/archive/jobs_r04/r04_job39.sh). Results below
+        // 16 MB: one part, delivered at the end.
+        constexpr double split_frac = 0.85;
         int64_t cut = p_begin;
         if (split_frac > 0.0 && need >= (size_t(16) << 20)) {
             ensure_mirrors(*s);
@@ -3258,7 +3186,12 @@ static void fill_from_build(rk_state &s, const void *const parts[4], bool on_dev
     s.box_size = box_size;
     s.box_deduced = box_size == 0.;
     std::vector<uint4> crit;
-    static const bool timing = std::getenv("RK_BUILD_TIMING") != nullptr; // diagnostic: phase times on stderr
+    
+#ifdef RK_BUILD_TIMING
+    constexpr bool timing = true; // diagnostic build (-DRK_BUILD_TIMING): phase times on stderr
+#else
+    constexpr bool timing = false;
+#endif
     const auto now = [] { return std::chrono::steady_clock::now(); };
     const auto t0 = now();
     auto t1 = t0, t2 = t0;
@@ -3435,10 +3368,17 @@ int rk_state_device_ptr(const rk_state *s, int what, void **ptr, int64_t *bytes)
             case 0: *ptr = s->buf[RK_BUF_PART4], *bytes = s->buf_bytes[RK_BUF_PART4]; break;
             case 1: *ptr = s->bld_perm, *bytes = s->bld_perm ? static_cast<int64_t>(n * sizeof(uint32_t)) : 0; break;
             case 2: *ptr = s->bld_codes, *bytes = s->bld_codes ? static_cast<int64_t>(n * sizeof(uint64_t)) : 0; break;
-            case 3: { // launch order of the first call on a small tree (diagnostic): critical-node indices, uint32
-                const bool have = s->first_order_valid && s->first_order;
+            case 3: { // launch order of the first call (diagnostic): critical-node indices, uint32 -- heavy-first on a small tree,
+                      // the queues of the light-tail arrangement on a large one
+                const bool have = (s->first_order_valid || s->first_tail_valid) && s->first_order;
                 *ptr = have ? s->first_order : nullptr;
                 *bytes = have ? (s->class2_off[RK_MAX_R] - s->class2_off[0]) * static_cast<int64_t>(sizeof(uint32_t)) : 0;
+                break;
+            }
+            case 4: { // table of the light-tail arrangement (FIRST_TAB_WORDS uint32; null unless the tree came with one)
+                const bool have = s->first_tail_valid && s->first_tab;
+                *ptr = have ? s->first_tab : nullptr;
+                *bytes = have ? static_cast<int64_t>(rk::FIRST_TAB_WORDS * sizeof(uint32_t)) : 0;
                 break;
             }
             default: throw rk::error(RK_EINVAL, "invalid selector for rk_state_device_ptr");

@@ -143,10 +143,11 @@ class State:
 
     def device_ptr(self, what):
         """(address, bytes) of a resident array: 'parts' ({x,y,z,m} AoS, Morton order), 'perm' (uint32), 'codes',
-        'first_order' (launch order of the first call on a small tree: critical-node indices, uint32)."""
+        'first_order' (launch order of the first call: critical-node indices, uint32), 'first_tab' (queue table of the light-tail
+        arrangement of a large tree, 72 uint32; (0, 0) unless the tree came with one)."""
         ptr = C.c_void_p()
         nbytes = C.c_int64()
-        sel = {"parts": 0, "perm": 1, "codes": 2, "first_order": 3}[what]
+        sel = {"parts": 0, "perm": 1, "codes": 2, "first_order": 3, "first_tab": 4}[what]
         _capi.check(_capi.lib().rk_state_device_ptr(self._h, sel, C.byref(ptr), C.byref(nbytes)))
         return ptr.value or 0, nbytes.value
 

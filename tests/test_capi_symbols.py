@@ -69,3 +69,18 @@ def test_selecting_a_cross_check_variant_without_a_state_is_an_error_not_a_crash
     lib = _capi.lib()
     assert lib.rk_set_kernel_variant(None, 1) != 0
     assert b"variant" in lib.rk_last_error()
+
+
+def test_environment_knobs_are_few_and_documented():
+    """The library reads at most 25 RK_* environment variables, and INTEGRATION.md's table names every one."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    knobs = set()
+    for f in glob.glob(os.path.join(root, "rakau_amd", "csrc", "*")) + glob.glob(os.path.join(root, "include", "**", "*.h*"), recursive=True):
+        if os.path.isfile(f):
+            knobs.update(re.findall(r'getenv\("(RK_[A-Z0-9_]+)"\)', open(f, errors="replace").read()))
+    assert 0 < len(knobs) <= 25, sorted(knobs)
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    missing = [k for k in sorted(knobs) if "`%s`" % k not in doc]
+    assert not missing, missing

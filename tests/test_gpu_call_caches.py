@@ -86,21 +86,20 @@ for variant in (0, 2, 3, 4):
 np.savez(sys.argv[1], **res)
 """
     files = []
-    # plain: no plan (full-range calls: one launch over the reversed class lists); tail / tail_chunks: the light-tail plan; the rest: the heavy-first plan of small calls with its
+    # plain: no plan (full-range calls: one launch over the reversed class lists); tail: the light-tail plan; the rest: the heavy-first plan of small calls with its
     # one-launch kernels (k_pc_any up to 6000 critical nodes, k_list_any above; forced both ways, and the mixed forms).
     for name, extra in (("plain", {"RK_PLAN": "0"}), ("tail", {"RK_PLAN_MAX_GROUPS": "64"}),
-                        ("tail_chunks", {"RK_PLAN_MAX_GROUPS": "64", "RK_PLAN_REGIONS": "0"}),
                         ("heavy_first_auto", {}), ("pc_any", {"RK_ANY": "1"}), ("list_any", {"RK_ANY": "3"}),
                         ("pc_r2_list_any", {"RK_ANY": "2"}),
                         ("class_launches", {"RK_ANY": "0"}),
                         # calls without a plan: one launch over the class lists read backwards (full range), forced both ways, off
                         ("first_pc_any", {"RK_PLAN": "0", "RK_ANY": "1"}), ("first_list_any", {"RK_PLAN": "0", "RK_ANY": "3"}),
-                        ("first_class_launches", {"RK_PLAN": "0", "RK_ANY_FIRST": "0"}),
+                        ("first_class_launches", {"RK_PLAN": "0", "RK_ANY": "0"}),
                         # first calls over the class lists read backwards instead of the order made on the device with the tree
                         ("first_pc_any_class_order", {"RK_PLAN": "0", "RK_ANY": "1", "RK_FIRST_ORDER": "0"}),
                         # graphs of forked sequences: parked, only the first two captured, never captured
-                        ("forked_graphs_cap2", {"RK_PLAN": "0", "RK_ANY_FIRST": "0", "RK_GRAPH_FORKED_MAX": "2"}),
-                        ("forked_graphs_off", {"RK_PLAN_MAX_GROUPS": "64", "RK_PLAN_REV_MAX_GROUPS": "0", "RK_GRAPH_FORKED": "0"}),
+                        ("forked_graphs_cap2", {"RK_PLAN": "0", "RK_ANY": "0", "RK_GRAPH_FORKED_MAX": "2"}),
+                        ("forked_graphs_off", {"RK_PLAN_MAX_GROUPS": "64", "RK_GRAPH_FORKED_MAX": "0"}),
                         ("no_graphs", {"RK_GRAPH": "0"}), ("linear_graphs", {"RK_GRAPH_LINEAR": "1"})):
         env = dict(os.environ, RK_BACKTRACE="1", PYTHONFAULTHANDLER="1", **extra)
         env["PYTHONPATH"] = os.pathsep.join([root, os.path.join(root, "tests"), env.get("PYTHONPATH", "")])
@@ -117,8 +116,8 @@ np.savez(sys.argv[1], **res)
             assert np.array_equal(files[0][k], other[k]), k
 
 
-@pytest.mark.parametrize("name,extra,nsig", [("one_launch_8", {"RK_GRAPH_LINEAR": "1"}, 8), ("forked_8", {"RK_PLAN": "0", "RK_ANY_FIRST": "0"}, 8),
-                                             ("forked_20_cap4", {"RK_PLAN": "0", "RK_ANY_FIRST": "0", "RK_GRAPH_FORKED_MAX": "4"}, 20)])
+@pytest.mark.parametrize("name,extra,nsig", [("one_launch_8", {"RK_GRAPH_LINEAR": "1"}, 8), ("forked_8", {"RK_PLAN": "0", "RK_ANY": "0"}, 8),
+                                             ("forked_20_cap4", {"RK_PLAN": "0", "RK_ANY": "0", "RK_GRAPH_FORKED_MAX": "4"}, 20)])
 def test_graph_cache_keeps_replay_for_recurring_signatures(name, extra, nsig):
     """tools/stress_graph_recurring.py: a caller alternating among `nsig` recurring signatures. Up to 8 (RK_GRAPH_CACHE) every
     signature is captured once and replayed ever after -- linear graphs (one-launch kernels) and forked ones (class kernels on
@@ -131,7 +130,7 @@ def test_graph_cache_keeps_replay_for_recurring_signatures(name, extra, nsig):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     # (the cache's own knobs are pinned: the test is about its default behaviour whatever the caller's environment says)
-    env = dict(os.environ, RK_BACKTRACE="1", PYTHONFAULTHANDLER="1", RK_GRAPH="1", RK_GRAPH_CACHE="8", RK_GRAPH_UPDATE="1")
+    env = dict(os.environ, RK_BACKTRACE="1", PYTHONFAULTHANDLER="1", RK_GRAPH="1", RK_GRAPH_CACHE="8")
     env.update(extra)
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_graph_recurring.py"), "1500", str(nsig)],
                          capture_output=True, text=True, timeout=900, env=env, cwd=root)

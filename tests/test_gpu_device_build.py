@@ -304,33 +304,77 @@ def test_exact_build_4m_census_and_time():
     sf.close()
 
 
-@pytest.mark.parametrize("n,ncrit", [(3000, 128), (60000, 128), (150000, 256), (150000, 1300), (1500000, 128)])
+def class2_of(size):
+    """rk_common.hpp class2_of_compute(): targets per lane R = c + 1 that minimises R / floor(64 / ceil(size / R))."""
+    best, best_cost = -1, 0.0
+    for c in range(4):
+        tp = (size + c) // (c + 1)
+        if tp > 64:
+            continue
+        cost = (c + 1) / (64 // tp)
+        if best < 0 or cost < best_cost - 1e-12:
+            best, best_cost = c, cost
+    return best
+
+
+@pytest.mark.parametrize("n,ncrit", [(3000, 128), (60000, 128), (150000, 256), (150000, 1300), (1500000, 128), (2300000, 128)])
 def test_first_call_launch_order_made_on_the_device(n, ncrit):
-    """Small trees (at most 49152 critical nodes) come with the launch order of their first call, made on the device with the
-    tree (rk_build.hip make_first_order): the critical nodes the wave kernels serve by decreasing size (in steps of two), ties in Morton order --
-    the heavy-first order repeated calls get from the host -- for trees built on the device, for host trees converted
-    there and for replicas; every such node exactly once, oversized nodes (ncrit = 1300) left to their own kernel. The first call over that
-    list gives the bits of the first call over the class lists (RK_FIRST_ORDER=0 is one of the environments of
+    """Trees come with the launch order of their first call, made on the device with the tree (rk_build.hip bin_classes) -- for
+    trees built on the device, for host trees converted there and for replicas.
+    Up to 49152 critical nodes: the critical nodes the wave kernels serve by decreasing size (in steps of two), ties in Morton order
+    -- the heavy-first order repeated calls get from the host; every such node exactly once, oversized nodes (ncrit = 1300) left
+    to their own kernel.
+    Beyond (up to 250000): the light-tail arrangement repeated calls get from the host -- per lane-mapping class and per XCD region
+    (eight regions of equal particle count) one queue: the nodes of the region in Morton order, those below the first quartile of
+    the class's sizes (estimated on a sample of at most 8192 nodes) at the end.
+    Either way the first call gives the bits of a repeated call (RK_FIRST_ORDER=0 is one of the environments of
     tests/test_gpu_call_caches.py)."""
     import torch
     m, x, y, z = oracle.plummer(n, np.float32)
     ot = oracle.Tree(x, y, z, m, ncrit=ncrit, max_leaf_n=16 if ncrit < 1000 else 300)
     built = rakau_amd.State.build(x, y, z, m, ncrit=ncrit, max_leaf_n=ot.max_leaf_n)
-    # (a replica sorts its own copy of the critical nodes: rk_state_clone / import / broadcast)
+
+    def fetch(st, what, count):
+        ptr, nbytes = st.device_ptr(what)
+        assert nbytes == 4 * count and ptr != 0, (what, nbytes, count)
+        d_got = torch.zeros(count, dtype=torch.int32, device="cuda")
+        rakau_amd._capi.check(rakau_amd._capi.lib().rk_device_memcpy(d_got.data_ptr(), ptr, nbytes, 0))
+        torch.cuda.synchronize()
+        return d_got.cpu().numpy().astype(np.int64)
+
+    # (a replica makes the order from its own copy of the critical nodes: rk_state_clone / import / broadcast)
     for st in (built, state_from_oracle(ot), built.clone(0)):
         cr = st.crit_ranges()
         size = (cr[:, 1] - cr[:, 0]).astype(np.int64)
-        ptr, nbytes = st.device_ptr("first_order")
-        if len(cr) > 49152:
-            assert nbytes == 0
-            continue
         wave = np.flatnonzero(size <= 256)
-        assert nbytes == 4 * len(wave) and ptr != 0
-        d_got = torch.zeros(len(wave), dtype=torch.int32, device="cuda")
-        rakau_amd._capi.check(rakau_amd._capi.lib().rk_device_memcpy(d_got.data_ptr(), ptr, nbytes, 0))
-        torch.cuda.synchronize()
-        expect = wave[np.lexsort((wave, (256 - size[wave]) >> 1))]  # sizes in steps of two, ties in Morton order
-        assert np.array_equal(d_got.cpu().numpy().astype(np.int64), expect)
+        if len(cr) <= 49152:
+            assert st.device_ptr("first_tab") == (0, 0)
+            got = fetch(st, "first_order", len(wave))
+            expect = wave[np.lexsort((wave, (256 - size[wave]) >> 1))]  # sizes in steps of two, ties in Morton order
+            assert np.array_equal(got, expect)
+        else:
+            got = fetch(st, "first_order", len(wave))
+            tab = fetch(st, "first_tab", 72)
+            cls = np.array([class2_of(int(v)) for v in size[wave]])
+            region = np.minimum(7, cr[wave, 0].astype(np.int64) * 8 // n)
+            pos = 0
+            # the size from which a node of class c is bulk: the first quartile of the class's sizes among every stride-th critical node
+            stride = max(1, len(cr) // 8192)
+            s_size = size[::stride]
+            s_size = s_size[(s_size >= 1) & (s_size <= 256)]
+            s_cls = np.array([class2_of(int(v)) for v in s_size])
+            for c in range(4):
+                of_class = np.sort(s_size[s_cls == c])
+                thr = int(of_class[min(len(of_class) - 1, len(of_class) // 4)]) if len(of_class) else 0
+                assert tab[64 + c] == thr
+                for xr in range(8):
+                    assert tab[c * 16 + xr] == pos
+                    sel = wave[(cls == c) & (region == xr)]
+                    expect = np.concatenate([sel[size[sel] >= thr], sel[size[sel] < thr]])
+                    assert tab[c * 16 + 8 + xr] == len(expect)
+                    assert np.array_equal(got[pos:pos + len(expect)], expect), (c, xr)
+                    pos += len(expect)
+            assert pos == len(wave)
         # and the first call, which runs over it, agrees with a repeated call (host plan) bit for bit
         mv = rakau_amd.mac_value_of(0.75, "bh", np.float32)
         a = st.acc_pot(0, mv)

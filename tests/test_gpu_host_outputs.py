@@ -85,8 +85,7 @@ def test_pinned_block_lifetime_and_errors():
     assert _capi.lib().rk_host_free(None) == 0
 
 
-@pytest.mark.parametrize("env", [{"RK_HOST_DIRECT": "0"}, {"RK_HOST_THREADS": "1"}, {"RK_HOST_THREADS": "3"},
-                                 {"RK_HOST_REGISTER": "1"}, {"RK_HOST_REGISTER": "1", "RK_HOST_REGISTER_MAX_MB": "0"}])
+@pytest.mark.parametrize("env", [{"RK_HOST_THREADS": "1"}, {"RK_HOST_THREADS": "3"}, {"RK_HOST_REGISTER": "1"}])
 def test_delivery_knobs_do_not_change_results(env):
     code = """
 import numpy as np, oracle, rakau_amd
