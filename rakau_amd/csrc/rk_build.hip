@@ -1175,7 +1175,7 @@ static_assert(NBIN >= static_cast<unsigned>(n_classes));
 
 // Launch order of the FIRST call on a small tree (at most FIRST_ORDER_MAX critical nodes): the critical nodes of the wave
 // kernels' classes sorted by decreasing size, ties in Morton order -- the order of the heavy-first launch plan that repeated
-// calls get from the host (rk_state.hip build_plan), made here so that a time-stepping loop, whose every traversal is a first
+// calls get from the host (rk_launch.hip build_plan), made here so that a time-stepping loop, whose every traversal is a first
 // call, has it too (100k particles, one-launch producer / consumer kernel: 0.144 ms over the class lists read backwards, 0.101
 // over the sorted list). Keys for a stable radix sort over eight bits (one pass): sizes in steps of two, 0 = the largest a
 // wavefront serves; oversized nodes (their own kernel) get the last key and fall off the end of the list.
@@ -1192,7 +1192,7 @@ __device__ inline uint32_t first_key(uint32_t size)
 }
 
 // Trees of FIRST_ORDER_MAX .. FIRST_TAIL_MAX critical nodes get the LIGHT-TAIL arrangement for their first call instead -- what the
-// host makes for repeated calls of that size (rk_state.hip build_plan, arrange_light_tail): per wave-kernel class the nodes in Morton
+// host makes for repeated calls of that size (rk_launch.hip build_plan, arrange_light_tail): per wave-kernel class the nodes in Morton
 // order with the lightest quarter of the class moved to the end, so that the device drains over short waves, and one spatial region
 // of the tree per XCD, the same regions in every class kernel, so that neighbouring nodes share an L2 whatever their class. Same
 // three partition kernels, other key: (class, region, bulk | light). Regions are cut at equal weight = particle count, and the

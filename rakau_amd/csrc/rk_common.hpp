@@ -42,7 +42,7 @@ constexpr int n_classes = 7;  // classes 0..5 are served by wave kernels, the la
 constexpr int big_class = n_classes - 1;
 // Beyond FIRST_ORDER_MAX and up to this many critical nodes a tree gets the LIGHT-TAIL arrangement of a first call instead (per
 // class and per XCD region: the nodes in Morton order, the lightest quarter of the class at the end; rk_build.hip k_tail_sizes).
-// The limit is RK_PLAN_TAIL_MAX_GROUPS' default: beyond it the plain Morton slices per XCD win (rk_state.hip).
+// The same limit holds for the light-tail plans of repeated calls: beyond it the plain Morton slices per XCD win (rk_launch.hip).
 constexpr unsigned FIRST_TAIL_MAX = 250000;
 // Table of the light-tail arrangement (uint32, device memory): per wave-kernel class c (R = c + 1) and XCD region x the start
 // [c * 16 + x] and the length [c * 16 + 8 + x] of its queue inside first_order; [64 + c] = size from which a node of class c is bulk.
@@ -295,7 +295,7 @@ struct rk_state {
     struct graph_entry {
         graph_key key;
         hipGraphExec_t exec;
-        bool forked; // the captured sequence has parallel branches (such executables are never destroyed, see rk_state.hip)
+        bool forked; // the captured sequence has parallel branches (such executables are never destroyed, see rk_launch.hip)
     };
     std::vector<graph_entry> gcache;
     std::vector<graph_key> seen_keys; // signatures of the last calls (a graph is captured when one recurs)

@@ -15,7 +15,7 @@
 //
 // The sequence of tiles, their contents, the number of source splits NS and the order in which every target receives its
 // contributions are those of the list kernel, so the results are BIT-IDENTICAL to it (tests assert this) -- which kernel
-// serves a call is therefore a pure scheduling decision (rk_state.hip picks this one for calls over few critical nodes).
+// serves a call is therefore a pure scheduling decision (rk_launch.hip picks this one for calls over few critical nodes).
 // What it buys there: the critical path of a group is max(list building, dense / consumers) instead of list building + dense.
 //
 // The MAC decisions are those of the reference's CPU engine (include/rakau/tree.hpp:2662-2672 of the reference).

@@ -196,7 +196,7 @@ __device__ __forceinline__ unsigned xcd_chunked_block(unsigned b, unsigned nb)
 // mode 0: XCD x walks chunks x, x + 8, x + 16, ... of XCD_CHUNK consecutive blocks (L2 locality inside a
 // chunk, work spread evenly over the XCDs whatever the spatial variation of the group costs);
 // mode 1: one contiguous slice per XCD; mode 2: identity (hardware round-robin: block i on XCD i % 8; the light-tail launch
-// plan of rk_state.hip lays its list out for this); mode 3: identity too -- the light-tail arrangement made on the device for
+// plan of rk_launch.hip lays its list out for this); mode 3: identity too -- the light-tail arrangement made on the device for
 // FIRST calls (rk_build.hip k_tail_sizes), whose per-XCD queues are not interleaved into one padded list but found through a table.
 constexpr unsigned XCD_CHUNK = 16;
 __device__ __forceinline__ unsigned xcd_map_block(unsigned b, unsigned nb, int mode)
