@@ -298,6 +298,19 @@ struct rk_state {
         bool forked; // the captured sequence has parallel branches (such executables are never destroyed, see rk_launch.hip)
     };
     std::vector<graph_entry> gcache;
+    // Executable graphs of the class kernels alone (no pre-pass, no events: four independent kernel nodes), RE-TARGETED on every use
+    // (hipGraphExecKernelNodeSetParams: new grid sizes and arguments, microseconds): what a call that is the first of its kind --
+    // every traversal of a time-stepping loop -- launches its class kernels through instead of forking them onto side streams
+    // (rk_launch.hip launch_classes_retargeted). func[] identifies the kernels (precision, Q, criterion, dimension, R).
+    struct class_graph {
+        int pdev = -1;
+        unsigned mask = 0u;
+        const void *func[4] = {};
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        hipGraphNode_t node[4] = {};
+    };
+    std::vector<class_graph> class_graphs;
     std::vector<graph_key> seen_keys; // signatures of the last calls (a graph is captured when one recurs)
     uint64_t graph_stats[4] = {};     // replays, captures (instantiated or re-targeted), direct launches, re-targeted executables
     hipStream_t cap_stream = nullptr;
@@ -402,6 +415,9 @@ void launch_traversal(const rk_state &s, int q, const kparams<F> &p, const int64
 template <typename F>
 void launch_list(const rk_state &s, int q, const kparams<F> &p, const int64_t cls_begin[n_classes],
                  const int64_t cls_end[n_classes], hipStream_t const streams[n_list_R], unsigned class_mask = ~0u);
+// The class kernel launch_list() would launch for lane-mapping class c of this state and Q (for kernel nodes of explicit graphs).
+template <typename F>
+const void *list_kernel_symbol(const rk_state &s, int q, int c);
 // One launch over critical nodes of any lane-mapping class (small calls): the list kernel, the producer / consumer kernel.
 template <typename F>
 void launch_list_any(const rk_state &s, int q, const kparams<F> &p, const uint32_t *list, int64_t n, hipStream_t stream,

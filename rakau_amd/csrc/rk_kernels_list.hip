@@ -897,6 +897,46 @@ void launch_list(const rk_state &s, int q, const kparams<F> &p, const int64_t cb
     RK_HIP(hipGetLastError());
 }
 
+template <typename F>
+const void *list_kernel_symbol(const rk_state &s, int q, int c)
+{
+    auto pick = [&](auto Qt, auto Mt) -> const void * {
+        constexpr int Q = decltype(Qt)::value, M = mac_targ(decltype(Mt)::value);
+        auto of_nd = [&](auto NDt) -> const void * {
+            constexpr int ND = decltype(NDt)::value;
+            switch (c) {
+                case 0: return reinterpret_cast<const void *>(&k_list<F, Q, M, 1, ND>);
+                case 1: return reinterpret_cast<const void *>(&k_list<F, Q, M, 2, ND>);
+                case 2: return reinterpret_cast<const void *>(&k_list<F, Q, M, 3, ND>);
+                case 3: return reinterpret_cast<const void *>(&k_list<F, Q, M, 4, ND>);
+                default: return nullptr;
+            }
+        };
+        if (s.ndim == 3 || !RK_QUAD_BODY) {
+            return of_nd(std::integral_constant<int, 3>{});
+        }
+        return of_nd(std::integral_constant<int, 2>{});
+    };
+    using i0 = std::integral_constant<int, 0>;
+    using i1 = std::integral_constant<int, 1>;
+    using i2 = std::integral_constant<int, 2>;
+    switch (q * 2 + s.mac) {
+        case 0: return pick(i0{}, i0{});
+#ifndef RK_SLIM
+        case 1: return pick(i0{}, i1{});
+        case 2: return pick(i1{}, i0{});
+        case 3: return pick(i1{}, i1{});
+        case 4: return pick(i2{}, i0{});
+        case 5: return pick(i2{}, i1{});
+#endif
+        default: return nullptr;
+    }
+}
+template const void *list_kernel_symbol<float>(const rk_state &, int, int);
+#ifndef RK_SLIM
+template const void *list_kernel_symbol<double>(const rk_state &, int, int);
+#endif
+
 // One launch over a list of critical nodes of any lane-mapping class (k_list_any).
 template <typename F>
 void launch_list_any(const rk_state &s, int q, const kparams<F> &p, const uint32_t *list, int64_t n, hipStream_t stream, int rmax)

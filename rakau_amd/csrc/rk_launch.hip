@@ -510,6 +510,141 @@ bool prepare_split(rk_state &s, rk::kparams<F> &p, int64_t p_begin, int64_t p_en
              && s.sl_clean_npart <= static_cast<int64_t>(p.sl_npart) && s.sl_clean_nseg <= static_cast<int64_t>(p.sl_nseg));
 }
 
+// ---- class kernels of a call that is the first of its kind, through a re-targeted executable graph ----
+// Four class kernels launched directly are four dispatches on four hardware queues joined by events: the queues are served round
+// robin, the R <= 2 kernels (8 waves per SIMD, short waves) take most slots first and the R = 3 kernel ends alone; replayed from a
+// graph they are served in order from one queue, which is worth 2.5 % at 4M particles and 4.5 % at 2M (tools/jobs_r06/r06_job3.sh).
+// Repeated calls get that from the graph cache; a call that is the first of its kind -- every traversal of a time-stepping loop --
+// cannot afford a capture + instantiation per call (round 5: 1 %). But its class kernels ARE always the same four kernels: an
+// explicit graph of four independent kernel nodes is instantiated once per (device, kernels, classes present) and RE-TARGETED per
+// call -- hipGraphExecKernelNodeSetParams with the call's grid sizes and arguments costs nothing measurable
+// (tools/ubench/graph_setparams.hip: 2398 us per call re-targeted, 2400 replayed unchanged, 2640-2650 forked directly) -- and
+// launched into the call's stream behind the pre-pass, which was launched directly and hides the host time of all this.
+// Executables of graphs with parallel branches are never destroyed (see forked_cap()); a state that goes away parks its own for
+// the next state with the same kernels. They count towards RK_GRAPH_FORKED_MAX.
+std::mutex g_class_graph_mtx;
+std::vector<rk_state::class_graph> g_class_graph_pool;
+
+void park_class_graphs(rk_state &s)
+{
+    if (s.class_graphs.empty()) {
+        return;
+    }
+    // (the caller has synchronised the device: nothing of this state is in flight)
+    std::lock_guard<std::mutex> lk(g_class_graph_mtx);
+    for (auto &g : s.class_graphs) {
+        g_class_graph_pool.push_back(g);
+    }
+    s.class_graphs.clear();
+}
+
+// Launches the class kernels of the call (all classes with nodes; order R = 3, 4, 1, 2 as in launch_list()) through the state's
+// re-targeted graph. Returns false -- nothing launched -- when no executable is to be had (cap reached, runtime refuses).
+template <typename F>
+bool launch_classes_retargeted(rk_state &s, int q, const rk::kparams<F> &p, const int64_t cb[rk::n_classes], const int64_t ce[rk::n_classes],
+                               hipStream_t stream)
+{
+    static const int order[4] = {2, 3, 0, 1};
+    static_assert(RK_MAX_R == 4, "four class kernels");
+    const int pdev = phys(s.device);
+    rk_state::class_graph want;
+    want.pdev = pdev;
+    int n_nodes = 0;
+    rk::kparams<F> args_p[4];
+    const uint32_t *args_list[4];
+    int args_n[4];
+    const uint32_t *args_ndev[4];
+    void *kargs[4][4];
+    hipKernelNodeParams kp[4];
+    for (int k = 0; k < 4; ++k) {
+        const int c = order[k];
+        const int64_t n = ce[c] - cb[c];
+        if (n <= 0) {
+            continue;
+        }
+        want.mask |= 1u << c;
+        want.func[n_nodes] = rk::list_kernel_symbol<F>(s, q, c);
+        if (!want.func[n_nodes]) {
+            return false;
+        }
+        args_p[n_nodes] = p;
+        args_list[n_nodes] = s.cur_lists + s.cur_off[c] + cb[c];
+        args_n[n_nodes] = static_cast<int>(n);
+        args_ndev[n_nodes] = nullptr;
+        kargs[n_nodes][0] = &args_p[n_nodes], kargs[n_nodes][1] = &args_list[n_nodes], kargs[n_nodes][2] = &args_n[n_nodes],
+        kargs[n_nodes][3] = &args_ndev[n_nodes];
+        kp[n_nodes] = hipKernelNodeParams{};
+        kp[n_nodes].func = const_cast<void *>(want.func[n_nodes]);
+        kp[n_nodes].gridDim = dim3(static_cast<unsigned>(n));
+        kp[n_nodes].blockDim = dim3(64);
+        kp[n_nodes].sharedMemBytes = 0;
+        kp[n_nodes].kernelParams = kargs[n_nodes];
+        kp[n_nodes].extra = nullptr;
+        ++n_nodes;
+    }
+    if (n_nodes < 2) {
+        return false; // (a single class: a plain launch is the same thing)
+    }
+    const auto same = [&](const rk_state::class_graph &g) {
+        return g.pdev == pdev && g.mask == want.mask && std::equal(g.func, g.func + 4, want.func);
+    };
+    rk_state::class_graph *use = nullptr;
+    for (auto &g : s.class_graphs) {
+        if (same(g)) {
+            use = &g;
+        }
+    }
+    if (!use) {
+        {
+            std::lock_guard<std::mutex> lk(g_class_graph_mtx);
+            for (size_t i = 0; i < g_class_graph_pool.size() && !use; ++i) {
+                if (same(g_class_graph_pool[i])) {
+                    s.class_graphs.push_back(g_class_graph_pool[i]);
+                    g_class_graph_pool.erase(g_class_graph_pool.begin() + static_cast<std::ptrdiff_t>(i));
+                    use = &s.class_graphs.back();
+                }
+            }
+        }
+        if (!use) {
+            if (forked_cap() == 0 || g_forked_execs.load(std::memory_order_relaxed) >= forked_cap()) {
+                return false;
+            }
+            std::lock_guard<std::mutex> capture_lock(g_capture_mtx); // (graph construction stays out of other threads' captures)
+            if (hipGraphCreate(&want.graph, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                return false;
+            }
+            bool ok = true;
+            for (int k = 0; k < n_nodes && ok; ++k) {
+                ok = hipGraphAddKernelNode(&want.node[k], want.graph, nullptr, 0, &kp[k]) == hipSuccess;
+            }
+            ok = ok && hipGraphInstantiate(&want.exec, want.graph, nullptr, nullptr, 0) == hipSuccess;
+            if (!ok) {
+                (void)hipGetLastError();
+                (void)hipGraphDestroy(want.graph); // (never instantiated or never launched: safe to destroy)
+                return false;
+            }
+            g_forked_execs.fetch_add(1, std::memory_order_relaxed);
+            s.class_graphs.push_back(want);
+            use = &s.class_graphs.back();
+            RK_HIP(hipGraphLaunch(use->exec, stream));
+            return true;
+        }
+    }
+    for (int k = 0; k < n_nodes; ++k) {
+        if (hipGraphExecKernelNodeSetParams(use->exec, use->node[k], &kp[k]) != hipSuccess) {
+            // (Nothing was launched yet: the caller falls back to direct launches. The executable is given up -- parked, never
+            // destroyed -- since some of its nodes may carry this call's arguments and others the previous call's.)
+            (void)hipGetLastError();
+            std::lock_guard<std::mutex> lk(g_class_graph_mtx);
+            use->mask = 0xffu; // matches nothing
+            return false;
+        }
+    }
+    RK_HIP(hipGraphLaunch(use->exec, stream));
+    return true;
+}
+
 // Streams, events and the supergroup scratch a traversal call needs. Created with the state (so that the first call does not
 // pay for them: 166 MB of scratch at 4M) and checked again by every call (a rebuilt tree may have more critical nodes).
 template <typename F>
@@ -910,7 +1045,14 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
             for (int i = 0; i < rk::n_list_R; ++i) {
                 streams[i] = (serial || i == 0) ? st : s.aux_stream[i - 1];
             }
-            if (forked) {
+            // The class kernels of a call that is not being captured: through the state's re-targeted executable graph when there
+            // is one to be had (launch_classes_retargeted()), forked onto the side streams otherwise.
+            bool classes_done = false;
+            if (!capturing && forked && !split && any_mode == 0 && pc_mask == 0u && use_graph && allow_graph) {
+                classes_done = launch_classes_retargeted<F>(s, q, p, cb, ce, st);
+            }
+            const bool fork_now = forked && !classes_done;
+            if (fork_now) {
                 RK_HIP(hipEventRecord(s.ev_fork, st));
                 for (int i = 0; i < rk::n_list_R - 1; ++i) {
                     RK_HIP(hipStreamWaitEvent(s.aux_stream[i], s.ev_fork, 0));
@@ -947,7 +1089,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                 } else {
                     rk::launch_list_any<F>(s, q, p, pl + s.plan.off_all, s.plan.n_all, streams[0]);
                 }
-            } else {
+            } else if (!classes_done) {
                 if (pc_mask) {
                     rk::launch_pc<F>(s, q, p, cb, ce, streams, pc_mask);
                 }
@@ -955,7 +1097,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                     rk::launch_list<F>(s, q, p, cb, ce, streams, ~pc_mask);
                 }
             }
-            if (forked) {
+            if (fork_now) {
                 for (int i = 0; i < rk::n_list_R - 1; ++i) {
                     RK_HIP(hipEventRecord(s.ev_join[i], s.aux_stream[i]));
                     RK_HIP(hipStreamWaitEvent(st, s.ev_join[i], 0));

@@ -178,6 +178,7 @@ void free_state(rk_state *s)
     (void)hipGetDevice(&prev);
     (void)hipSetDevice(phys(s->device));
     release_tree(s);
+    park_class_graphs(*s);
     for (void *b : {s->d_out, s->sup_common, s->sup_resid, s->sup_cnt, s->z_scratch, s->sl_idx, s->sl_next,
                     s->sl_cnt, s->sl_ctl, s->sl_fb, s->sl_pbase, s->sl_part, s->first_order, s->first_tab}) {
         rk::pool_free(b);

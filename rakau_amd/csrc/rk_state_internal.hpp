@@ -104,6 +104,7 @@ void check_device(int device);
 // rk_launch.hip
 extern std::atomic<int> g_forked_execs;
 void drop_graph_exec(rk_state &s);
+void park_class_graphs(rk_state &s); // (a state that goes away hands its re-targetable class-kernel graphs to the next one)
 std::vector<void *> take_retired_plan_buffers();
 void ensure_call_resources_any(rk_state &s);
 void check_call(const rk_state *s, int q, void *const *out, double mac_value, double G, double eps2);
