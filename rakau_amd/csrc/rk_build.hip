@@ -1211,43 +1211,65 @@ static_assert(RK_MAX_R * 16 <= NKEY - 1);
 // thr[c] = the size at position floor(n_c / 4) of the ascending sizes of class c among a SAMPLE of the critical nodes -- every
 // tail_stride(n_crit)-th one, at most 8192: one block takes their sizes into an LDS histogram (no global atomics: thousands of nodes
 // share every common size, and same-address atomics cost the 4M rebuild 0.45 ms when every node made one), one thread per size
-// looks its class up, one thread per class finds the quartile. The result goes behind the queue table, first_tab[64 + c].
+// looks its class up, a prefix sum per class finds the quartile. The result goes behind the queue table, first_tab[64 + c].
 __host__ __device__ inline uint32_t tail_stride(uint32_t n_crit)
 {
     return n_crit / 8192u > 1u ? n_crit / 8192u : 1u;
 }
 __global__ void __launch_bounds__(1024) k_tail_thr(const uint4 *crit, uint32_t n_crit, uint32_t *first_tab)
 {
-    __shared__ uint32_t cnt[64 * RK_MAX_R + 1];
-    __shared__ uint8_t cls[64 * RK_MAX_R + 1];
-    for (unsigned sz = threadIdx.x; sz <= 64u * RK_MAX_R; sz += blockDim.x) {
+    constexpr unsigned NS = 64u * RK_MAX_R + 1u; // sizes 0 .. 256
+    __shared__ uint32_t cnt[NS];
+    __shared__ uint8_t cls[NS];
+    __shared__ uint32_t pre[2][NS];
+    for (unsigned sz = threadIdx.x; sz < NS; sz += blockDim.x) {
         cnt[sz] = 0u;
         cls[sz] = static_cast<uint8_t>(class2_of_compute(sz ? sz : 1u));
     }
     __syncthreads();
+    // The sample: nodes 0, stride, 2 stride, ... -- the first 8 192 of them, eight per thread, all loads of a thread in flight
+    // together -- into the LDS histogram. (The first form of this kernel, a strided loop with one load in flight per thread and a
+    // serial scan per class, took 20 us of a 4M rebuild: tools/jobs_r06/r06_job13.sh.)
     const uint32_t stride = tail_stride(n_crit);
-    for (uint32_t g = threadIdx.x * stride; g < n_crit; g += blockDim.x * stride) {
-        const uint32_t size = crit[g].w;
-        if (size >= 1u && size <= 64u * RK_MAX_R) {
-            atomicAdd(&cnt[size], 1u);
+    uint32_t mine[8];
+#pragma unroll
+    for (unsigned k = 0; k < 8u; ++k) {
+        const uint64_t g = (static_cast<uint64_t>(k) * blockDim.x + threadIdx.x) * stride;
+        mine[k] = g < n_crit ? crit[g].w : 0u;
+    }
+#pragma unroll
+    for (unsigned k = 0; k < 8u; ++k) {
+        if (mine[k] >= 1u && mine[k] < NS) {
+            atomicAdd(&cnt[mine[k]], 1u);
         }
     }
     __syncthreads();
-    if (threadIdx.x < RK_MAX_R) {
-        const unsigned c = threadIdx.x;
-        uint32_t n_c = 0u;
-        for (uint32_t sz = 1u; sz <= 64u * RK_MAX_R; ++sz) {
-            n_c += cls[sz] == c ? cnt[sz] : 0u;
+    // Per class: inclusive prefix sums of the class's counts over the sizes (Hillis-Steele in LDS), then the size at which the
+    // prefix first exceeds floor(n_c / 4).
+    for (unsigned c = 0; c < static_cast<unsigned>(RK_MAX_R); ++c) {
+        unsigned cur = 0u;
+        for (unsigned sz = threadIdx.x; sz < NS; sz += blockDim.x) {
+            pre[0][sz] = cls[sz] == c ? cnt[sz] : 0u;
         }
+        __syncthreads();
+        for (unsigned d = 1u; d < NS; d <<= 1) {
+            for (unsigned sz = threadIdx.x; sz < NS; sz += blockDim.x) {
+                pre[cur ^ 1u][sz] = pre[cur][sz] + (sz >= d ? pre[cur][sz - d] : 0u);
+            }
+            cur ^= 1u;
+            __syncthreads();
+        }
+        const uint32_t n_c = pre[cur][NS - 1u];
         const uint32_t k = n_c ? (n_c / 4u < n_c - 1u ? n_c / 4u : n_c - 1u) : 0u;
-        uint32_t cum = 0u, t = 0u;
-        for (uint32_t sz = 1u; sz <= 64u * RK_MAX_R && t == 0u; ++sz) {
-            cum += cls[sz] == c ? cnt[sz] : 0u;
-            if (cum > k) {
-                t = sz;
+        for (unsigned sz = threadIdx.x; sz < NS; sz += blockDim.x) {
+            if (sz >= 1u && n_c && pre[cur][sz] > k && pre[cur][sz - 1u] <= k) {
+                first_tab[64u + c] = sz;
             }
         }
-        first_tab[64u + c] = t;
+        if (threadIdx.x == 0u && n_c == 0u) {
+            first_tab[64u + c] = 0u;
+        }
+        __syncthreads();
     }
 }
 

@@ -358,9 +358,9 @@ def test_first_call_launch_order_made_on_the_device(n, ncrit):
             cls = np.array([class2_of(int(v)) for v in size[wave]])
             region = np.minimum(7, cr[wave, 0].astype(np.int64) * 8 // n)
             pos = 0
-            # the size from which a node of class c is bulk: the first quartile of the class's sizes among every stride-th critical node
+            # the size from which a node of class c is bulk: the first quartile of the class's sizes among the first 8192 of every stride-th critical node
             stride = max(1, len(cr) // 8192)
-            s_size = size[::stride]
+            s_size = size[::stride][:8192]
             s_size = s_size[(s_size >= 1) & (s_size <= 256)]
             s_cls = np.array([class2_of(int(v)) for v in s_size])
             for c in range(4):
