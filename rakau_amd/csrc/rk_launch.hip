@@ -988,7 +988,7 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
         // nodes from its per-region queues -- every traversal of a time-stepping loop on 2M-8M particles is such a call.
         // Measured against what such calls ran before (examples/leapfrog, traversal ms, tools/jobs_r06/r06_job5.sh): 1.9M particles
         // (51k nodes; one launch over the class lists read backwards) 0.986 -> 0.973, 2.2M (60k) 1.13 -> 1.08, 3M (class kernels,
-        // one Morton slice per XCD) 1.48 -> 1.42, 4M 1.92 -> 1.85, 6M 2.88 -> 2.80; the rebuild pays 20-30 us for it.
+        // one Morton slice per XCD) 1.48 -> 1.42, 4M 1.92 -> 1.85, 6M 2.88 -> 2.80; the rebuild pays 10-15 us for it.
         if (s.cur_lists == static_cast<const uint32_t *>(s.buf[RK_BUF_CLASS]) && s.first_tail_valid && s.first_order && s.first_tab
             && s.variant == 0 && any_mode == 0 && !split && pc_mask == 0u && g_lo == 0 && g_hi == s.n_crit) {
             s.cur_lists = static_cast<const uint32_t *>(s.first_order);
