@@ -381,3 +381,35 @@ def test_first_call_launch_order_made_on_the_device(n, ncrit):
         b = st.acc_pot(0, mv)
         c = st.acc_pot(0, mv)
         assert all(np.array_equal(u, v) and np.array_equal(u, w) for u, v, w in zip(a, b, c))
+
+
+def test_first_call_light_tail_arrangement_fp64_and_quadtree():
+    """The light-tail arrangement of first calls (trees of 49152-250000 critical nodes) through the fp64 kernels and the 2-D kernels:
+    the first call (class kernels over the device-made queues, re-targeted executable graph) gives the bits of the repeated calls
+    (host-made plan, captured graph), and the table tiles the wave-kernel nodes."""
+    import torch
+    for dtype, ndim, n in ((np.float64, 3, 2_300_000), (np.float32, 2, 2_300_000)):
+        if ndim == 3:
+            m, x, y, z = oracle.plummer(n, dtype)
+            st = rakau_amd.State.build(x, y, z, m)
+        else:
+            m, x, y = oracle.Rng(7).uniform_particles(n, 3.0, dtype, ndim=2)
+            st = rakau_amd.State.build(x, y, None, m)
+        assert 49152 < st.n_crit <= 250000, st.n_crit
+        ptr, nbytes = st.device_ptr("first_tab")
+        assert nbytes == 4 * 72 and ptr != 0
+        d_tab = torch.zeros(72, dtype=torch.int32, device="cuda")
+        rakau_amd._capi.check(rakau_amd._capi.lib().rk_device_memcpy(d_tab.data_ptr(), ptr, nbytes, 0))
+        torch.cuda.synchronize()
+        tab = d_tab.cpu().numpy().astype(np.int64)
+        cr = st.crit_ranges()
+        n_wave = int(np.count_nonzero((cr[:, 1] - cr[:, 0]) <= 256))
+        starts = np.array([tab[c * 16 + xr] for c in range(4) for xr in range(8)])
+        lens = np.array([tab[c * 16 + 8 + xr] for c in range(4) for xr in range(8)])
+        assert starts[0] == 0 and np.array_equal(starts[1:], np.cumsum(lens)[:-1]) and lens.sum() == n_wave
+        mv = rakau_amd.mac_value_of(0.75, "bh", dtype)
+        a = st.acc_pot(2, mv, eps2=1e-6)
+        b = st.acc_pot(2, mv, eps2=1e-6)
+        c = st.acc_pot(2, mv, eps2=1e-6)
+        assert all(np.array_equal(u, v) and np.array_equal(u, w) for u, v, w in zip(a, b, c))
+        st.close()
