@@ -333,7 +333,9 @@ struct rk_state {
         int64_t off[rk::n_classes + 1] = {};
         // Heavy-first plans also carry merged lists for the one-launch kernels (k_pc_any / k_list_any): the wave-kernel
         // classes together, and without the R = 2 class (which then keeps its own producer / consumer launch).
-        int64_t off_all = 0, n_all = 0, off_oth = 0, n_oth = 0, off_123 = 0, n_123 = 0;
+        int64_t off_all = 0, n_all = 0, off_oth = 0, n_oth = 0;
+        int64_t off_reg = 0, n_reg = 0; // all classes as eight heavy-first queues, one per XCD region, interleaved and padded: what
+                                        // the one-launch kernels run over (off_all: the same nodes as one sorted list)
     } plan;
     std::vector<launch_plan> gcache_plan; // gcache_plan[i]: the plan gcache[i] was captured with (d_lists null: none)
     std::vector<launch_plan> plans;       // the last few plans built (most recent last): a caller alternating among ranges --
@@ -420,8 +422,7 @@ template <typename F>
 const void *list_kernel_symbol(const rk_state &s, int q, int c);
 // One launch over critical nodes of any lane-mapping class (small calls): the list kernel, the producer / consumer kernel.
 template <typename F>
-void launch_list_any(const rk_state &s, int q, const kparams<F> &p, const uint32_t *list, int64_t n, hipStream_t stream,
-                     int rmax = 4);
+void launch_list_any(const rk_state &s, int q, const kparams<F> &p, const uint32_t *list, int64_t n, hipStream_t stream);
 template <typename F>
 void launch_pc_any(const rk_state &s, int q, const kparams<F> &p, const uint32_t *list, int64_t n, hipStream_t stream);
 // n_dev (optional): the number of list entries lives in device memory (at most n).

@@ -662,8 +662,8 @@ __global__ void __launch_bounds__(64 * (BIG ? LK_BIG_WPB : RK_WPB), BIG ? (sizeo
 // would otherwise start 25-45 us apart and leave the device to drain over the class launched last): every wavefront
 // picks the R of its node and runs the same list_node<..., R> the class kernels run. Compiled for the registers of the
 // largest R; the launch is too small to fill the device anyway.
-template <typename F, int Q, int MAC, int ND, int RMAX = 4>
-__global__ void __launch_bounds__(64, sizeof(F) == 4 ? (RMAX >= 4 ? RK_WANY : RK_W3) : RK_W64_ANY) k_list_any(const kparams<F> P, const uint32_t *__restrict__ list, int n_list)
+template <typename F, int Q, int MAC, int ND>
+__global__ void __launch_bounds__(64, sizeof(F) == 4 ? RK_WANY : RK_W64_ANY) k_list_any(const kparams<F> P, const uint32_t *__restrict__ list, int n_list)
 {
     __shared__ lk_wave_lds<F> s_lds;
     const int lane = threadIdx.x;
@@ -680,11 +680,7 @@ __global__ void __launch_bounds__(64, sizeof(F) == 4 ? (RMAX >= 4 ? RK_WANY : RK
         case 0: list_node<F, Q, MAC, 1, ND, false>(P, s_lds, g, lane, 0); break;
         case 1: list_node<F, Q, MAC, 2, ND, false>(P, s_lds, g, lane, 0); break;
         case 2: list_node<F, Q, MAC, 3, ND, false>(P, s_lds, g, lane, 0); break;
-        case 3:
-            if constexpr (RMAX >= 4) {
-                list_node<F, Q, MAC, 4, ND, false>(P, s_lds, g, lane, 0);
-            }
-            break;
+        case 3: list_node<F, Q, MAC, 4, ND, false>(P, s_lds, g, lane, 0); break;
         default: break; // oversized nodes are not on this list
     }
 }
@@ -939,7 +935,7 @@ template const void *list_kernel_symbol<double>(const rk_state &, int, int);
 
 // One launch over a list of critical nodes of any lane-mapping class (k_list_any).
 template <typename F>
-void launch_list_any(const rk_state &s, int q, const kparams<F> &p, const uint32_t *list, int64_t n, hipStream_t stream, int rmax)
+void launch_list_any(const rk_state &s, int q, const kparams<F> &p, const uint32_t *list, int64_t n, hipStream_t stream)
 {
     if (n <= 0) {
         return;
@@ -949,23 +945,9 @@ void launch_list_any(const rk_state &s, int q, const kparams<F> &p, const uint32
     auto go = [&](auto Qt, auto Mt) {
         constexpr int Q = decltype(Qt)::value, M = mac_targ(decltype(Mt)::value);
         if (s.ndim == 3 || !RK_QUAD_BODY) {
-            if (rmax >= 4) {
-                hipLaunchKernelGGL((k_list_any<F, Q, M, 3, 4>), grid, block, 0, stream, p, list, cnt);
-            } else {
-#ifdef RK_ANY_RMAX3
-                hipLaunchKernelGGL((k_list_any<F, Q, M, 3, 3>), grid, block, 0, stream, p, list, cnt);
-#else
-                throw error(RK_EINVAL, "k_list_any for R <= 3 (RK_ANY=4, an experiment of round 3) is only in builds with -DRK_ANY_RMAX3");
-#endif
-            }
-        } else if (rmax >= 4) {
-            hipLaunchKernelGGL((k_list_any<F, Q, M, 2, 4>), grid, block, 0, stream, p, list, cnt);
+            hipLaunchKernelGGL((k_list_any<F, Q, M, 3>), grid, block, 0, stream, p, list, cnt);
         } else {
-#ifdef RK_ANY_RMAX3
-            hipLaunchKernelGGL((k_list_any<F, Q, M, 2, 3>), grid, block, 0, stream, p, list, cnt);
-#else
-            throw error(RK_EINVAL, "k_list_any for R <= 3 (RK_ANY=4, an experiment of round 3) is only in builds with -DRK_ANY_RMAX3");
-#endif
+            hipLaunchKernelGGL((k_list_any<F, Q, M, 2>), grid, block, 0, stream, p, list, cnt);
         }
     };
     using i0 = std::integral_constant<int, 0>;
@@ -984,9 +966,9 @@ void launch_list_any(const rk_state &s, int q, const kparams<F> &p, const uint32
     }
     RK_HIP(hipGetLastError());
 }
-template void launch_list_any<float>(const rk_state &, int, const kparams<float> &, const uint32_t *, int64_t, hipStream_t, int);
+template void launch_list_any<float>(const rk_state &, int, const kparams<float> &, const uint32_t *, int64_t, hipStream_t);
 #ifndef RK_SLIM
-template void launch_list_any<double>(const rk_state &, int, const kparams<double> &, const uint32_t *, int64_t, hipStream_t, int);
+template void launch_list_any<double>(const rk_state &, int, const kparams<double> &, const uint32_t *, int64_t, hipStream_t);
 #endif
 
 // Critical nodes of more than 64 * RK_MAX_R particles: k_list<..., BIG> (one workgroup per node).

@@ -332,14 +332,14 @@ void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64
         }
     }
     s.plan.off[rk::n_classes] = static_cast<int64_t>(lists.size());
-    s.plan.off_all = s.plan.n_all = s.plan.off_oth = s.plan.n_oth = s.plan.off_123 = s.plan.n_123 = 0;
+    s.plan.off_all = s.plan.n_all = s.plan.off_oth = s.plan.n_oth = s.plan.off_reg = s.plan.n_reg = 0;
     if (lpt) {
         // Merged heavy-first lists over the wave-kernel classes (stable: equal weights keep class, then Morton order): all
-        // of them, all but R = 2, all but R = 4.
-        for (int pass = 0; pass < 3; ++pass) {
+        // of them, all but R = 2.
+        for (int pass = 0; pass < 2; ++pass) {
             const auto first = static_cast<std::ptrdiff_t>(lists.size());
             for (int c = 0; c < RK_MAX_R; ++c) {
-                if ((pass == 1 && c == 1) || (pass == 2 && c == 3)) {
+                if (pass == 1 && c == 1) {
                     continue;
                 }
                 // (copied first: inserting a range of a vector into itself is undefined once it reallocates)
@@ -348,8 +348,37 @@ void build_plan(rk_state &s, int64_t p_begin, int64_t p_end, int64_t g_lo, int64
             }
             std::stable_sort(lists.begin() + first, lists.end(),
                              [&](uint32_t a, uint32_t b2) { return s.work_cache[a] > s.work_cache[b2]; });
-            (pass == 0 ? s.plan.off_all : (pass == 1 ? s.plan.off_oth : s.plan.off_123)) = first;
-            (pass == 0 ? s.plan.n_all : (pass == 1 ? s.plan.n_oth : s.plan.n_123)) = static_cast<int64_t>(lists.size()) - first;
+            (pass == 0 ? s.plan.off_all : s.plan.off_oth) = first;
+            (pass == 0 ? s.plan.n_all : s.plan.n_oth) = static_cast<int64_t>(lists.size()) - first;
+        }
+        {
+            // The merged heavy-first list again as EIGHT QUEUES, one per XCD: the nodes of one eighth of the range's particles,
+            // heavy-first inside the queue; entry i of the list is served by block i, i.e. by XCD i % 8 (shorter queues padded with
+            // entries the kernels skip). This is what the one-launch kernels run over (round 6): dealt in chunks of 16 consecutive
+            // entries of the ONE sorted list -- nodes of like size from anywhere in the range -- every XCD's L2 saw the leaves and
+            // lower tree of the whole range; now it sees an eighth. Kernel ms, chunks -> queues (tools/jobs_r06/r06_job19.sh, _job20):
+            // k_pc_any 100k 0.098 -> 0.095, 150k 0.133 -> 0.127, 200k 0.169 -> 0.164; k_list_any 250k 0.216 -> 0.209, 350k 0.228 ->
+            // 0.220, 500k 0.315 -> 0.302, 1M 0.592 -> 0.580, 1.5M 0.853 -> 0.839; fp64 500k 0.554 -> 0.543, 1M 1.134 -> 1.114; the
+            // 0.5M-particle shards of the 4M tree equal (0.310-0.324 / 0.313-0.330). Same nodes, same bits.
+            const std::vector<uint32_t> all(lists.begin() + s.plan.off_all, lists.begin() + s.plan.off_all + s.plan.n_all);
+            std::vector<uint32_t> q[8];
+            const double span = static_cast<double>(p_end - p_begin);
+            for (uint32_t g : all) {
+                const double rel = static_cast<double>(s.crit_begin[g] - p_begin) / span;
+                q[std::min(7, std::max(0, static_cast<int>(rel * 8.)))].push_back(g);
+            }
+            size_t longest = 0;
+            for (const auto &v : q) {
+                longest = std::max(longest, v.size());
+            }
+            const auto first = static_cast<std::ptrdiff_t>(lists.size());
+            for (size_t pos = 0; pos < longest; ++pos) {
+                for (const auto &v : q) {
+                    lists.push_back(pos < v.size() ? v[pos] : rk::RK_PLAN_PAD_VALUE);
+                }
+            }
+            s.plan.off_reg = first;
+            s.plan.n_reg = static_cast<int64_t>(lists.size()) - first;
         }
     }
     // The list buffer: always a fresh one (the block cache makes that cheap), so that nothing in flight -- an earlier call on any
@@ -1077,17 +1106,16 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                         rk::launch_list_any<F>(s, q, p, first_list, first_n, streams[0]);
                     }
                 } else if (any_mode == 1) {
-                    rk::launch_pc_any<F>(s, q, p, pl + s.plan.off_all, s.plan.n_all, streams[0]);
+                    auto pr = p;
+                    pr.xcd_mode = 2; // (the per-XCD queues of the plan: block i serves entry i)
+                    rk::launch_pc_any<F>(s, q, pr, pl + s.plan.off_reg, s.plan.n_reg, streams[0]);
                 } else if (any_mode == 2) {
                     rk::launch_pc<F>(s, q, p, cb, ce, streams, 0x2u);
                     rk::launch_list_any<F>(s, q, p, pl + s.plan.off_oth, s.plan.n_oth, streams[0]);
-                } else if (any_mode == 4) {
-                    // The R = 4 class on its own kernel (first: its nodes are the longest), the rest on a k_list_any compiled for
-                    // the registers of R = 3.
-                    rk::launch_list<F>(s, q, p, cb, ce, streams, 0x8u);
-                    rk::launch_list_any<F>(s, q, p, pl + s.plan.off_123, s.plan.n_123, streams[0], 3);
                 } else {
-                    rk::launch_list_any<F>(s, q, p, pl + s.plan.off_all, s.plan.n_all, streams[0]);
+                    auto pr = p;
+                    pr.xcd_mode = 2;
+                    rk::launch_list_any<F>(s, q, pr, pl + s.plan.off_reg, s.plan.n_reg, streams[0]);
                 }
             } else if (!classes_done) {
                 if (pc_mask) {
