@@ -284,10 +284,12 @@ RK_EXPORT int rk_state_set_perm(rk_state *s, const uint64_t *perm);
 
 /* Device address and size of a resident array: 0 = particles {x, y, z, m} in Morton order, 1 = perm (uint32),
  * 2 = sorted Morton codes (uint64). For callers that keep their own data on the GPU (gather / scatter).
- * 3 (diagnostic) = the launch order of the first call on the tree, critical-node indices as uint32: by decreasing size for trees
- * of at most 49152 critical nodes, the per-class / per-region queues of the light-tail arrangement up to 250000 (0 bytes beyond);
- * 4 (diagnostic) = the table of that arrangement (72 uint32: per class c and region x the start [16 c + x] and length [16 c + 8 + x]
- * of the queue, [64 + c] = the size from which a node of class c counts as bulk; 0 bytes for other trees). */
+ * 3 (diagnostic) = the launch order of the first call on the tree, critical-node indices as uint32: eight per-region queues, nodes by
+ * decreasing size inside, for trees of at most 49152 critical nodes; the per-class / per-region queues of the light-tail arrangement
+ * up to 250000 (0 bytes beyond);
+ * 4 (diagnostic) = the table of those queues (72 uint32. Small trees: start [x] and length [8 + x] of the queue of region x. Large
+ * ones: per class c and region x the start [16 c + x] and length [16 c + 8 + x], [64 + c] = the size from which a node of class c
+ * counts as bulk; 0 bytes for trees without such an order). */
 RK_EXPORT int rk_state_device_ptr(const rk_state *s, int what, void **ptr, int64_t *bytes);
 
 /* *box_size = domain size; info[0..3] = box deduced, max_leaf_n, built on device (0/1), number of internal nodes. */

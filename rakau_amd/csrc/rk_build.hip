@@ -1173,22 +1173,29 @@ __global__ void k_records(uint4 *topo, const uint64_t *ncode, const uint32_t *pa
 constexpr unsigned NBIN = 8;
 static_assert(NBIN >= static_cast<unsigned>(n_classes));
 
-// Launch order of the FIRST call on a small tree (at most FIRST_ORDER_MAX critical nodes): the critical nodes of the wave
-// kernels' classes sorted by decreasing size, ties in Morton order -- the order of the heavy-first launch plan that repeated
-// calls get from the host (rk_launch.hip build_plan), made here so that a time-stepping loop, whose every traversal is a first
-// call, has it too (100k particles, one-launch producer / consumer kernel: 0.144 ms over the class lists read backwards, 0.101
-// over the sorted list). Keys for a stable radix sort over eight bits (one pass): sizes in steps of two, 0 = the largest a
-// wavefront serves; oversized nodes (their own kernel) get the last key and fall off the end of the list.
+// Launch order of the FIRST call on a small tree (at most FIRST_ORDER_MAX critical nodes): what the heavy-first launch plan of
+// rk_launch.hip build_plan gives repeated calls, made here so that a time-stepping loop, whose every traversal is a first call, has
+// it too (100k particles, one-launch producer / consumer kernel: 0.144 ms over the class lists read backwards, 0.101 over a sorted
+// list) -- EIGHT QUEUES, one per XCD region (eighths of the particle range; the critical nodes tile it, so a node's region follows
+// from its first particle), the critical nodes of the wave kernels' classes inside a queue by decreasing size, ties in Morton order.
+// Keys of a stable partition over eight bits: (region, size in steps of eight: 0 = the largest a wavefront serves, the sizes below
+// sixteen together); oversized nodes (their own kernel) get the last key and fall off the end of the list. (Rounds 4-5 and the
+// first half of round 6: one list, sizes in steps of two.)
 constexpr unsigned FIRST_ORDER_KEY_BITS = 8;
-static_assert(((64 * RK_MAX_R) >> 1) < (1 << FIRST_ORDER_KEY_BITS) - 1);
+static_assert(64 * RK_MAX_R == 256, "first_key(): 31 size buckets of eight");
 // The three kernels below also make the first-call launch order of small trees when they are handed key_hist / first_order: the same
 // stable partition over the 256 keys of first_key() -- per-block histograms, a scan per key over the blocks, a scatter that ranks
 // every node among the equal keys of its block (wavefront: the lanes with the same key from eight ballots; block: counts per wave
 // in LDS). Rounds 4-5 sorted (key, index) pairs with the library afterwards: 4-8 launches of ~5 us each on a 100k-particle tree.
 constexpr unsigned NKEY = 1u << FIRST_ORDER_KEY_BITS;
-__device__ inline uint32_t first_key(uint32_t size)
+__host__ __device__ inline uint32_t first_key(uint32_t size, uint32_t begin, uint32_t nparts)
 {
-    return (size == 0u || size > 64u * RK_MAX_R) ? NKEY - 1u : (64u * RK_MAX_R - size) >> 1;
+    if (size == 0u || size > 64u * RK_MAX_R) {
+        return NKEY - 1u;
+    }
+    const uint64_t x8 = static_cast<uint64_t>(begin) * 8u / nparts;
+    const uint32_t bucket = (64u * RK_MAX_R - size) >> 3;
+    return static_cast<uint32_t>(x8 < 7u ? x8 : 7u) * 32u + (bucket < 30u ? bucket : 30u);
 }
 
 // Trees of FIRST_ORDER_MAX .. FIRST_TAIL_MAX critical nodes get the LIGHT-TAIL arrangement for their first call instead -- what the
@@ -1273,9 +1280,9 @@ __global__ void __launch_bounds__(1024) k_tail_thr(const uint4 *crit, uint32_t n
     }
 }
 
-// tail != 0 (= the number of particles): the keys of the light-tail arrangement instead of those of the heavy-first order.
+// tail != 0: the keys of the light-tail arrangement instead of those of the heavy-first order. nparts: the number of particles.
 __global__ void __launch_bounds__(256) k_bin_count(const uint4 *crit, uint32_t n_crit, uint32_t *block_hist, ctrl_block *ctrl,
-                                                   uint32_t *key_hist, uint32_t tail, const uint32_t *first_tab)
+                                                   uint32_t *key_hist, uint32_t nparts, uint32_t tail, const uint32_t *first_tab)
 {
     __shared__ uint32_t h[NBIN];
     __shared__ uint32_t hk[NKEY];
@@ -1304,7 +1311,7 @@ __global__ void __launch_bounds__(256) k_bin_count(const uint4 *crit, uint32_t n
         atomicAdd(&h[c], 1u);
         atomicMax(&mx, size);
         if (key_hist) {
-            atomicAdd(&hk[tail ? tail_key(size, c, c4.x, tail, thr) : first_key(size)], 1u);
+            atomicAdd(&hk[tail ? tail_key(size, c, c4.x, nparts, thr) : first_key(size, c4.x, nparts)], 1u);
         }
     }
     __syncthreads();
@@ -1362,7 +1369,8 @@ __global__ void __launch_bounds__(256) k_bin_scan(uint32_t *block_hist, uint32_t
 
 __global__ void __launch_bounds__(256) k_bin_scatter(const uint4 *crit, uint32_t n_crit, const uint32_t *block_base,
                                                      ctrl_block *ctrl, uint32_t *lists, const uint32_t *key_base,
-                                                     const uint32_t *key_total, uint32_t *first_order, uint32_t tail, uint32_t *first_tab)
+                                                     const uint32_t *key_total, uint32_t *first_order, uint32_t nparts, uint32_t tail,
+                                                     uint32_t *first_tab)
 {
     __shared__ uint32_t wave_cnt[4][NBIN];
     __shared__ uint32_t wave_key[4][NKEY];
@@ -1406,7 +1414,25 @@ __global__ void __launch_bounds__(256) k_bin_scatter(const uint4 *crit, uint32_t
             key_off[threadIdx.x] += v;
             __syncthreads();
         }
-        key = tail ? tail_key(size, c, c4.x, tail, thr) : first_key(size);
+        key = tail ? tail_key(size, c, c4.x, nparts, thr) : first_key(size, c4.x, nparts);
+        if (!tail && blockIdx.x == 0u) {
+            // Heavy-first order: the table of the eight queues (starts [x], lengths [8 + x]) the one-launch kernels read
+            // (rk_list_common.hpp any_list_entry()) and the grid of their launch, 8 x the longest queue.
+            if (threadIdx.x < 8u) {
+                const unsigned k0 = threadIdx.x * 32u;
+                const uint32_t start = key_off[k0] - key_total[k0];
+                first_tab[threadIdx.x] = start;
+                first_tab[8u + threadIdx.x] = key_off[k0 + 30u] - start;
+            }
+            if (threadIdx.x == 0u) {
+                uint32_t longest = 0u;
+                for (unsigned x = 0; x < 8u; ++x) {
+                    longest = max(longest, key_off[x * 32u + 30u] - (key_off[x * 32u] - key_total[x * 32u]));
+                }
+                ctrl->first_grid[0] = 8u * longest;
+                ctrl->first_grid[1] = ctrl->first_grid[2] = ctrl->first_grid[3] = 0u;
+            }
+        }
         if (tail && blockIdx.x == 0u) {
             // The table the class kernels read (rk_common.hpp FIRST_TAB_WORDS) and the grids of their launches.
             if (threadIdx.x < RK_MAX_R * 8u) {
@@ -1668,7 +1694,7 @@ static bin_tmp bin_classes(rk_state &s, const uint4 *crit, uint32_t n_crit, uint
     bin_tmp t;
     const unsigned nb = nblk(n_crit);
     t.hist = dalloc<uint32_t>(static_cast<size_t>(nb) * NBIN);
-    const bool want_first = first_order_enabled() && n_crit <= FIRST_ORDER_MAX;
+    const bool want_first = first_order_enabled() && n_crit <= FIRST_ORDER_MAX && nparts > 0u;
     const bool want_tail = want_first_tail(n_crit, nparts);
     uint32_t *key_total = nullptr, *first_order = nullptr;
     if (want_first || want_tail) {
@@ -1684,19 +1710,19 @@ static bin_tmp bin_classes(rk_state &s, const uint4 *crit, uint32_t n_crit, uint
         t.key_hist = dalloc<uint32_t>(static_cast<size_t>(nb) * NKEY + NKEY);
         key_total = t.key_hist.get() + static_cast<size_t>(nb) * NKEY;
     }
+    if ((want_first || want_tail) && !s.first_tab) {
+        s.first_tab = pool_alloc(FIRST_TAB_WORDS * sizeof(uint32_t));
+    }
     if (want_tail) {
-        if (!s.first_tab) {
-            s.first_tab = pool_alloc(FIRST_TAB_WORDS * sizeof(uint32_t));
-        }
         hipLaunchKernelGGL(k_tail_thr, dim3(1), dim3(1024), 0, st, crit, n_crit, static_cast<uint32_t *>(s.first_tab));
     }
-    const uint32_t tail = want_tail ? nparts : 0u;
-    hipLaunchKernelGGL(k_bin_count, dim3(nb), dim3(256), 0, st, crit, n_crit, t.hist.get(), ctrl, t.key_hist.get(), tail,
+    const uint32_t tail = want_tail ? 1u : 0u;
+    hipLaunchKernelGGL(k_bin_count, dim3(nb), dim3(256), 0, st, crit, n_crit, t.hist.get(), ctrl, t.key_hist.get(), nparts, tail,
                        static_cast<const uint32_t *>(s.first_tab));
     hipLaunchKernelGGL(k_bin_scan, dim3(NBIN + (first_order ? NKEY : 0u)), dim3(256), 0, st, t.hist.get(), nb, ctrl, t.key_hist.get(),
                        key_total);
     hipLaunchKernelGGL(k_bin_scatter, dim3(nb), dim3(256), 0, st, crit, n_crit, t.hist.get(), ctrl, lists, t.key_hist.get(), key_total,
-                       first_order, tail, static_cast<uint32_t *>(s.first_tab));
+                       first_order, nparts, tail, static_cast<uint32_t *>(s.first_tab));
     s.first_order_valid = want_first;
     s.first_tail_valid = want_tail;
     return t;
@@ -1704,7 +1730,7 @@ static bin_tmp bin_classes(rk_state &s, const uint4 *crit, uint32_t n_crit, uint
 static void take_first_grid(rk_state &s, const bld::ctrl_block &hc)
 {
     for (int c = 0; c < 4; ++c) {
-        s.first_grid[c] = s.first_tail_valid ? hc.first_grid[c] : 0u;
+        s.first_grid[c] = (s.first_tail_valid || s.first_order_valid) ? hc.first_grid[c] : 0u;
     }
 }
 

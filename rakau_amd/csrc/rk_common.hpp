@@ -181,8 +181,9 @@ struct kparams {
     const uint32_t *perm; // non-null: original-order output, results of Morton particle i go to out[perm[i]]
     unsigned long long *dbg; // diagnostic builds only (RK_STAMPS): per-section cycle totals
     int mac;                 // RK_MAC_BH | RK_MAC_BH_GEOM (the list kernels read it at run time: one code object for both)
-    int xcd_mode;            // block -> group-list mapping (see xcd_map_block); 3: the queues of first_tab (class kernels only)
-    const uint32_t *first_tab; // xcd_mode 3: queue starts / lengths per (class, XCD region), see rk_state::first_tab
+    int xcd_mode;            // block -> group-list mapping (see xcd_map_block); 3: the queues of first_tab per (class, XCD region), class
+                             // kernels; 4: its eight queues per XCD region, one-launch kernels
+    const uint32_t *first_tab; // xcd_mode 3 / 4: queue starts and lengths, see rk_state::first_tab
     int any_rev;             // one-launch kernels: block i serves list entry n - 1 - i (class lists read backwards: R = 4 first)
     // Supergroup pre-pass (k_super): K consecutive target groups share the upper part of list building.
     // super_k == 0 disables it. Per supergroup S: sup_common[S * SUP_CAPC ...] = sources {x, y, z, m} accepted for every

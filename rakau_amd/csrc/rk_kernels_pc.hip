@@ -709,7 +709,11 @@ __global__ void __launch_bounds__(64 * (1 + RK_PC_NCONS), (sizeof(F) == 4 ? RK_P
     if (static_cast<int>(blk) >= n_list) {
         return;
     }
-    const uint32_t g = __builtin_amdgcn_readfirstlane(list[P.any_rev ? static_cast<unsigned>(n_list) - 1u - blk : blk]);
+    unsigned entry = 0u;
+    if (!any_list_entry(P, blk, n_list, entry)) {
+        return;
+    }
+    const uint32_t g = __builtin_amdgcn_readfirstlane(list[entry]);
     if (g == RK_PLAN_PAD_VALUE) {
         return;
     }

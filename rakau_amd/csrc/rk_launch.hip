@@ -1051,11 +1051,14 @@ void run_impl(rk_state &s, int q, int64_t p_begin, int64_t p_end, void *const *d
                 any_mode = (any_env == 1 || any_env == 3) ? any_env : (g_hi <= pc_any_below_nodes(sizeof(F) == 8) ? 1 : 3);
                 p.any_rev = 1;
                 p.xcd_mode = 0; // chunks of consecutive entries dealt round-robin to the XCDs, as for a heavy-first plan
-                if (s.first_order_valid && s.first_order) {
-                    // A small tree built (or converted) on the device comes with the order of a heavy-first plan, nodes by
-                    // decreasing size (rk_build.hip k_first_order): 100k particles 0.144 -> 0.10 ms on k_pc_any.
+                if (s.first_order_valid && s.first_order && s.first_tab) {
+                    // A small tree built (or converted) on the device comes with the order of a heavy-first plan -- eight per-XCD
+                    // queues, nodes by decreasing size inside (rk_build.hip first_key()): 100k particles 0.144 -> 0.10 ms on k_pc_any.
                     first_list = static_cast<const uint32_t *>(s.first_order);
+                    first_n = static_cast<int64_t>(s.first_grid[0]);
                     p.any_rev = 0;
+                    p.xcd_mode = 4; // (the queue table: rk_list_common.hpp any_list_entry())
+                    p.first_tab = static_cast<const uint32_t *>(s.first_tab);
                 }
             }
         }

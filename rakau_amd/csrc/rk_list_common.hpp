@@ -216,6 +216,24 @@ __device__ __forceinline__ unsigned xcd_map_block(unsigned b, unsigned nb, int m
     return (pos / XCD_CHUNK * 8u + xcd) * XCD_CHUNK + pos % XCD_CHUNK;
 }
 
+// One-launch kernels, xcd_mode 4: the list is eight queues (one per XCD region) behind a table of their starts [x] and lengths
+// [8 + x] -- the launch order of a first call made on the device with the tree (rk_build.hip bin_classes). Block i serves entry
+// i / 8 of queue i % 8; returns false for a block past the end of its queue.
+template <typename F>
+__device__ __forceinline__ bool any_list_entry(const kparams<F> &P, unsigned blk, int n_list, unsigned &entry)
+{
+    if (P.xcd_mode == 4) {
+        const uint32_t x = blk & 7u, pos = blk >> 3;
+        if (pos >= P.first_tab[8u + x]) {
+            return false;
+        }
+        entry = P.first_tab[x] + pos;
+        return true;
+    }
+    entry = P.any_rev ? static_cast<unsigned>(n_list) - 1u - blk : blk;
+    return true;
+}
+
 template <typename F, int Q, int R, bool SELF, int ND>
 __device__ __forceinline__ void lk_interact_src(const typename vt<F>::v4 &s, int j, const typename vt<F>::v4 (&tp)[R],
                                                 F (&acc)[R][nres_of(Q)], F eps2, const int (&tidx)[R])

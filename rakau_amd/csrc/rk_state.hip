@@ -1040,8 +1040,8 @@ int rk_state_device_ptr(const rk_state *s, int what, void **ptr, int64_t *bytes)
                 *bytes = have ? (s->class2_off[RK_MAX_R] - s->class2_off[0]) * static_cast<int64_t>(sizeof(uint32_t)) : 0;
                 break;
             }
-            case 4: { // table of the light-tail arrangement (FIRST_TAB_WORDS uint32; null unless the tree came with one)
-                const bool have = s->first_tail_valid && s->first_tab;
+            case 4: { // queue table of the first-call order (FIRST_TAB_WORDS uint32; null unless the tree came with one)
+                const bool have = (s->first_tail_valid || s->first_order_valid) && s->first_tab;
                 *ptr = have ? s->first_tab : nullptr;
                 *bytes = have ? static_cast<int64_t>(rk::FIRST_TAB_WORDS * sizeof(uint32_t)) : 0;
                 break;

@@ -143,8 +143,8 @@ class State:
 
     def device_ptr(self, what):
         """(address, bytes) of a resident array: 'parts' ({x,y,z,m} AoS, Morton order), 'perm' (uint32), 'codes',
-        'first_order' (launch order of the first call: critical-node indices, uint32), 'first_tab' (queue table of the light-tail
-        arrangement of a large tree, 72 uint32; (0, 0) unless the tree came with one)."""
+        'first_order' (launch order of the first call: critical-node indices, uint32), 'first_tab' (queue table of that order,
+        72 uint32: eight queues for a small tree, queues per class and region for a large one; (0, 0) unless the tree came with one)."""
         ptr = C.c_void_p()
         nbytes = C.c_int64()
         sel = {"parts": 0, "perm": 1, "codes": 2, "first_order": 3, "first_tab": 4}[what]

@@ -321,9 +321,9 @@ def class2_of(size):
 def test_first_call_launch_order_made_on_the_device(n, ncrit):
     """Trees come with the launch order of their first call, made on the device with the tree (rk_build.hip bin_classes) -- for
     trees built on the device, for host trees converted there and for replicas.
-    Up to 49152 critical nodes: the critical nodes the wave kernels serve by decreasing size (in steps of two), ties in Morton order
-    -- the heavy-first order repeated calls get from the host; every such node exactly once, oversized nodes (ncrit = 1300) left
-    to their own kernel.
+    Up to 49152 critical nodes: eight queues, one per XCD region (eighths of the particle range), the critical nodes the wave kernels
+    serve inside a queue by decreasing size (in steps of eight), ties in Morton order -- the heavy-first queues repeated calls get
+    from the host; every such node exactly once, oversized nodes (ncrit = 1300) left to their own kernel.
     Beyond (up to 250000): the light-tail arrangement repeated calls get from the host -- per lane-mapping class and per XCD region
     (eight regions of equal particle count) one queue: the nodes of the region in Morton order, those below the first quartile of
     the class's sizes (estimated on a sample of at most 8192 nodes) at the end.
@@ -348,10 +348,19 @@ def test_first_call_launch_order_made_on_the_device(n, ncrit):
         size = (cr[:, 1] - cr[:, 0]).astype(np.int64)
         wave = np.flatnonzero(size <= 256)
         if len(cr) <= 49152:
-            assert st.device_ptr("first_tab") == (0, 0)
+            # eight queues, one per XCD region; inside a queue sizes in steps of eight (those below sixteen together), ties in Morton order
             got = fetch(st, "first_order", len(wave))
-            expect = wave[np.lexsort((wave, (256 - size[wave]) >> 1))]  # sizes in steps of two, ties in Morton order
-            assert np.array_equal(got, expect)
+            tab = fetch(st, "first_tab", 72)
+            region = np.minimum(7, cr[wave, 0].astype(np.int64) * 8 // n)
+            bucket = np.minimum(30, (256 - size[wave]) >> 3)
+            pos = 0
+            for xr in range(8):
+                sel = wave[region == xr]
+                expect = sel[np.lexsort((sel, bucket[region == xr]))]
+                assert tab[xr] == pos and tab[8 + xr] == len(expect), (xr, tab[:16])
+                assert np.array_equal(got[pos:pos + len(expect)], expect), xr
+                pos += len(expect)
+            assert pos == len(wave)
         else:
             got = fetch(st, "first_order", len(wave))
             tab = fetch(st, "first_tab", 72)
